@@ -1,0 +1,46 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def golden_spec(name="state_dict_spec"):
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        return [(k, tuple(s), d) for k, s, d in json.load(f)]
+
+
+@pytest.fixture(scope="session")
+def det_sd():
+    from oracle.weights import det_tensor
+    return {k: det_tensor(k, s) for k, s, _ in golden_spec()}
+
+
+@pytest.fixture(scope="session")
+def det_sd_concat():
+    from oracle.weights import det_tensor
+    return {k: det_tensor(k, s) for k, s, _ in golden_spec("state_dict_spec_concat")}

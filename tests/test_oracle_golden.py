@@ -1,0 +1,165 @@
+"""The oracle (oracle/ffraft_ref.py) against vectors produced by the reference.
+
+CPU-only.  This is what makes the oracle a *pinned* checker: every fixture was
+written by tests/golden/make_golden.py from the reference's own modules.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ffraft_ref as orc
+
+torch.set_num_threads(8)
+
+
+def crc(t):
+    return zlib.crc32(t.contiguous().numpy().tobytes())
+
+
+CASES = {
+    "fwd_rand_128x192_b2_it12": (lambda: orc.synthetic_inputs(2, 128, 192, seed=0), 12),
+    "fwd_shift_128x192_b2_it12": (lambda: orc.shifted_pair(2, 128, 192, seed=1), 12),
+    "fwd_shift_128x160_b1_it4_init": (lambda: orc.shifted_pair(1, 128, 160, seed=2), 4),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_matches_reference(name, det_sd):
+    g = load_golden(name)
+    make, iters = CASES[name]
+    inp = make()
+    assert [crc(inp[0]), crc(inp[1]), crc(inp[2])] == g["in_crc"].tolist(), "synthetic inputs drifted"
+    finit = torch.from_numpy(g["flow_init"]) if "flow_init" in g else None
+    taps = {}
+    with torch.no_grad():
+        flow_low, flow_up = orc.ffraft_forward(det_sd, *inp, raft_iters=iters, flow_init=finit,
+                                               test_mode=True, taps=taps)
+        preds = orc.ffraft_forward(det_sd, *inp, raft_iters=iters, flow_init=finit)
+    # Same ATen kernels on the same machine class: expect (near) bit equality.
+    tol = dict(rtol=2e-6, atol=2e-5)
+    np.testing.assert_allclose(taps["fmap1"][:, ::4].numpy(), g["fmap1"], **tol)
+    np.testing.assert_allclose(taps["fmap2"][:, ::4].numpy(), g["fmap2"], **tol)
+    np.testing.assert_allclose(taps["cnet"][:, ::4].numpy(), g["cnet"], **tol)
+    np.testing.assert_allclose(taps["pyramid"][3].numpy(), g["pyr3"], **tol)
+    np.testing.assert_allclose(taps["pyramid"][2].numpy(), g["pyr2"], **tol)
+    np.testing.assert_allclose(taps["pyramid"][1][::37].numpy(), g["pyr1_rows"], **tol)
+    np.testing.assert_allclose(taps["pyramid"][0][::37].numpy(), g["pyr0_rows"], **tol)
+    b, _, h8, w8 = taps["fmap1"].shape
+    c0 = orc.coords_grid(b, h8, w8)
+    np.testing.assert_allclose(orc.corr_lookup(taps["pyramid"], c0)[:1].numpy(), g["look0"], **tol)
+    crand = torch.from_numpy(g["crand"])
+    pyr_b0 = [p[: h8 * w8] for p in taps["pyramid"]]
+    np.testing.assert_allclose(orc.corr_lookup(pyr_b0, crand).numpy(), g["look_rand"], **tol)
+    np.testing.assert_allclose(flow_low.numpy(), g["flow_low"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(flow_up.numpy(), g["flow_up"], rtol=0, atol=1e-4)
+    assert len(preds) == int(g["n_preds"][0])
+    np.testing.assert_allclose(preds[0].numpy(), g["pred_first"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(preds[len(preds) // 2].numpy(), g["pred_mid"], rtol=0, atol=1e-4)
+    # the explicit (index-replaying) lookup agrees with the grid_sample route
+    ex = orc.corr_lookup_explicit(pyr_b0, crand)
+    np.testing.assert_allclose(ex.numpy(), g["look_rand"], rtol=2e-6, atol=5e-5)
+
+
+def test_update_block_internals(det_sd):
+    g = load_golden("fwd_shift_128x192_b2_it12")
+    inp = orc.shifted_pair(2, 128, 192, seed=1)
+    taps = {}
+    with torch.no_grad():
+        orc.ffraft_forward(det_sd, *inp, raft_iters=1, test_mode=True, taps=taps)
+    it0 = taps["iters"][0]
+    np.testing.assert_allclose(it0["net"][:, ::8].numpy(), g["net1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(it0["up_mask"][:, ::16].numpy(), g["up_mask1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(it0["delta"].numpy(), g["delta1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(it0["flow_up"].numpy(), g["up1"], rtol=0, atol=2e-4)
+
+
+def test_384x512_config1(det_sd):
+    g = load_golden("fwd_shift_384x512_b1_it12")
+    inp = orc.shifted_pair(1, 384, 512, seed=6)
+    assert [crc(inp[0]), crc(inp[1]), crc(inp[2])] == g["in_crc"].tolist()
+    with torch.no_grad():
+        flow_low, flow_up = orc.ffraft_forward(det_sd, *inp, raft_iters=12, test_mode=True)
+    np.testing.assert_allclose(flow_low.numpy(), g["flow_low"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(flow_up[:, :, ::4, ::4].numpy(), g["flow_up_sub"], rtol=0, atol=2e-4)
+
+
+def test_concat_fusion(det_sd_concat):
+    g = load_golden("fwd_concat_128x160_b1_it4")
+    inp = orc.shifted_pair(1, 128, 160, seed=8)
+    with torch.no_grad():
+        fl, fu = orc.ffraft_forward(det_sd_concat, *inp, raft_iters=4, test_mode=True, fusion_type="concat")
+    np.testing.assert_allclose(fu.numpy(), g["flow_up"], rtol=0, atol=1e-4)
+
+
+def test_train_step_matches_reference(det_sd):
+    """Train-mode forward (BN batch statistics) + sequence L1 + autograd."""
+    g = load_golden("train_shift_128x128_b2_it3")
+    inp = orc.shifted_pair(2, 128, 128, seed=4)
+    gen = torch.Generator().manual_seed(5)
+    flow_gt = (torch.randn(2, 2, 128, 128, generator=gen) * 5).clamp(-400, 400)
+    assert crc(flow_gt) == int(g["flow_gt_crc"][0])
+    valid = torch.ones(2, 128, 128)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+          for k, v in det_sd.items()}
+    preds = orc.ffraft_forward(sd, *inp, raft_iters=3, training=True)
+    loss, _ = orc.sequence_l1(preds, flow_gt, valid)
+    loss.backward()
+    assert abs(loss.item() - g["loss"][0]) < 1e-4
+    for key in [k for k in g if k.startswith("grad:")]:
+        name = "flow_net." + key[5:]
+        # norm3 and downsample.1 are one module in the reference; the gradient
+        # arrives on the key the oracle reads (downsample.1)
+        name = name.replace(".norm3.", ".downsample.1.")
+        gk = sd[name].grad
+        got = gk.flatten()[:: max(1, gk.numel() // 512)].numpy()
+        np.testing.assert_allclose(got, g[key], rtol=1e-3, atol=2e-4 * max(1.0, float(np.abs(g[key]).max())))
+    for key in [k for k in g if k.startswith("buf:")]:
+        np.testing.assert_allclose(sd["flow_net." + key[4:]].numpy(), g[key], rtol=0, atol=1e-5)
+
+
+def test_sampler_index_math_matches_reference():
+    """lookup_taps' floor indices == the taps ATen actually touched."""
+    g = load_golden("sampler_index")
+    n_checked = 0
+    for key in [k for k in g if k.startswith("xs_")]:
+        h, w = map(int, key[3:].split("x"))
+        xs = torch.from_numpy(g[key])
+        n = xs.numel()
+        coords = torch.stack([xs, torch.full((n,), float(h // 2))], 0).view(1, 2, 1, n)
+        x0, y0, wx, wy = orc.lookup_taps(coords, [(h, w)])[0]
+        lo, cnt, wlo = g[f"lo_{h}x{w}"], g[f"cnt_{h}x{w}"], g[f"wlo_{h}x{w}"]
+        x0 = x0.numpy()
+        wx = wx.numpy()
+        two = cnt == 2  # both taps in bounds and both weights non-zero: unambiguous
+        assert (x0[two] == lo[two]).all(), f"{h}x{w}: floor index differs from the reference sampler"
+        np.testing.assert_allclose((1 - wx)[two], wlo[two], rtol=0, atol=3e-7)
+        one = cnt == 1  # upper weight exactly 0, or one tap out of range
+        ok = (x0[one] == lo[one]) | ((x0[one] == -1) & (lo[one] == 0)) | (wx[one] == 0)
+        assert ok.all()
+        none = cnt == 0
+        assert ((x0[none] < -1) | (x0[none] >= w) | ((x0[none] == -1) & (wx[none] == 0))).all()
+        n_checked += int(two.sum())
+    assert n_checked > 10000
+    plane = torch.from_numpy(g["kat_plane"])
+    pts = torch.from_numpy(g["kat_pts"]).view(1, 9, 2)
+    coords = pts.permute(0, 2, 1).reshape(1, 2, 1, 9)
+    x0, y0, wx, wy = orc.lookup_taps(coords, [(48, 64)])[0]
+    vals = []
+    for i in range(9):
+        acc = 0.0
+        for dy, wyv in ((0, 1 - wy[i, 4]), (1, wy[i, 4])):
+            for dx, wxv in ((0, 1 - wx[i, 4]), (1, wx[i, 4])):
+                xx, yy = int(x0[i, 4]) + dx, int(y0[i, 4]) + dy
+                if 0 <= xx < 64 and 0 <= yy < 48:
+                    acc += float(plane[0, 0, yy, xx] * wxv * wyv)
+        vals.append(acc)
+    np.testing.assert_allclose(np.array(vals), g["kat_out"].reshape(-1), rtol=0, atol=1e-5)
+
+
+def test_upsample_known_answer():
+    g = load_golden("upsample")
+    out = orc.upsample_flow(torch.from_numpy(g["flow"]), torch.from_numpy(g["mask"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=1e-6)
