@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""FF-RAFT hot-path benchmark (BASELINE.json metric: frame-pairs/sec, 384x512, iters=12).
+
+One process per GPU.  A "step" = one forward pass of the full hot path
+(CCE encoders -> corr volume + pyramid -> 12 x {lookup, update block, convex
+upsample}) over one batch of synthetic frame pairs already resident in HBM.
+Forward is embarrassingly data-parallel: ranks hold independent batches, no
+data-path collective ("scaling": "weak").
+
+Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
+  roofline     - the CorrBlock lookup kernel (HBM-bound), timed live with HIP
+                 events on the launch stream inside the timed region
+  cpu_baseline - the CPU oracle (a restatement of the reference pinned by golden
+                 vectors; kind "port") timed on this box's host cores, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+LOOKUP_BYTES_PER_QUERY = 2904  # 4*100*4 (windows) + 4*81*4 (output) + 8 (coords)
+
+
+def cfg():
+    from argparse import Namespace
+    return Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"),
+                     MODEL=Namespace(FUSION_TYPE="1x1conv", LOAD_MODULE_TO_BRANCH=False))
+
+
+def shard_units(total_units: int, world: int, rank: int):
+    """Contiguous split of `total_units` independent frame pairs over ranks."""
+    base, rem = divmod(total_units, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def synthetic_batch(b, h, w, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    i1 = torch.randint(0, 256, (b, 3, h, w), generator=g).float()
+    i2 = torch.roll(i1, shifts=(3, -5), dims=(2, 3)) + torch.randn(b, 3, h, w, generator=g) * 2
+    m1 = (torch.rand(b, 1, h, w, generator=g) < 500.0 / (h * w)).float() * 255   # ORB-like, 500 points
+    return [t.contiguous().to(device) for t in (i1, i2.clamp(0, 255), m1, torch.zeros_like(m1))]
+
+
+def cpu_baseline(h, w, iters, budget_s=20.0):
+    """Time the CPU oracle on the SAME workload shape (B=1), bounded to ~budget_s."""
+    from oracle import ffraft_ref as orc
+    from oracle.weights import det_tensor
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_spec.json")) as f:
+        sd = {k: det_tensor(k, s) for k, s, _ in json.load(f)}
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    inp = orc.shifted_pair(1, h, w, seed=1234)
+    with torch.no_grad():
+        orc.ffraft_forward(sd, *inp, raft_iters=iters, test_mode=True)  # warm-up
+        times = []
+        t_end = time.perf_counter() + budget_s
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
+            t0 = time.perf_counter()
+            orc.ffraft_forward(sd, *inp, raft_iters=iters, test_mode=True)
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} forwards of B=1 {h}x{w} iters={iters} fp32 (median {med * 1e3:.1f} ms), "
+                      f"oracle/ffraft_ref.py on torch CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frame pairs per GPU per step (BASELINE config 2: 8)")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from focusflow_official_amd import FF_RAFT_FUSION, ops
+    torch.manual_seed(1234)
+    model = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
+    # weak scaling: every rank owns args.batch independent pairs of the global batch
+    lo, hi = shard_units(args.batch * world, world, rank)
+    batch = synthetic_batch(hi - lo, args.height, args.width, 1234 + rank, device)
+
+    def step():
+        with torch.no_grad():
+            return model(*batch, raft_iters=args.iters, test_mode=True)
+
+    for _ in range(args.warmup):
+        step()
+    ops.profile_begin("ff_corr_lookup_fwd")          # HIP events around every lookup launch
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    lookup_ms = ops.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(out[1]).all()
+
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        q = (hi - lo) * (args.height // 8) * (args.width // 8)
+        per_launch_ms = sum(lookup_ms) / max(1, len(lookup_ms))
+        achieved = LOOKUP_BYTES_PER_QUERY * q / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        line = {
+            "metric": "frame-pairs/sec FF-RAFT 384x512 iters=12", "value": round(pairs / elapsed, 3),
+            "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"FF-RAFT forward (test_mode), {args.batch} pairs/GPU {args.height}x{args.width}, "
+                                   f"iters={args.iters}, random-init weights, ORB-like masks (BASELINE configs[1])",
+                       "pairs_per_gpu": args.batch, "parallelism": f"dp{world} (independent shards, no collective)"},
+            "roofline": {"kernel": "lookup_kernel (ff_corr_lookup_fwd)", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches": len(lookup_ms), "avg_launch_us": round(per_launch_ms * 1e3, 2),
+                         "algorithmic_bytes_per_launch": LOOKUP_BYTES_PER_QUERY * q},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.height, args.width, args.iters)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""ctypes binding of libfocusflow_hip.so (the C ABI in include/focusflow_hip.h).
+
+There is NO fallback: if the library is missing, or a call is made without a
+HIP device, this raises.  PyTorch is only used by callers for device memory and
+streams; every pointer handed over here is ``tensor.data_ptr()``.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libfocusflow_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+MAX_SEG = 3
+_fp = C.c_void_p
+_ll = C.c_longlong
+
+
+class FFConvParams(C.Structure):
+    _fields_ = [
+        ("x", _fp * MAX_SEG), ("x_ld", C.c_int * MAX_SEG), ("x_c", C.c_int * MAX_SEG),
+        ("x_gstride", _ll * MAX_SEG), ("groups", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("w", _fp), ("w_gstride", _ll), ("bias", _fp), ("ch_scale", _fp), ("ch_shift", _fp),
+        ("out_scale", C.c_float), ("res", _fp), ("res_ld", C.c_int), ("y", _fp), ("y_ld", C.c_int),
+        ("y_gstride", _ll), ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
+        ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
+        ("act", C.c_int), ("act_res", C.c_int),
+    ]
+
+
+# name -> argtypes; every function returns int (0 = ok) except the two below
+_SIGS = {
+    "ff_conv2d_fwd": [C.POINTER(FFConvParams), _fp],
+    "ff_pack_conv_weight": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp],
+    "ff_norm_stats": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
+    "ff_norm_apply": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_float,
+                      _fp, _fp, C.c_int, _fp, C.c_int, _fp],
+    "ff_bn_fold": [_fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_int, _fp],
+    "ff_bn_update_running": [_fp, _ll, C.c_float, _fp, _fp, C.c_int, _fp],
+    "ff_prep_input": [_fp, C.c_int, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_corr_pyramid": [_fp, _fp, _fp, _fp, _ll, C.c_int, C.c_int, _fp],
+    "ff_corr_lookup_fwd": [C.POINTER(_fp), C.c_int, C.c_int, _fp, _ll, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp],
+    "ff_act_copy": [_fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
+    "ff_coords_init": [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_coords_step": [_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_gru_rh": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
+    "ff_gru_blend": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
+    "ff_upsample_flow": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_nhwc_to_nchw": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+}
+EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version"])
+
+_lib = None
+
+
+class FocusFlowHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FocusFlowHipError(
+            f"{LIB_PATH} is missing: build it with `python -m focusflow_official_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.ff_last_error.restype = C.c_char_p
+    lib.ff_last_error.argtypes = []
+    lib.ff_abi_version.restype = C.c_int
+    lib.ff_abi_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise FocusFlowHipError(f"{name} failed ({rc}): {lib.ff_last_error().decode()}")

@@ -1,0 +1,228 @@
+"""Condition Control Encoder (FFE + CFE with fusion units) on the HIP path.
+
+Mirrors the reference's module tree so that ``state_dict()`` keys and shapes
+are interchangeable (parallel_fusion.py:153-274, extractor.py:6-56,118-192),
+but the modules below only HOLD parameters: ``nn.Conv2d`` / ``nn.BatchNorm2d``
+instances are never called.  The forward is a sequence of libfocusflow_hip
+launches on NHWC fp32 tensors.
+"""
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU
+
+EPS = 1e-5
+
+
+class PackedConv:
+    """Cache of one (or several Cout-concatenated) nn.Conv2d in kernel layout.
+
+    Packed rows are [Cout][KH][KW][cin_pad]; re-packed by ff_pack_conv_weight
+    whenever a source parameter changes (version counter) or moves.
+    """
+
+    def __init__(self, convs: Sequence[nn.Conv2d], cin_pad: Optional[int] = None):
+        self.convs = list(convs)
+        c0 = self.convs[0]
+        self.kh, self.kw = c0.kernel_size
+        self.stride = c0.stride[0]
+        self.pad = tuple(c0.padding)
+        self.cin = c0.in_channels
+        self.cin_pad = cin_pad if cin_pad is not None else (self.cin + 3) // 4 * 4
+        self.cout = sum(c.out_channels for c in self.convs)
+        for c in self.convs:
+            assert c.kernel_size == c0.kernel_size and c.in_channels == c0.in_channels and c.stride == c0.stride
+        self._key = None
+        self.w = None
+        self.b = None
+
+    def get(self):
+        key = tuple((c.weight._version, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()) for c in self.convs)
+        if key != self._key:
+            dev = self.convs[0].weight.device
+            self.w = torch.empty((self.cout, self.kh * self.kw * self.cin_pad), dtype=torch.float32, device=dev)
+            self.b = torch.empty(self.cout, dtype=torch.float32, device=dev)
+            off = 0
+            for c in self.convs:
+                ops.pack_conv_weight(c.weight.detach(), self.w, self.cin_pad, off)
+                self.b[off:off + c.out_channels].copy_(c.bias.detach())  # device memcpy
+                off += c.out_channels
+            self._key = key
+        return self.w, self.b
+
+    def __call__(self, xs, act=ACT_NONE, **kw):
+        w, b = self.get()
+        if not isinstance(xs, (list, tuple)):
+            xs = [xs]
+        return ops.conv2d(xs, w, b, self.cout, self.kh, self.kw, self.stride, self.pad, act=act, **kw)
+
+
+def _make_norm(kind: str, c: int):
+    if kind == "batch":
+        return nn.BatchNorm2d(c)
+    if kind == "instance":
+        return nn.InstanceNorm2d(c)  # no parameters, no buffers: contributes no state_dict keys
+    if kind == "none":
+        return nn.Sequential()
+    raise ValueError(f"norm_fn {kind} is not supported on the HIP path")
+
+
+class ResidualBlock(nn.Module):
+    """Parameter holder with the reference's names (extractor.py:6-46)."""
+
+    def __init__(self, in_planes, planes, norm_fn, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1)
+        self.norm1 = _make_norm(norm_fn, planes)
+        self.norm2 = _make_norm(norm_fn, planes)
+        self.stride = stride
+        self.downsample = None
+        if stride != 1:
+            # the reference registers this norm twice: as norm3 and as downsample.1
+            self.norm3 = _make_norm(norm_fn, planes)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride), self.norm3)
+        self._p1, self._p2 = PackedConv([self.conv1]), PackedConv([self.conv2])
+        self._pd = PackedConv([self.downsample[0]]) if stride != 1 else None
+
+
+class _FusionConv(nn.Module):
+    """Conv1x1 / Concat fusion operators (parallel_fusion.py:76-95): `.conv` only."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 1)
+        self._p = PackedConv([self.conv])
+
+
+class FusionUnit(nn.Module):
+    """parallel_fusion.py:98-150 for the '1x1conv', '1x1conv-unidirection' and 'concat' types."""
+
+    def __init__(self, c, fusion_type, bi_direction=True):
+        super().__init__()
+        self.fusion_type = fusion_type
+        if fusion_type in ("1x1conv", "1x1conv-unidirection"):
+            self.mask2img = _FusionConv(c, c)
+            self.img2mask = _FusionConv(c, c) if (bi_direction and fusion_type == "1x1conv") else None
+        elif fusion_type == "concat":
+            self.mask2img = _FusionConv(2 * c, c)
+            self.img2mask = _FusionConv(2 * c, c) if bi_direction else None
+        elif fusion_type in ("SA", "CA"):
+            raise NotImplementedError(f"fusion type {fusion_type} is not built on the HIP path yet (SURVEY §8f-3)")
+        else:
+            raise ValueError(f"Fusion type {fusion_type} not supported.")
+
+    def run(self, mask, img):
+        if self.fusion_type == "concat":
+            img_out = self.mask2img._p([img, mask])
+            mask_out = self.img2mask._p([mask, img]) if self.img2mask is not None else mask
+        else:  # out = q + conv1x1(v): the residual add rides in the conv epilogue
+            img_out = self.mask2img._p(mask, res=img)
+            mask_out = self.img2mask._p(img, res=mask) if self.img2mask is not None else mask
+        return mask_out, img_out
+
+
+class BasicParallelFusionLayer(nn.Module):
+    """CCE = frame branch (FFE) + condition branch (CFE) + 5 fusion units.
+
+    Same constructor and attribute names as parallel_fusion.py:153-209; call
+    with NHWC4 tensors from ops.prep_input, returns NHWC (B, H/8, W/8, output_dim).
+    """
+
+    def __init__(self, img_channel=3, mask_channel=3, output_dim=128, norm_fn="batch", dropout=0, cfg=None):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.fusion_type = cfg.MODEL.FUSION_TYPE
+        if dropout and dropout > 0:
+            raise NotImplementedError("dropout > 0 is not used by any reference config and is not built")
+        self.norm1 = _make_norm(norm_fn, 64)
+        self.conv1 = nn.Conv2d(img_channel, 64, 7, stride=2, padding=3)
+        self.layer1 = self._stage(64, 64, 1)
+        self.layer2 = self._stage(64, 96, 2)
+        self.layer3 = self._stage(96, 128, 2)
+        self.conv2 = nn.Conv2d(128, output_dim, 1)
+        self.mask_norm1 = _make_norm(norm_fn, 64)
+        self.mask_conv1 = nn.Conv2d(mask_channel, 64, 7, stride=2, padding=3)
+        self.fusion1 = FusionUnit(64, self.fusion_type, True)
+        self.fusion2 = FusionUnit(64, self.fusion_type, True)
+        self.fusion3 = FusionUnit(96, self.fusion_type, True)
+        self.fusion4 = FusionUnit(128, self.fusion_type, True)
+        self.fusion5 = FusionUnit(output_dim, self.fusion_type, False)
+        self.mask_layer1 = self._stage(64, 64, 1)
+        self.mask_layer2 = self._stage(64, 96, 2)
+        self.mask_layer3 = self._stage(96, 128, 2)
+        self.mask_conv2 = nn.Conv2d(128, output_dim, 1)
+        self.dropout = None
+        # parallel_fusion.py:198-205 initialisation
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._stem = PackedConv([self.conv1], 4)
+        self._mstem = PackedConv([self.mask_conv1], 4)
+        self._out = PackedConv([self.conv2])
+        self._mout = PackedConv([self.mask_conv2])
+
+    def _stage(self, cin, cout, stride):
+        return nn.Sequential(ResidualBlock(cin, cout, self.norm_fn, stride), ResidualBlock(cout, cout, self.norm_fn, 1))
+
+    # -- execution ---------------------------------------------------------
+    def _conv_norm(self, x, pc: PackedConv, norm, act, res=None):
+        """act(norm(conv(x))) and, with `res`, relu(res + that)."""
+        if self.norm_fn == "instance":
+            y = pc(x)
+            st = ops.norm_stats(y, per_sample=True)
+            return ops.norm_apply(y, st, True, EPS, act=act, res=res, out=y)
+        if self.norm_fn == "batch":
+            if norm.training:
+                y = pc(x)
+                st = ops.norm_stats(y, per_sample=False)
+                b, h, w, _ = y.shape
+                ops.bn_update_running(norm, st, b * h * w)
+                norm.num_batches_tracked += 1
+                return ops.norm_apply(y, st, False, norm.eps, norm.weight, norm.bias, act=act, res=res, out=y)
+            sc, sh = ops.bn_fold(norm)  # eval: scale/shift ride in the conv epilogue
+            return pc(x, act=act, ch_scale=sc, ch_shift=sh, res=res, act_res=ACT_RELU)
+        return pc(x, act=act, res=res, act_res=ACT_RELU)  # 'none'
+
+    def _block(self, blk: ResidualBlock, x):
+        y = self._conv_norm(x, blk._p1, blk.norm1, ACT_RELU)
+        if blk.downsample is not None:
+            x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
+        return self._conv_norm(y, blk._p2, blk.norm2, ACT_RELU, res=x)
+
+    def _run_stage(self, stage, x):
+        return self._block(stage[1], self._block(stage[0], x))
+
+    def forward(self, x, mask):
+        m = self._conv_norm(mask, self._mstem, self.mask_norm1, ACT_RELU)
+        x = self._conv_norm(x, self._stem, self.norm1, ACT_RELU)
+        m, x = self.fusion1.run(m, x)
+        m, x = self._run_stage(self.mask_layer1, m), self._run_stage(self.layer1, x)
+        m, x = self.fusion2.run(m, x)
+        m, x = self._run_stage(self.mask_layer2, m), self._run_stage(self.layer2, x)
+        m, x = self.fusion3.run(m, x)
+        m, x = self._run_stage(self.mask_layer3, m), self._run_stage(self.layer3, x)
+        m, x = self.fusion4.run(m, x)
+        m, x = self._mout(m), self._out(x)
+        m, x = self.fusion5.run(m, x)
+        return x
+
+    # -- reference API -----------------------------------------------------
+    def freeze_self(self, mode):
+        if mode == "parallel":  # parallel_fusion.py:249-267: freeze the frame branch
+            for mod in (self.conv1, self.norm1, self.layer1, self.layer2, self.layer3, self.conv2):
+                for p in mod.parameters():
+                    p.requires_grad = False
+
+    def copy_to_branch(self):  # parallel_fusion.py:269-274
+        self.mask_conv1.load_state_dict(self.conv1.state_dict())
+        self.mask_layer1.load_state_dict(self.layer1.state_dict())
+        self.mask_layer2.load_state_dict(self.layer2.state_dict())
+        self.mask_layer3.load_state_dict(self.layer3.state_dict())
+        self.mask_conv2.load_state_dict(self.conv2.state_dict())

@@ -1,0 +1,28 @@
+"""CorrBlock on the HIP path (corr.py:12-60): all-pairs volume on the fp32 matrix
+pipe, 4-level average-pool pyramid, radius-4 bilinear window lookup."""
+from typing import List
+
+import torch
+
+from . import ops
+
+
+class CorrBlock:
+    """Same call protocol as the reference: build once per pair, call per iteration.
+
+    fmap1/fmap2: NHWC (B, H8, W8, C) fp32.  ``__call__(coords)`` takes NHWC
+    (B, H8, W8, 2) [x, y] coordinates and returns NHWC (B, H8, W8, levels*(2r+1)^2).
+    HBM layout: level l is [B*Q][h_l][w_l] row-major fp32 planes (Q = H8*W8).
+    """
+
+    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4):
+        if num_levels != 4:
+            raise NotImplementedError("the pyramid kernel builds exactly 4 levels (all reference configs)")
+        self.num_levels = num_levels
+        self.radius = radius
+        b, h, w, _ = fmap1.shape
+        vol = ops.corr_volume(fmap1.contiguous(), fmap2.contiguous())
+        self.corr_pyramid: List[torch.Tensor] = ops.corr_pyramid(vol, h, w)
+
+    def __call__(self, coords: torch.Tensor, want_taps: bool = False):
+        return ops.corr_lookup(self.corr_pyramid, coords, self.radius, want_taps)

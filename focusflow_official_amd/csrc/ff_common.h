@@ -1,0 +1,42 @@
+// Shared helpers for libfocusflow_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "focusflow_hip.h"
+
+namespace ff {
+
+char* err_buf();  // thread-local, defined in api.hip
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define FF_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return ff::fail(FF_EINVAL, __VA_ARGS__);   \
+    } while (0)
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FF_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return FF_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case FF_ACT_RELU: return v > 0.f ? v : 0.f;
+        case FF_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case FF_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+}  // namespace ff

@@ -1,0 +1,162 @@
+// InstanceNorm2d / BatchNorm2d on NHWC activations (HBM-bound, 16-byte accesses).
+//
+//   ff_norm_stats : one pass; a thread owns 4 channels (one float4 per pixel),
+//                   a block walks a slab of pixels, partial sums are kept in fp64
+//                   and merged with fp64 atomics into stats[s][c] = {sum, sumsq}.
+//   ff_norm_apply : y = act((x-mean)*rstd*gamma+beta), optional residual+relu.
+#include "ff_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SLAB = 2048;  // pixels per block
+
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, int ld, int HW, int C,
+                                                         int per_sample, double* __restrict__ stats) {
+    __shared__ double red[256 * 8];
+    const int cg = C >> 2;               // float4 groups per pixel
+    const int lanes_pix = 256 / cg;      // pixels handled per step (cg divides 256)
+    const int t = threadIdx.x;
+    const int g = t % cg, pl = t / cg;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * SLAB;
+    const int p1 = min(p0 + SLAB, HW);
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (pl < lanes_pix) {
+        const float* base = x + ((long long)b * HW) * ld + g * 4;
+        for (int p = p0 + pl; p < p1; p += lanes_pix) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * ld);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double d = (double)v[j];
+                s[j] += d;
+                q[j] += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[t * 8 + j] = s[j];
+        red[t * 8 + 4 + j] = q[j];
+    }
+    __syncthreads();
+    // threads 0..C-1 each finish one channel
+    if (t < C) {
+        const int gg = t >> 2, j = t & 3;
+        double ss = 0, qq = 0;
+        for (int k = 0; k < lanes_pix; ++k) {
+            ss += red[(k * cg + gg) * 8 + j];
+            qq += red[(k * cg + gg) * 8 + 4 + j];
+        }
+        double* dst = stats + ((long long)(per_sample ? b : 0) * C + t) * 2;
+        atomicAdd(dst, ss);
+        atomicAdd(dst + 1, qq);
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, int ld, float* __restrict__ y,
+                                                         int y_ld, int HW, int C, const double* __restrict__ stats,
+                                                         int per_sample, double inv_count, float eps,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int act, const float* __restrict__ res, int res_ld) {
+    __shared__ float s_mul[256], s_add[256];
+    const int b = blockIdx.y;
+    const int t = threadIdx.x;
+    if (t < C) {
+        const double* st = stats + ((long long)(per_sample ? b : 0) * C + t) * 2;
+        const double mean = st[0] * inv_count;
+        double var = st[1] * inv_count - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float gm = gamma ? gamma[t] : 1.f;
+        const float bt = beta ? beta[t] : 0.f;
+        s_mul[t] = rstd * gm;
+        s_add[t] = bt - (float)mean * rstd * gm;
+    }
+    __syncthreads();
+    const int cg = C >> 2;
+    const int total = HW * cg;
+    const float* xb = x + (long long)b * HW * ld;
+    float* yb = y + (long long)b * HW * y_ld;
+    const float* rb = res ? res + (long long)b * HW * res_ld : nullptr;
+    for (int i = blockIdx.x * 256 + t; i < total; i += gridDim.x * 256) {
+        const int g = i % cg;
+        const long long p = i / cg;
+        f32x4 v = *reinterpret_cast<const f32x4*>(xb + p * ld + g * 4);
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (rb) r = *reinterpret_cast<const f32x4*>(rb + p * res_ld + g * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float o = v[j] * s_mul[g * 4 + j] + s_add[g * 4 + j];
+            o = ff::apply_act(o, act);
+            if (rb) { o += r[j]; o = o > 0.f ? o : 0.f; }
+            v[j] = o;
+        }
+        *reinterpret_cast<f32x4*>(yb + p * y_ld + g * 4) = v;
+    }
+}
+
+__global__ void bn_fold_kernel(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
+                               float* sc, float* sh, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float inv = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f;
+    sc[c] = inv * g;
+    sh[c] = (beta ? beta[c] : 0.f) - rm[c] * inv * g;
+}
+
+__global__ void bn_update_kernel(const double* stats, double count, float momentum, float* rm, float* rv, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stats[c * 2] / count;
+    double var = stats[c * 2 + 1] / count - mean * mean;
+    if (var < 0) var = 0;
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+}
+
+}  // namespace
+
+extern "C" int ff_norm_stats(const float* x, int ld, int B, int HW, int C, int per_sample, double* stats, void* stream) {
+    FF_REQUIRE(x && stats, "ff_norm_stats: null pointer");
+    FF_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 256, "ff_norm_stats: C=%d must be a multiple of 4, <= 256", C);
+    FF_REQUIRE(ld >= C && ld % 4 == 0 && ff::aligned16(x), "ff_norm_stats: ld/alignment");
+    dim3 grid((HW + SLAB - 1) / SLAB, B);
+    norm_stats_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(x, ld, HW, C, per_sample, stats);
+    return ff::check_launch("ff_norm_stats");
+}
+
+extern "C" int ff_norm_apply(const float* x, int ld, float* y, int y_ld, int B, int HW, int C, const double* stats,
+                             int per_sample, float eps, const float* gamma, const float* beta, int act,
+                             const float* res, int res_ld, void* stream) {
+    FF_REQUIRE(x && y && stats, "ff_norm_apply: null pointer");
+    FF_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 256 && (long long)HW * C < (1ll << 32),
+               "ff_norm_apply: C=%d unsupported", C);
+    FF_REQUIRE(ld >= C && ld % 4 == 0 && y_ld >= C && y_ld % 4 == 0 && ff::aligned16(x) && ff::aligned16(y),
+               "ff_norm_apply: ld/alignment");
+    FF_REQUIRE(!res || (res_ld >= C && res_ld % 4 == 0 && ff::aligned16(res)), "ff_norm_apply: residual ld/alignment");
+    const double inv_count = 1.0 / ((double)HW * (per_sample ? 1 : B));
+    const long long total = (long long)HW * (C / 4);
+    int gx = (int)((total + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    dim3 grid(gx, B);
+    norm_apply_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(x, ld, y, y_ld, HW, C, stats, per_sample,
+                                                                          inv_count, eps, gamma, beta, act, res, res_ld);
+    return ff::check_launch("ff_norm_apply");
+}
+
+extern "C" int ff_bn_fold(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
+                          float* sc, float* sh, int C, void* stream) {
+    FF_REQUIRE(rm && rv && sc && sh && C > 0, "ff_bn_fold: bad argument");
+    bn_fold_kernel<<<(C + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(rm, rv, gamma, beta, eps, sc, sh, C);
+    return ff::check_launch("ff_bn_fold");
+}
+
+extern "C" int ff_bn_update_running(const double* stats, long long count, float momentum, float* rm, float* rv, int C,
+                                    void* stream) {
+    FF_REQUIRE(stats && rm && rv && C > 0 && count > 0, "ff_bn_update_running: bad argument");
+    bn_update_kernel<<<(C + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(stats, (double)count, momentum, rm, rv, C);
+    return ff::check_launch("ff_bn_update_running");
+}

@@ -1,0 +1,241 @@
+// Small HBM-bound kernels around the update block: input scaling, coordinate
+// bookkeeping, GRU gate arithmetic and the convex upsampler.
+#pragma clang fp contract(off)
+#include "ff_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ff_raft.py:142-145: x -> 2*(x/255) - 1, in that rounding order.
+__device__ __forceinline__ float scale255(float v) { return __fsub_rn(__fmul_rn(2.f, __fdiv_rn(v, 255.0f)), 1.0f); }
+
+__global__ void prep_input_kernel(const float* __restrict__ src, int src_c, float fill, float* __restrict__ dst,
+                                  int B, int HW) {
+    const long long total = (long long)B * HW;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / HW, p = i - b * HW;
+        f32x4 o;
+        if (!src) {
+            const float v = scale255(fill);
+            o = (f32x4){v, v, v, 0.f};
+        } else if (src_c == 1) {
+            const float v = scale255(src[b * HW + p]);
+            o = (f32x4){v, v, v, 0.f};
+        } else {
+            const float* s = src + b * 3 * HW + p;
+            o = (f32x4){scale255(s[0]), scale255(s[HW]), scale255(s[2ll * HW]), 0.f};
+        }
+        *reinterpret_cast<f32x4*>(dst + i * 4) = o;
+    }
+}
+
+__global__ void act_copy_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld,
+                                long long npix, int C, int act) {
+    const int cg = C >> 2;
+    const long long total = npix * cg;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / cg;
+        const int g = (int)(i - p * cg);
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + p * src_ld + g * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ff::apply_act(v[j], act);
+        *reinterpret_cast<f32x4*>(dst + p * dst_ld + g * 4) = v;
+    }
+}
+
+__global__ void coords_init_kernel(float* __restrict__ coords, const float* __restrict__ finit, int B, int H, int W) {
+    const int HW = H * W;
+    const long long total = (long long)B * HW;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / HW;
+        const int p = (int)(i - b * HW);
+        float x = (float)(p % W), y = (float)(p / W);
+        if (finit) {  // raft.py:211-212, flow_init is NCHW (B,2,H,W)
+            x = __fadd_rn(x, finit[(b * 2) * HW + p]);
+            y = __fadd_rn(y, finit[(b * 2 + 1) * HW + p]);
+        }
+        coords[i * 2] = x;
+        coords[i * 2 + 1] = y;
+    }
+}
+
+__global__ void coords_step_kernel(float* __restrict__ coords1, const float* __restrict__ delta, int delta_ld,
+                                   float* __restrict__ flow4, float* __restrict__ slot, int slot_ld, int B, int H,
+                                   int W) {
+    const int HW = H * W;
+    const long long total = (long long)B * HW;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        float x = coords1[i * 2], y = coords1[i * 2 + 1];
+        if (delta) {  // raft.py:223
+            x = __fadd_rn(x, delta[i * delta_ld]);
+            y = __fadd_rn(y, delta[i * delta_ld + 1]);
+            coords1[i * 2] = x;
+            coords1[i * 2 + 1] = y;
+        }
+        const float fx = __fsub_rn(x, (float)(p % W)), fy = __fsub_rn(y, (float)(p / W));  // raft.py:219
+        if (flow4) *reinterpret_cast<f32x4*>(flow4 + i * 4) = (f32x4){fx, fy, 0.f, 0.f};
+        if (slot) {
+            slot[i * slot_ld] = fx;
+            slot[i * slot_ld + 1] = fy;
+        }
+    }
+}
+
+__global__ void gru_rh_kernel(const float* __restrict__ r, int r_ld, const float* __restrict__ h, int h_ld,
+                              float* __restrict__ rh, int rh_ld, long long npix, int C) {
+    const int cg = C >> 2;
+    const long long total = npix * cg;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / cg;
+        const int g = (int)(i - p * cg);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(r + p * r_ld + g * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(h + p * h_ld + g * 4);
+        *reinterpret_cast<f32x4*>(rh + p * rh_ld + g * 4) = a * b;
+    }
+}
+
+__global__ void gru_blend_kernel(const float* __restrict__ z, int z_ld, const float* __restrict__ q, int q_ld,
+                                 const float* __restrict__ h, int h_ld, float* __restrict__ hn, int hn_ld,
+                                 long long npix, int C) {
+    const int cg = C >> 2;
+    const long long total = npix * cg;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / cg;
+        const int g = (int)(i - p * cg);
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + p * z_ld + g * 4);
+        const f32x4 qq = *reinterpret_cast<const f32x4*>(q + p * q_ld + g * 4);
+        const f32x4 hh = *reinterpret_cast<const f32x4*>(h + p * h_ld + g * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)  // (1-z)*h + z*q, update.py:49
+            o[j] = __fadd_rn(__fmul_rn(__fsub_rn(1.f, zz[j]), hh[j]), __fmul_rn(zz[j], qq[j]));
+        *reinterpret_cast<f32x4*>(hn + p * hn_ld + g * 4) = o;
+    }
+}
+
+// raft.py:159-170.  One block per coarse row (b, h); thread = (w, sub-pixel ij).
+// mask channel = k*64 + i*8 + j, k = ky*3+kx (F.unfold order); output row 8h+i, col 8w+j.
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ flow, int flow_ld,
+                                                       const float* __restrict__ mask, int mask_ld,
+                                                       float* __restrict__ out, int H, int W) {
+    const int b = blockIdx.y, h = blockIdx.x;
+    const long long rowpix = ((long long)b * H + h) * W;
+    const int HW8 = 64 * H * W;
+    for (int t = threadIdx.x; t < W * 64; t += 256) {
+        const int w = t >> 6, ij = t & 63, i = ij >> 3, j = ij & 7;
+        const float* m = mask + (rowpix + w) * mask_ld + ij;
+        float mv[9], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            mv[k] = m[k * 64];
+            mx = fmaxf(mx, mv[k]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            mv[k] = expf(mv[k] - mx);
+            den += mv[k];
+        }
+        float ox = 0.f, oy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = h + k / 3 - 1, xx = w + k % 3 - 1;
+            float fx = 0.f, fy = 0.f;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                const float* f = flow + (((long long)b * H + yy) * W + xx) * flow_ld;
+                fx = 8.f * f[0];
+                fy = 8.f * f[1];
+            }
+            const float wgt = mv[k] / den;
+            ox += wgt * fx;
+            oy += wgt * fy;
+        }
+        const long long o = (long long)b * 2 * HW8 + (long long)(8 * h + i) * (8 * W) + 8 * w + j;
+        out[o] = ox;
+        out[o + HW8] = oy;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int B, int HW,
+                                    int C) {
+    const long long total = (long long)B * C * HW;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % HW;
+        const long long bc = i / HW;
+        const int c = (int)(bc % C);
+        const long long b = bc / C;
+        dst[i] = src[(b * HW + p) * ld + c];
+    }
+}
+
+inline int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int ff_prep_input(const float* src, int src_c, float fill, float* dst, int B, int H, int W, void* stream) {
+    FF_REQUIRE(dst && B > 0 && H > 0 && W > 0, "ff_prep_input: bad argument");
+    FF_REQUIRE(!src || src_c == 1 || src_c == 3, "ff_prep_input: src_c must be 1 or 3 (got %d)", src_c);
+    FF_REQUIRE(ff::aligned16(dst), "ff_prep_input: dst not 16-byte aligned");
+    prep_input_kernel<<<grid_for((long long)B * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(src, src_c, fill, dst, B, H * W);
+    return ff::check_launch("ff_prep_input");
+}
+
+extern "C" int ff_act_copy(const float* src, int src_ld, float* dst, int dst_ld, long long npix, int C, int act,
+                           void* stream) {
+    FF_REQUIRE(src && dst && npix > 0 && C > 0 && C % 4 == 0, "ff_act_copy: bad argument");
+    FF_REQUIRE(src_ld % 4 == 0 && dst_ld % 4 == 0 && ff::aligned16(src) && ff::aligned16(dst), "ff_act_copy: alignment");
+    act_copy_kernel<<<grid_for(npix * (C / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(src, src_ld, dst, dst_ld, npix, C, act);
+    return ff::check_launch("ff_act_copy");
+}
+
+extern "C" int ff_coords_init(float* coords, const float* flow_init, int B, int H, int W, void* stream) {
+    FF_REQUIRE(coords && B > 0 && H > 0 && W > 0, "ff_coords_init: bad argument");
+    coords_init_kernel<<<grid_for((long long)B * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(coords, flow_init, B, H, W);
+    return ff::check_launch("ff_coords_init");
+}
+
+extern "C" int ff_coords_step(float* coords1, const float* delta, int delta_ld, float* flow4, float* slot, int slot_ld,
+                              int B, int H, int W, void* stream) {
+    FF_REQUIRE(coords1 && B > 0 && H > 0 && W > 0, "ff_coords_step: bad argument");
+    FF_REQUIRE(!delta || delta_ld >= 2, "ff_coords_step: delta_ld");
+    FF_REQUIRE(!flow4 || ff::aligned16(flow4), "ff_coords_step: flow4 alignment");
+    FF_REQUIRE(!slot || slot_ld >= 2, "ff_coords_step: slot_ld");
+    coords_step_kernel<<<grid_for((long long)B * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(coords1, delta, delta_ld, flow4, slot, slot_ld, B, H, W);
+    return ff::check_launch("ff_coords_step");
+}
+
+extern "C" int ff_gru_rh(const float* r, int r_ld, const float* h, int h_ld, float* rh, int rh_ld, long long npix,
+                         int C, void* stream) {
+    FF_REQUIRE(r && h && rh && npix > 0 && C > 0 && C % 4 == 0, "ff_gru_rh: bad argument");
+    FF_REQUIRE(r_ld % 4 == 0 && h_ld % 4 == 0 && rh_ld % 4 == 0 && ff::aligned16(r) && ff::aligned16(h) && ff::aligned16(rh), "ff_gru_rh: alignment");
+    gru_rh_kernel<<<grid_for(npix * (C / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(r, r_ld, h, h_ld, rh, rh_ld, npix, C);
+    return ff::check_launch("ff_gru_rh");
+}
+
+extern "C" int ff_gru_blend(const float* z, int z_ld, const float* q, int q_ld, const float* h, int h_ld, float* hn,
+                            int hn_ld, long long npix, int C, void* stream) {
+    FF_REQUIRE(z && q && h && hn && npix > 0 && C > 0 && C % 4 == 0, "ff_gru_blend: bad argument");
+    FF_REQUIRE(z_ld % 4 == 0 && q_ld % 4 == 0 && h_ld % 4 == 0 && hn_ld % 4 == 0 && ff::aligned16(z) && ff::aligned16(q) && ff::aligned16(h) && ff::aligned16(hn), "ff_gru_blend: alignment");
+    gru_blend_kernel<<<grid_for(npix * (C / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(z, z_ld, q, q_ld, h, h_ld, hn, hn_ld, npix, C);
+    return ff::check_launch("ff_gru_blend");
+}
+
+extern "C" int ff_upsample_flow(const float* flow, int flow_ld, const float* mask, int mask_ld, float* out, int B,
+                                int H, int W, void* stream) {
+    FF_REQUIRE(flow && mask && out && B > 0 && H > 0 && W > 0, "ff_upsample_flow: bad argument");
+    FF_REQUIRE(flow_ld >= 2 && mask_ld >= 576, "ff_upsample_flow: flow_ld/mask_ld too small");
+    dim3 grid(H, B);
+    upsample_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(flow, flow_ld, mask, mask_ld, out, H, W);
+    return ff::check_launch("ff_upsample_flow");
+}
+
+extern "C" int ff_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int H, int W, int C, void* stream) {
+    FF_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && ld >= C, "ff_nhwc_to_nchw: bad argument");
+    nhwc_to_nchw_kernel<<<grid_for((long long)B * H * W * C), 256, 0, static_cast<hipStream_t>(stream)>>>(src, ld, dst, B, H * W, C);
+    return ff::check_launch("ff_nhwc_to_nchw");
+}

@@ -1,0 +1,275 @@
+"""Tensor-level wrappers over the C ABI (device pointers in, device pointers out).
+
+Activations are NHWC fp32 torch tensors of shape (B, H, W, C) whose last dim is
+contiguous; a tensor may be a channel slice of a wider buffer (stride(2) = ld).
+torch is used for allocation and stream handles only — all arithmetic happens
+in libfocusflow_hip.so.
+"""
+import ctypes as C
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _hip
+from ._hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, FFConvParams  # noqa: F401
+
+Tensor = torch.Tensor
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Optional per-launch timing of ONE entry point with HIP events recorded on the
+# launch stream (bench.py's roofline leg).  Off unless profile_begin() is called.
+_prof_name = None
+_prof_events = []
+
+
+def profile_begin(name: str):
+    global _prof_name
+    _prof_name = name
+    _prof_events.clear()
+
+
+def profile_end():
+    """-> list of per-launch milliseconds (synchronises)."""
+    global _prof_name
+    _prof_name = None
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in _prof_events]
+    _prof_events.clear()
+    return ms
+
+
+def _timed_call(name, *args):
+    if _prof_name == name:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _hip.call(name, *args)
+        b.record()
+        _prof_events.append((a, b))
+    else:
+        _hip.call(name, *args)
+
+
+def _require_gpu(t: Tensor):
+    if not t.is_cuda:
+        raise _hip.FocusFlowHipError(
+            "the FF-RAFT hot path runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise _hip.FocusFlowHipError(f"fp32 tensors expected, got {t.dtype}")
+
+
+def _ld(t: Tensor) -> int:
+    """floats per pixel of an NHWC (B,H,W,C) view; checks it is pixel-dense."""
+    _require_gpu(t)
+    b, h, w, c = t.shape
+    ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else max(t.stride(0), c))
+    if t.stride(3) != 1 or (w > 1 and h > 1 and t.stride(1) != w * ld) or (b > 1 and t.stride(0) != h * w * ld):
+        raise _hip.FocusFlowHipError(f"not an NHWC view: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld
+
+
+def _p(t: Optional[Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def empty_nhwc(b, h, w, c, like: Tensor) -> Tensor:
+    return torch.empty((b, h, w, c), dtype=torch.float32, device=like.device)
+
+
+# ----------------------------------------------------------------------------
+def pack_conv_weight(w_oihw: Tensor, dst: Tensor, cin_pad: int, cout_offset: int = 0):
+    """OIHW parameter -> rows [cout_offset, cout_offset+Cout) of dst [rows][KH*KW*cin_pad]."""
+    _require_gpu(w_oihw)
+    co, ci, kh, kw = w_oihw.shape
+    assert dst.is_contiguous() and dst.shape[1] == kh * kw * cin_pad and dst.shape[0] >= cout_offset + co
+    _hip.call("ff_pack_conv_weight", _p(w_oihw.contiguous()), co, ci, kh, kw, _p(dst), cin_pad, cout_offset, _stream())
+
+
+def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: int, kh: int, kw: int,
+           stride: int = 1, pad=(0, 0), act: int = ACT_NONE, out: Optional[Tensor] = None,
+           res: Optional[Tensor] = None, act_res: int = ACT_NONE, ch_scale: Optional[Tensor] = None,
+           ch_shift: Optional[Tensor] = None, out_scale: float = 1.0) -> Tensor:
+    """Convolution over the channel-concatenation of `xs` (see FFConvParams)."""
+    if isinstance(pad, int):
+        pad = (pad, pad)
+    x0 = xs[0]
+    b, h, w, _ = x0.shape
+    ho = (h + 2 * pad[0] - kh) // stride + 1
+    wo = (w + 2 * pad[1] - kw) // stride + 1
+    if out is None:
+        out = empty_nhwc(b, ho, wo, (cout + 3) // 4 * 4, x0)[..., :cout] if cout % 4 else empty_nhwc(b, ho, wo, cout, x0)
+    p = FFConvParams()
+    cin = 0
+    for i, x in enumerate(xs):
+        assert x.shape[:3] == x0.shape[:3]
+        p.x[i] = x.data_ptr()
+        p.x_ld[i] = _ld(x)
+        p.x_c[i] = x.shape[3]
+        p.x_gstride[i] = 0
+        cin += x.shape[3]
+    assert wpack.is_contiguous() and wpack.shape[-1] == kh * kw * cin and wpack.shape[0] >= cout, \
+        f"packed weight {tuple(wpack.shape)} vs Cout {cout}, K {kh * kw * cin}"
+    p.groups, p.B, p.H, p.W = 1, b, h, w
+    p.w, p.w_gstride = wpack.data_ptr(), 0
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.ch_scale = ch_scale.data_ptr() if ch_scale is not None else None
+    p.ch_shift = ch_shift.data_ptr() if ch_shift is not None else None
+    p.out_scale = out_scale
+    p.res = res.data_ptr() if res is not None else None
+    p.res_ld = _ld(res) if res is not None else 0
+    p.y, p.y_ld, p.y_gstride = out.data_ptr(), _ld(out), 0
+    p.Ho, p.Wo, p.Cout = ho, wo, cout
+    p.KH, p.KW, p.stride, p.pad_h, p.pad_w = kh, kw, stride, pad[0], pad[1]
+    p.act, p.act_res = act, act_res
+    assert out.shape[:3] == (b, ho, wo) and out.shape[3] >= cout
+    _hip.call("ff_conv2d_fwd", C.byref(p), _stream())
+    return out
+
+
+def corr_volume(fmap1: Tensor, fmap2: Tensor) -> Tensor:
+    """corr.py:52-60: vol[b][i][j] = <f1[b,i,:], f2[b,j,:]> / sqrt(C) as a grouped 1x1 conv
+    whose per-sample weights are fmap2.  Returns (B, Q, Q) planes [B*Q][H8][W8]."""
+    b, h, w, c = fmap1.shape
+    q = h * w
+    assert fmap1.is_contiguous() and fmap2.is_contiguous() and fmap2.shape == fmap1.shape
+    vol = torch.empty((b, q, q), dtype=torch.float32, device=fmap1.device)
+    p = FFConvParams()
+    p.x[0], p.x_ld[0], p.x_c[0], p.x_gstride[0] = fmap1.data_ptr(), c, c, q * c
+    p.groups, p.B, p.H, p.W = b, 1, h, w
+    p.w, p.w_gstride = fmap2.data_ptr(), q * c
+    p.out_scale = 1.0 / math.sqrt(c)
+    p.y, p.y_ld, p.y_gstride = vol.data_ptr(), q, q * q
+    p.Ho, p.Wo, p.Cout = h, w, q
+    p.KH = p.KW = p.stride = 1
+    _require_gpu(fmap1)
+    _hip.call("ff_conv2d_fwd", C.byref(p), _stream())
+    return vol
+
+
+def corr_pyramid(vol: Tensor, h: int, w: int) -> List[Tensor]:
+    b, q, _ = vol.shape
+    n = b * q
+    lv = [vol.view(n, h, w)]
+    hh, ww = h, w
+    for _ in range(3):
+        hh, ww = hh // 2, ww // 2
+        lv.append(torch.empty((n, hh, ww), dtype=torch.float32, device=vol.device))
+    _hip.call("ff_corr_pyramid", _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), n, h, w, _stream())
+    return lv
+
+
+def corr_lookup(levels: List[Tensor], coords: Tensor, radius: int = 4, want_taps: bool = False):
+    """coords: (B, H, W, 2) [x, y].  Returns (B, H, W, L*(2r+1)^2) (+ int32 taps)."""
+    _require_gpu(coords)
+    b, h, w, _ = coords.shape
+    assert coords.is_contiguous()
+    nl = len(levels)
+    nk = nl * (2 * radius + 1) ** 2
+    out = empty_nhwc(b, h, w, nk, coords)
+    taps = torch.empty((b * h * w, nl, 2, 2 * radius + 1), dtype=torch.int32, device=coords.device) if want_taps else None
+    arr = (C.c_void_p * 4)(*[lv.data_ptr() for lv in levels] + [0] * (4 - nl))
+    h0, w0 = levels[0].shape[-2:]
+    _timed_call("ff_corr_lookup_fwd", arr, nl, radius, _p(coords), b * h * w, h0, w0, _p(out), nk, _p(taps), _stream())
+    return (out, taps) if want_taps else out
+
+
+# ----------------------------------------------------------------------------
+def norm_stats(x: Tensor, per_sample: bool) -> Tensor:
+    b, h, w, c = x.shape
+    stats = torch.zeros((b if per_sample else 1, c, 2), dtype=torch.float64, device=x.device)
+    _hip.call("ff_norm_stats", _p(x), _ld(x), b, h * w, c, int(per_sample), _p(stats), _stream())
+    return stats
+
+
+def norm_apply(x: Tensor, stats: Tensor, per_sample: bool, eps: float = 1e-5, gamma=None, beta=None,
+               act: int = ACT_NONE, res: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    b, h, w, c = x.shape
+    if out is None:
+        out = empty_nhwc(b, h, w, c, x)
+    _hip.call("ff_norm_apply", _p(x), _ld(x), _p(out), _ld(out), b, h * w, c, _p(stats), int(per_sample), eps,
+              _p(gamma), _p(beta), act, _p(res), _ld(res) if res is not None else 0, _stream())
+    return out
+
+
+def bn_fold(bn: torch.nn.BatchNorm2d):
+    c = bn.num_features
+    sc = torch.empty(c, dtype=torch.float32, device=bn.weight.device)
+    sh = torch.empty_like(sc)
+    _require_gpu(bn.weight)
+    _hip.call("ff_bn_fold", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), bn.eps, _p(sc),
+              _p(sh), c, _stream())
+    return sc, sh
+
+
+def bn_update_running(bn: torch.nn.BatchNorm2d, stats: Tensor, count: int):
+    _hip.call("ff_bn_update_running", _p(stats), count, bn.momentum, _p(bn.running_mean), _p(bn.running_var),
+              bn.num_features, _stream())
+
+
+# ----------------------------------------------------------------------------
+def prep_input(src_nchw: Optional[Tensor], b, h, w, like: Tensor, fill: float = 0.0) -> Tensor:
+    dst = empty_nhwc(b, h, w, 4, like)
+    if src_nchw is not None:
+        _require_gpu(src_nchw)
+        src_nchw = src_nchw.contiguous()
+        assert src_nchw.shape[0] == b and src_nchw.shape[2:] == (h, w)
+    _hip.call("ff_prep_input", _p(src_nchw), src_nchw.shape[1] if src_nchw is not None else 0, fill, _p(dst), b, h, w,
+              _stream())
+    return dst
+
+
+def act_copy(src: Tensor, dst: Tensor, act: int):
+    b, h, w, c = src.shape
+    assert dst.shape == src.shape
+    _hip.call("ff_act_copy", _p(src), _ld(src), _p(dst), _ld(dst), b * h * w, c, act, _stream())
+
+
+def coords_init(b, h, w, like: Tensor, flow_init: Optional[Tensor] = None) -> Tensor:
+    coords = empty_nhwc(b, h, w, 2, like)
+    if flow_init is not None:
+        _require_gpu(flow_init)
+        flow_init = flow_init.contiguous()
+        assert flow_init.shape == (b, 2, h, w)
+    _hip.call("ff_coords_init", _p(coords), _p(flow_init), b, h, w, _stream())
+    return coords
+
+
+def coords_step(coords1: Tensor, delta: Optional[Tensor], flow4: Optional[Tensor], slot: Optional[Tensor]):
+    b, h, w, _ = coords1.shape
+    _hip.call("ff_coords_step", _p(coords1), _p(delta), _ld(delta) if delta is not None else 0, _p(flow4), _p(slot),
+              _ld(slot) if slot is not None else 0, b, h, w, _stream())
+
+
+def gru_rh(r: Tensor, h: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    b, hh, ww, c = h.shape
+    if out is None:
+        out = empty_nhwc(b, hh, ww, c, h)
+    _hip.call("ff_gru_rh", _p(r), _ld(r), _p(h), _ld(h), _p(out), _ld(out), b * hh * ww, c, _stream())
+    return out
+
+
+def gru_blend(z: Tensor, q: Tensor, h: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    b, hh, ww, c = h.shape
+    if out is None:
+        out = empty_nhwc(b, hh, ww, c, h)
+    _hip.call("ff_gru_blend", _p(z), _ld(z), _p(q), _ld(q), _p(h), _ld(h), _p(out), _ld(out), b * hh * ww, c, _stream())
+    return out
+
+
+def upsample_flow(flow: Tensor, mask: Tensor) -> Tensor:
+    """flow (B,H,W,>=2) NHWC, mask (B,H,W,576) NHWC -> (B,2,8H,8W) NCHW."""
+    b, h, w, _ = flow.shape
+    out = torch.empty((b, 2, 8 * h, 8 * w), dtype=torch.float32, device=flow.device)
+    _hip.call("ff_upsample_flow", _p(flow), _ld(flow), _p(mask), _ld(mask), _p(out), b, h, w, _stream())
+    return out
+
+
+def nhwc_to_nchw(x: Tensor) -> Tensor:
+    b, h, w, c = x.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+    _hip.call("ff_nhwc_to_nchw", _p(x), _ld(x), _p(out), b, h, w, c, _stream())
+    return out

@@ -1,0 +1,88 @@
+"""RAFT graph on the HIP path (raft.py:40-236, the 'parallel' inside-fusion build)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .cce import BasicParallelFusionLayer
+from .corr_block import CorrBlock
+from .ops import ACT_RELU, ACT_TANH
+from .update_block import BasicUpdateBlock
+
+
+class RAFT(nn.Module):
+    def __init__(self, in_channels=3, small=False, dropout=0., alternate_corr=False, abandon_fnet=False,
+                 inside_fusion=None, fuse_cnet=False, cfg=None):
+        super().__init__()
+        if small or abandon_fnet or inside_fusion != "parallel" or not fuse_cnet:
+            raise NotImplementedError(
+                "the HIP path builds the configuration every shipped FF-RAFT experiment uses: "
+                "small=False, inside_fusion='parallel', fuse_cnet=True (SURVEY §2.1)")
+        self.small, self.abandon_fnet, self.inside_fusion, self.fuse_cnet, self.cfg = small, abandon_fnet, inside_fusion, fuse_cnet, cfg
+        self.hidden_dim = hdim = 128
+        self.context_dim = cdim = 128
+        self.corr_levels, self.corr_radius = 4, 4
+        self.dropout = dropout
+        # ALT_CORR selects an on-the-fly correlation in the reference (extension not
+        # vendored there); here the flag is accepted and the materialised pyramid is used.
+        self.alternate_corr = alternate_corr
+        mc = cfg.TRAIN.MASK_CHANNEL
+        self.fnet = BasicParallelFusionLayer(3, mc, output_dim=256, norm_fn="instance", dropout=dropout, cfg=cfg)
+        self.cnet = BasicParallelFusionLayer(3, mc, output_dim=hdim + cdim, norm_fn="batch", dropout=dropout, cfg=cfg)
+        self.update_block = BasicUpdateBlock(self.corr_levels, self.corr_radius, hidden_dim=hdim)
+
+    # -- reference API (raft.py:104-148) ------------------------------------
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def freeze_self(self, mode):
+        if mode == "parallel":
+            self.fnet.freeze_self(mode)
+            self.cnet.freeze_self(mode)
+            self.update_block.freeze_self(mode)
+
+    def load_model(self, model_path, flag="all", strict=True):
+        model_dict = {k.replace("module.", ""): v for k, v in torch.load(model_path).items()}
+        if flag == "backend":
+            for k in ("fnet.conv1.weight", "fnet.conv1.bias", "cnet.conv1.weight", "cnet.conv1.bias"):
+                model_dict.pop(k)
+            strict = False
+        self.load_state_dict(model_dict, strict=strict)
+        if flag == "all" and self.cfg.MODEL.LOAD_MODULE_TO_BRANCH:
+            self.fnet.copy_to_branch()
+            self.cnet.copy_to_branch()
+
+    # -- forward ------------------------------------------------------------
+    def forward(self, image1, image2, mask1=None, mask2=None, iters=12, flow_init=None, upsample=True,
+                test_mode=False):
+        """Inputs are NHWC4 tensors from ops.prep_input (already scaled to [-1,1]).
+        Returns the reference's outputs in NCHW: a list of `iters` (B,2,H,W) flows,
+        or (flow_low, flow_up) in test_mode.  raft.py:173-236."""
+        b, hh, ww, _ = image1.shape
+        h8, w8 = hh // 8, ww // 8
+        fmap1 = self.fnet(image1, mask1)
+        fmap2 = self.fnet(image2, mask2)
+        self.fmap = fmap1
+        corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius)
+        cnet = self.cnet(image1, mask1)
+        net = ops.empty_nhwc(b, h8, w8, 128, cnet)
+        inp = ops.empty_nhwc(b, h8, w8, 128, cnet)
+        ops.act_copy(cnet[..., :128], net, ACT_TANH)
+        ops.act_copy(cnet[..., 128:], inp, ACT_RELU)
+        coords1 = ops.coords_init(b, h8, w8, cnet, flow_init)
+        flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
+        flow_predictions = []
+        delta = None
+        flow_up = None
+        for _ in range(iters):
+            corr = corr_fn(coords1)
+            motion = ops.empty_nhwc(b, h8, w8, 128, cnet)
+            ops.coords_step(coords1, None, flow4, motion[..., 126:])      # flow = coords1 - coords0
+            net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, motion)
+            ops.coords_step(coords1, delta, flow4, None)                  # coords1 += delta
+            flow_up = ops.upsample_flow(flow4, up_mask)
+            flow_predictions.append(flow_up)
+        if test_mode:
+            return ops.nhwc_to_nchw(flow4[..., :2]), flow_up
+        return flow_predictions

@@ -1,0 +1,100 @@
+"""BasicUpdateBlock on the HIP path (update.py:79-146).
+
+Parameter holders keep the reference's names; the forward is 10 convolution
+launches + 4 gate kernels per iteration:
+  convc1 -> convc2 ; convf1 -> convf2 ; conv(cat)            (motion encoder)
+  [convz|convr] fused Cout=256 with sigmoid epilogue ; r*h ; convq with tanh
+  epilogue on cat[r*h, x] (3 input segments, no concat buffer) ; blend   (x2)
+  [flow_head.conv1|mask.0] fused Cout=512 with relu ; flow_head.conv2 ; mask.2 (x0.25)
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .cce import PackedConv
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+
+
+class FlowHead(nn.Module):
+    def __init__(self, input_dim=128, hidden_dim=256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+
+
+class SepConvGRU(nn.Module):
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        c = hidden_dim + input_dim
+        self.convz1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convr1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convq1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convz2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convr2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convq2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self._zr = [PackedConv([self.convz1, self.convr1]), PackedConv([self.convz2, self.convr2])]
+        self._q = [PackedConv([self.convq1]), PackedConv([self.convq2])]
+        self.hidden_dim = hidden_dim
+
+    def run(self, h, xs):
+        """h: (B,H,W,128); xs: list of NHWC segments forming x.  update.py:45-60."""
+        c = self.hidden_dim
+        for zr_conv, q_conv in zip(self._zr, self._q):
+            zr = zr_conv([h] + xs, act=ACT_SIGMOID)             # z = zr[..., :c], r = zr[..., c:]
+            rh = ops.gru_rh(zr[..., c:], h)
+            q = q_conv([rh] + xs, act=ACT_TANH)
+            h = ops.gru_blend(zr[..., :c], q, h)
+        return h
+
+
+class BasicMotionEncoder(nn.Module):
+    def __init__(self, corr_levels, corr_radius):
+        super().__init__()
+        cor_planes = corr_levels * (2 * corr_radius + 1) ** 2
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
+        self._c1, self._c2 = PackedConv([self.convc1]), PackedConv([self.convc2])
+        self._f1, self._f2 = PackedConv([self.convf1], 4), PackedConv([self.convf2])
+        self._cv = PackedConv([self.conv])
+
+    def run(self, flow4, corr, motion):
+        """flow4: (B,H,W,4) zero-padded flow; motion: (B,H,W,128) whose channels
+        126:128 already hold the flow (torch.cat([out, flow]) of update.py:97)."""
+        cor = self._c2(self._c1(corr, act=ACT_RELU), act=ACT_RELU)
+        flo = self._f2(self._f1(flow4, act=ACT_RELU), act=ACT_RELU)
+        self._cv([cor, flo], act=ACT_RELU, out=motion[..., :126])
+        return motion
+
+
+class BasicUpdateBlock(nn.Module):
+    def __init__(self, corr_levels, corr_radius, hidden_dim=128, input_dim=128):
+        super().__init__()
+        self.encoder = BasicMotionEncoder(corr_levels, corr_radius)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(256, 64 * 9, 1, padding=0))
+        self._heads = PackedConv([self.flow_head.conv1, self.mask[0]])
+        self._flow2 = PackedConv([self.flow_head.conv2])
+        self._mask2 = PackedConv([self.mask[2]])
+
+    def run(self, net, inp, corr, flow4, motion):
+        """-> (net, up_mask, delta_flow), all NHWC.  update.py:126-135."""
+        motion = self.encoder.run(flow4, corr, motion)
+        net = self.gru.run(net, [inp, motion])
+        hid = self._heads(net, act=ACT_RELU)                      # [flow-head 256 | mask-head 256]
+        delta = self._flow2(hid[..., :256])
+        up_mask = self._mask2(hid[..., 256:], out_scale=0.25)     # ".25 * self.mask(net)"
+        return net, up_mask, delta
+
+    def freeze_self(self, mode):
+        if mode == "parallel":  # update.py:137-146
+            for p in self.encoder.parameters():
+                p.requires_grad = False
+            for p in self.gru.parameters():
+                p.requires_grad = False
+            for p in self.flow_head.parameters():
+                p.requires_grad = True

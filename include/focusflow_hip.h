@@ -1,0 +1,164 @@
+/*
+ * focusflow_hip.h — C ABI of libfocusflow_hip.so, the MI355X (gfx950) native
+ * implementation of FocusFlow's FF-RAFT hot path.
+ *
+ * The reference has no FFI of its own: its boundary is the torch.nn.Module API
+ * (SURVEY.md §8b).  These entry points are what a Python maintainer would bind
+ * with ctypes from the reference's modules; each one
+ * names the reference lines it replaces, relative to
+ * core/models/ff-raft/FF_RAFT_Core/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless said otherwise; fp32.
+ *   - activations are NHWC: element (b,y,x,c) of a tensor with `ld` floats per
+ *     pixel lives at  ptr[((b*H + y)*W + x)*ld + c]   (ld >= C lets a tensor be
+ *     a channel slice of a wider buffer).  Pointers and `ld`s that feed a
+ *     convolution input must be multiples of 4 floats (16-byte vector loads).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     Calls only enqueue work; they never synchronise or allocate.
+ *   - return value: 0 on success, negative FF_E* on failure; ff_last_error()
+ *     returns a thread-local message for the last failure.
+ */
+#ifndef FOCUSFLOW_HIP_H
+#define FOCUSFLOW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FF_OK 0
+#define FF_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define FF_EHIP (-2)     /* HIP runtime reported an error */
+
+#define FF_ACT_NONE 0
+#define FF_ACT_RELU 1
+#define FF_ACT_SIGMOID 2
+#define FF_ACT_TANH 3
+
+#define FF_MAX_SEG 3
+
+const char* ff_last_error(void);
+int ff_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Convolution (implicit GEMM on fp32 MFMA), replaces every nn.Conv2d call of
+ * the path: extractor.py:48-56, parallel_fusion.py:87-95/:211-247,
+ * update.py:13-14/:45-60/:89-97/:121-135 — and, with per-sample "weights",
+ * the all-pairs matmul of corr.py:52-60.
+ *
+ * Input = up to 3 channel segments read as if concatenated (torch.cat along C
+ * in the reference: update.py:46,54,95,128).  Output element:
+ *     v = sum_k x*w ; v += bias[c] ; v *= out_scale ;
+ *     v = v*ch_scale[c] + ch_shift[c] ; v = act(v) ; v += res ; v = act_res(v)
+ * (null pointers skip their step; act_res only applies when res is given).
+ * ---------------------------------------------------------------------- */
+typedef struct FFConvParams {
+    const float* x[FF_MAX_SEG];        /* input segments (NHWC)                         */
+    int x_ld[FF_MAX_SEG];              /* floats per pixel of each segment buffer       */
+    int x_c[FF_MAX_SEG];               /* channels taken from each segment (mult. of 4) */
+    long long x_gstride[FF_MAX_SEG];   /* floats between groups (0 unless groups > 1)   */
+    int groups;                        /* outer batch with its own weights (corr: B)    */
+    int B, H, W;                       /* per-group input: B images of H x W            */
+    const float* w;                    /* packed [Cout][KH][KW][Cin], Cin = sum x_c     */
+    long long w_gstride;               /* floats between groups' weights (0 = shared)   */
+    const float* bias;                 /* [Cout] or NULL                                */
+    const float* ch_scale;             /* [Cout] or NULL                                */
+    const float* ch_shift;             /* [Cout] or NULL (required iff ch_scale)        */
+    float out_scale;
+    const float* res;                  /* residual, NHWC [B*Ho*Wo][res_ld], or NULL     */
+    int res_ld;
+    float* y;                          /* output NHWC [B*Ho*Wo][y_ld]                   */
+    int y_ld;
+    long long y_gstride;
+    int Ho, Wo, Cout;
+    int KH, KW, stride, pad_h, pad_w;
+    int act;                           /* FF_ACT_*, before the residual add             */
+    int act_res;                       /* FF_ACT_*, after the residual add              */
+} FFConvParams;
+
+int ff_conv2d_fwd(const FFConvParams* p, void* stream);
+
+/* nn.Conv2d weight (OIHW, as stored in the state_dict) -> packed
+ * [Cout][KH][KW][cin_pad] rows, written at row `cout_offset` of a destination
+ * holding `dst_rows` rows (lets convz|convr share one packed matrix). */
+int ff_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW,
+                        float* dst, int cin_pad, int cout_offset, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Normalisation: nn.InstanceNorm2d (extractor.py:28-32, per-sample statistics,
+ * no affine) and nn.BatchNorm2d (extractor.py:22-26; train = batch statistics).
+ *   ff_norm_stats : stats[s][c] = {sum, sum of squares} in fp64, s = sample
+ *                   (per_sample=1) or 0 (batch statistics).  `stats` must be
+ *                   zeroed by the caller (hipMemsetAsync) before the call.
+ *   ff_norm_apply : y = act((x-mean)*rstd*gamma + beta) ; if res: y = relu(y+res)
+ *   ff_bn_fold    : eval-mode BatchNorm as a per-channel scale/shift for the
+ *                   convolution epilogue.
+ *   ff_bn_update_running : running-stat update of a train-mode BatchNorm.
+ * ---------------------------------------------------------------------- */
+int ff_norm_stats(const float* x, int ld, int B, int HW, int C, int per_sample,
+                  double* stats, void* stream);
+int ff_norm_apply(const float* x, int ld, float* y, int y_ld, int B, int HW, int C,
+                  const double* stats, int per_sample, float eps,
+                  const float* gamma, const float* beta, int act,
+                  const float* res, int res_ld, void* stream);
+int ff_bn_fold(const float* running_mean, const float* running_var, const float* gamma,
+               const float* beta, float eps, float* ch_scale, float* ch_shift, int C, void* stream);
+int ff_bn_update_running(const double* stats, long long count, float momentum,
+                         float* running_mean, float* running_var, int C, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Input preparation: ff_raft.py:31-38 ('point' masks: 1 -> 3 channels, second
+ * mask = 255) and :142-145 (x -> 2*(x/255) - 1), NCHW [0,255] -> NHWC, 4
+ * channels per pixel (channel 3 = 0).  src == NULL fills with `fill_value`
+ * before scaling (mask2).
+ * ---------------------------------------------------------------------- */
+int ff_prep_input(const float* src_nchw, int src_c, float fill_value, float* dst_nhwc4,
+                  int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------
+ * CorrBlock (corr.py:12-60).  The volume itself is ff_conv2d_fwd with
+ * groups = B (fmap2 as per-sample 1x1 weights, out_scale = 1/sqrt(C)).
+ *   ff_corr_pyramid    : levels 1..3 by 2x2 average pooling (corr.py:24-27),
+ *                        planes are [B*Q][h_l][w_l] row-major, floor on odd sizes.
+ *   ff_corr_lookup_fwd : radius-r bilinear window lookup (corr.py:29-50 +
+ *                        utils.py:57-71), out NHWC [B*Q][out_ld], channel
+ *                        k = level*(2r+1)^2 + a*(2r+1) + b with a = x-offset index.
+ *                        taps_dbg (nullable): int32 [B*Q][levels][2][2r+1]
+ *                        floor indices (x then y) — used by the bit-exactness tests.
+ * ---------------------------------------------------------------------- */
+int ff_corr_pyramid(const float* lvl0, float* lvl1, float* lvl2, float* lvl3,
+                    long long planes, int h0, int w0, void* stream);
+int ff_corr_lookup_fwd(const float* const* levels /* HOST array of 4 device ptrs */,
+                       int num_levels, int radius, const float* coords /* [B*Q][2] x,y */,
+                       long long queries, int h0, int w0, float* out, int out_ld,
+                       int* taps_dbg, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Update-block glue (raft.py:205-231, update.py:45-60).
+ * ---------------------------------------------------------------------- */
+/* dst[pix][0..C) = act(src[pix][0..C))  with independent lds (torch.split + tanh/relu) */
+int ff_act_copy(const float* src, int src_ld, float* dst, int dst_ld, long long npix, int C,
+                int act, void* stream);
+/* coords_grid (utils.py:74-77): coords[b][y][x] = (x, y) (+ flow_init NHWC2 if given) */
+int ff_coords_init(float* coords, const float* flow_init_nchw, int B, int H, int W, void* stream);
+/* coords1 += delta (if delta) ; flow = coords1 - coords0 written to
+ * flow4 [npix][4] (zero padded, conv input) and to motion[...,126:128] style
+ * slot `slot` ([npix][slot_ld], 2 floats) if non-null.   raft.py:219,223 */
+int ff_coords_step(float* coords1, const float* delta, int delta_ld, float* flow4,
+                   float* slot, int slot_ld, int B, int H, int W, void* stream);
+/* GRU gates (update.py:47-49): rh = r*h ; h' = (1-z)*h + z*q */
+int ff_gru_rh(const float* r, int r_ld, const float* h, int h_ld, float* rh, int rh_ld,
+              long long npix, int C, void* stream);
+int ff_gru_blend(const float* z, int z_ld, const float* q, int q_ld, const float* h, int h_ld,
+                 float* h_new, int hn_ld, long long npix, int C, void* stream);
+/* convex 8x upsampling (raft.py:159-170): flow NHWC [B*H*W][flow_ld] (2 ch),
+ * mask NHWC [B*H*W][mask_ld] (576 ch) -> out NCHW (B,2,8H,8W) */
+int ff_upsample_flow(const float* flow, int flow_ld, const float* mask, int mask_ld,
+                     float* out_nchw, int B, int H, int W, void* stream);
+/* NHWC [npix][ld] (C ch) -> NCHW (B,C,H,W) */
+int ff_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int H, int W, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOCUSFLOW_HIP_H */

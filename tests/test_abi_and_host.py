@@ -1,0 +1,121 @@
+"""CPU-side checks: the C ABI library builds/loads and exports every symbol the
+header declares; host-side module mirrors the reference's state_dict; the
+product path refuses to run without a HIP device (no fallback)."""
+import ctypes
+import json
+import os
+import re
+import sys
+from argparse import Namespace
+
+import pytest
+import torch
+
+from conftest import ROOT, golden_spec
+
+
+def _cfg(ft="1x1conv"):
+    return Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"),
+                     MODEL=Namespace(FUSION_TYPE=ft, LOAD_MODULE_TO_BRANCH=False))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from focusflow_official_amd import build
+    return build.build_hip(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    hdr = open(os.path.join(ROOT, "include", "focusflow_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(ff_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(lib_path)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in focusflow_hip.h but not exported"
+    from focusflow_official_amd import _hip
+    assert set(_hip.EXPORTS) == declared, "ctypes table and header disagree"
+    lib.ff_abi_version.restype = ctypes.c_int
+    assert lib.ff_abi_version() == 1
+
+
+def test_conv_params_struct_layout(lib_path):
+    """ctypes mirror of FFConvParams must match the C layout (size check via a C compile)."""
+    import subprocess, tempfile
+    from focusflow_official_amd._hip import FFConvParams
+    src = '#include <stdio.h>\n#include "focusflow_hip.h"\nint main(){printf("%zu %zu %zu", sizeof(FFConvParams), ' \
+          '__builtin_offsetof(FFConvParams, w), __builtin_offsetof(FFConvParams, act_res));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        size, off_w, off_ar = map(int, subprocess.run([os.path.join(d, "t")], capture_output=True, text=True).stdout.split())
+    assert ctypes.sizeof(FFConvParams) == size
+    assert FFConvParams.w.offset == off_w and FFConvParams.act_res.offset == off_ar
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu(lib_path):
+    """Argument validation happens before any launch, so it is testable here."""
+    from focusflow_official_amd import _hip
+    lib = _hip.load()
+    assert lib.ff_conv2d_fwd(None, None) == -1
+    assert b"null params" in lib.ff_last_error()
+    p = _hip.FFConvParams()
+    p.x[0], p.w, p.y = 16, 16, 16
+    p.x_c[0], p.x_ld[0] = 6, 8          # channels not a multiple of 4
+    p.groups = p.B = p.H = p.W = p.Cout = p.KH = p.KW = p.stride = 1
+    assert lib.ff_conv2d_fwd(ctypes.byref(p), None) == -1
+    assert b"multiple of 4" in lib.ff_last_error()
+    assert lib.ff_corr_pyramid(16, 16, 16, 16, 10, 4, 4, None) == -1   # plane too small for 4 levels
+    arr = (ctypes.c_void_p * 4)(16, 16, 16, 16)
+    assert lib.ff_corr_lookup_fwd(arr, 4, 4, 16, 10, 12, 16, 16, 324, None, None) == -1
+    assert b"divides by (n-1)" in lib.ff_last_error()   # the reference's own H/8 >= 16 limit
+
+
+@pytest.mark.parametrize("ft,spec", [("1x1conv", "state_dict_spec"), ("concat", "state_dict_spec_concat")])
+def test_state_dict_matches_reference(lib_path, ft, spec):
+    from focusflow_official_amd import FF_RAFT_FUSION
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg(ft))
+    mine = {k: (tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()}
+    ref = {k: (s, d) for k, s, d in golden_spec(spec)}
+    assert mine == ref
+    if ft == "1x1conv":
+        assert sum(p.numel() for p in m.parameters()) == 7662272
+    # shared BN registration (extractor.py:25-26,44-45): norm3 IS downsample.1
+    blk = m.flow_net.cnet.layer2[0]
+    assert blk.norm3 is blk.downsample[1]
+    # reference API surface used by train.py
+    m.flow_net.freeze_bn()
+    assert not m.flow_net.cnet.norm1.training
+    m.train()
+    m.freeze_self()
+    assert not m.flow_net.fnet.conv1.weight.requires_grad and m.flow_net.fnet.mask_conv1.weight.requires_grad
+    assert m.flow_net.update_block.flow_head.conv1.weight.requires_grad
+    assert not m.flow_net.update_block.gru.convz1.weight.requires_grad
+
+
+def test_unsupported_configurations_fail_loudly(lib_path):
+    from focusflow_official_amd import FF_RAFT_FUSION
+    with pytest.raises(NotImplementedError):
+        FF_RAFT_FUSION(use_fusion="attention", cfg=_cfg())
+    with pytest.raises(NotImplementedError):
+        FF_RAFT_FUSION(use_fusion="parallel", fuse_cnet=True, cfg=_cfg("SA"))
+    with pytest.raises(ValueError):
+        FF_RAFT_FUSION(use_fusion="parallel", fuse_cnet=True, cfg=_cfg("bogus"))
+
+
+def test_no_cpu_fallback(lib_path):
+    """Calling the model with CPU tensors must raise, not silently compute on the host."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    from focusflow_official_amd._hip import FocusFlowHipError
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg()).eval()
+    x = torch.zeros(1, 3, 128, 128)
+    with pytest.raises(FocusFlowHipError):
+        m(x, x, torch.zeros(1, 1, 128, 128), torch.zeros(1, 1, 128, 128), raft_iters=1, test_mode=True)
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "focusflow_official_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("test oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,365 @@
+"""GPU parity: libfocusflow_hip (through its C ABI) against the CPU oracle and the
+reference-generated golden vectors.  Everything here needs a real MI355X.
+
+Tolerances: fp32 activations rtol 2e-5 (fp32 MFMA is an exact fma chain; the
+summation order differs from oneDNN's); final flow max-abs 1e-3 (BASELINE.json
+north_star); lookup tap indices bit-exact.
+"""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import ffraft_ref as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(t, pad_to=None):
+    """NCHW cpu -> NHWC device (test plumbing)."""
+    t = t.permute(0, 2, 3, 1).contiguous()
+    if pad_to and t.shape[-1] < pad_to:
+        t = F.pad(t, (0, pad_to - t.shape[-1]))
+    return t.to(DEV)
+
+
+def nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, rtol=2e-5, atol=None, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if atol is None:
+        atol = rtol * max(1.0, float(np.abs(b).max()))
+    err = np.abs(a - b) - rtol * np.abs(b)
+    assert err.max() <= atol, f"{what}: max violation {err.max():.3e} (atol {atol:.3e}), max|ref| {np.abs(b).max():.3e}"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from focusflow_official_amd import ops as _ops
+    return _ops
+
+
+def _cfg(ft="1x1conv"):
+    return Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"),
+                     MODEL=Namespace(FUSION_TYPE=ft, LOAD_MODULE_TO_BRANCH=False))
+
+
+def _model(sd, ft="1x1conv"):
+    from focusflow_official_amd import FF_RAFT_FUSION
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg(ft))
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval()
+
+
+# ----------------------------------------------------------------------------
+# operators
+# ----------------------------------------------------------------------------
+CONV_CASES = [
+    # (segments, cout, kh, kw, stride, pad, B, H, W, act, use_res)
+    ([3], 64, 7, 7, 2, (3, 3), 2, 40, 56, 1, False),        # stem (Cin 3 -> padded 4)
+    ([64], 64, 3, 3, 1, (1, 1), 2, 24, 40, 0, True),        # residual 3x3
+    ([64], 96, 3, 3, 2, (1, 1), 1, 33, 47, 1, False),       # stride 2, odd sizes, Cout 96 tile
+    ([64], 96, 1, 1, 2, (0, 0), 2, 32, 48, 0, False),       # downsample 1x1 s2
+    ([128], 256, 1, 1, 1, (0, 0), 1, 16, 24, 0, True),      # fusion / output conv
+    ([324], 256, 1, 1, 1, (0, 0), 1, 16, 24, 1, False),     # convc1 (K tail 324 = 10*32+4)
+    ([2], 128, 7, 7, 1, (3, 3), 1, 16, 24, 1, False),       # convf1 (Cin 2 -> padded 4)
+    ([192, 64], 126, 3, 3, 1, (1, 1), 1, 16, 24, 1, False), # motion conv: 2 segments, Cout 126
+    ([128, 128, 128], 256, 1, 5, 1, (0, 2), 2, 16, 24, 2, False),  # convz|convr horizontal, sigmoid
+    ([128, 128, 128], 128, 5, 1, 1, (2, 0), 1, 16, 24, 3, False),  # convq vertical, tanh
+    ([256], 2, 3, 3, 1, (1, 1), 1, 16, 24, 0, False),       # flow head conv2 (Cout 2)
+    ([256], 576, 1, 1, 1, (0, 0), 1, 16, 24, 0, False),     # mask head
+    ([128], 128, 3, 3, 1, (1, 1), 8, 48, 64, 1, False),     # big-M: 128x128 tiles
+    ([64], 64, 3, 3, 1, (1, 1), 2, 96, 128, 1, False),      # 128x64 tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"c{'+'.join(map(str, c[0]))}-o{c[1]}-k{c[2]}x{c[3]}-s{c[4]}")
+def test_conv2d(ops, case):
+    segs, cout, kh, kw, stride, pad, b, h, w, act, use_res = case
+    g = torch.Generator().manual_seed(hash(str(case)) & 0xFFFF)
+    cin = sum(segs)
+    xs = [torch.randn(b, c, h, w, generator=g) for c in segs]
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / (cin * kh * kw) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(torch.cat(xs, 1), wt, bias, stride=stride, padding=pad)
+    ref = [lambda v: v, torch.relu, torch.sigmoid, torch.tanh][act](ref)
+    res = torch.randn_like(ref) if use_res else None
+    if use_res:
+        ref = torch.relu(ref + res)
+    cin_pads = [(c + 3) // 4 * 4 for c in segs]
+    assert len(segs) == 1 or cin_pads == segs
+    wp = torch.empty(cout, kh * kw * sum(cin_pads), device=DEV)
+    ops.pack_conv_weight(wt.to(DEV), wp, sum(cin_pads))
+    # inputs as channel slices of a wider buffer to exercise ld != C
+    xd = []
+    for x, cp in zip(xs, cin_pads):
+        buf = torch.zeros(b, h, w, cp + 8, device=DEV)
+        buf[..., 4:4 + x.shape[1]] = nhwc(x)
+        xd.append(buf[..., 4:4 + cp])
+    out = ops.conv2d(xd, wp, bias.to(DEV), cout, kh, kw, stride, pad, act=act,
+                     res=nhwc(res) if use_res else None, act_res=1 if use_res else 0)
+    torch.cuda.synchronize()
+    close(nchw(out), ref, what="conv2d")
+
+
+def test_conv_epilogue_scale_shift_and_outscale(ops):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 64, 16, 24, generator=g)
+    wt = torch.randn(64, 64, 3, 3, generator=g) / 24
+    bias, sc, sh = (torch.randn(64, generator=g) for _ in range(3))
+    ref = torch.relu((F.conv2d(x, wt, bias, padding=1) * 0.25) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wp = torch.empty(64, 9 * 64, device=DEV)
+    ops.pack_conv_weight(wt.to(DEV), wp, 64)
+    out = ops.conv2d([nhwc(x)], wp, bias.to(DEV), 64, 3, 3, 1, 1, act=1, ch_scale=sc.to(DEV), ch_shift=sh.to(DEV),
+                     out_scale=0.25)
+    close(nchw(out), ref, what="epilogue")
+
+
+@pytest.mark.parametrize("c,h,w,b", [(64, 64, 96, 2), (96, 31, 47, 3), (128, 16, 24, 1), (256, 16, 24, 2)])
+def test_instance_norm(ops, c, h, w, b):
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(b, c, h, w, generator=g) * 3 + 1.5
+    res = torch.randn(b, c, h, w, generator=g)
+    xd = nhwc(x)
+    st = ops.norm_stats(xd, per_sample=True)
+    y = ops.norm_apply(xd, st, True, 1e-5, act=1)
+    close(nchw(y), torch.relu(F.instance_norm(x)), rtol=1e-5, atol=2e-5, what="instance_norm+relu")
+    y2 = ops.norm_apply(xd, st, True, 1e-5, act=1, res=nhwc(res))
+    close(nchw(y2), torch.relu(res + torch.relu(F.instance_norm(x))), rtol=1e-5, atol=2e-5, what="instance_norm+res")
+
+
+def test_batch_norm_train_and_eval(ops):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 96, 20, 28, generator=g) * 2 - 0.7
+    bn = torch.nn.BatchNorm2d(96)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(96, generator=g))
+        bn.bias.copy_(torch.randn(96, generator=g))
+        bn.running_mean.copy_(torch.randn(96, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(96, generator=g) + 0.5)
+    import copy
+    bn_d = copy.deepcopy(bn).to(DEV)
+    ref = bn(x)  # train mode: batch stats + running update
+    xd = nhwc(x)
+    st = ops.norm_stats(xd, per_sample=False)
+    ops.bn_update_running(bn_d, st, 3 * 20 * 28)
+    y = ops.norm_apply(xd, st, False, bn_d.eps, bn_d.weight, bn_d.bias)
+    close(nchw(y), ref.detach(), rtol=1e-5, atol=3e-5, what="bn train")
+    close(bn_d.running_mean.cpu(), bn.running_mean, rtol=1e-6, atol=1e-6, what="running_mean")
+    close(bn_d.running_var.cpu(), bn.running_var, rtol=1e-5, atol=1e-6, what="running_var")
+    bn.eval()
+    sc, sh = ops.bn_fold(bn_d)
+    close((xd * sc + sh).cpu().permute(0, 3, 1, 2), bn(x).detach(), rtol=1e-5, atol=3e-5, what="bn eval fold")
+
+
+def test_prep_input_bit_exact(ops):
+    i1, i2, m1, _ = orc.synthetic_inputs(2, 64, 96, seed=3)
+    r1, r2, rm1, rm2 = orc.prepare_inputs(i1, i2, m1, None, 3)
+    d = ops.prep_input(i1.to(DEV), 2, 64, 96, i1.to(DEV))
+    assert torch.equal(nchw(d)[:, :3], r1) and (d[..., 3] == 0).all()
+    dm = ops.prep_input(m1.to(DEV), 2, 64, 96, d)
+    assert torch.equal(nchw(dm)[:, :3], rm1)
+    dm2 = ops.prep_input(None, 2, 64, 96, d, fill=255.0)
+    assert torch.equal(nchw(dm2)[:, :3], rm2)
+
+
+# ----------------------------------------------------------------------------
+# CorrBlock
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("b,h,w", [(2, 16, 24), (1, 46, 62), (1, 20, 16)])
+def test_corr_volume_and_pyramid(ops, b, h, w):
+    g = torch.Generator().manual_seed(h)
+    f1, f2 = torch.randn(b, 256, h, w, generator=g), torch.randn(b, 256, h, w, generator=g)
+    ref = orc.corr_pyramid(orc.corr_volume(f1, f2))
+    vol = ops.corr_volume(nhwc(f1), nhwc(f2))
+    pyr = ops.corr_pyramid(vol, h, w)
+    for lv, (a, r) in enumerate(zip(pyr, ref)):
+        assert a.shape[-2:] == r.shape[-2:]
+        close(a.cpu(), r[:, 0], rtol=1e-5, atol=3e-5, what=f"pyramid level {lv}")
+
+
+def _lookup_case(ops, pyr_cpu, coords_nchw):
+    """pyr_cpu: list of (N,1,h,w) cpu planes; returns (hip_out NCHW, hip_taps, c_out, c_taps)."""
+    from oracle import corr_c
+    lv = [p[:, 0].contiguous().to(DEV) for p in pyr_cpu]
+    out, taps = ops.corr_lookup(lv, nhwc(coords_nchw), 4, want_taps=True)
+    c_out, c_taps = corr_c.lookup([p[:, 0].numpy().copy() for p in pyr_cpu], coords_nchw.numpy())
+    return nchw(out), taps.cpu().numpy(), c_out, c_taps
+
+
+@pytest.mark.parametrize("h,w", [(48, 64), (46, 62), (16, 24)])
+def test_lookup_taps_bit_exact_and_values(ops, h, w):
+    g = torch.Generator().manual_seed(w)
+    b = 1
+    vol = torch.randn(b, h * w, h, w, generator=g) * 30
+    pyr = orc.corr_pyramid(vol)
+    base = orc.coords_grid(b, h, w)
+    cases = {
+        "integer": base.clone(),                                          # iteration 0: exactly on pixels
+        "random": base + (torch.rand(base.shape, generator=g) * 16 - 8),
+        "halves": base + 0.5, "eighths": base * 1.125,
+        "far_outside": base + torch.tensor([w + 20.0, -h - 20.0]).view(1, 2, 1, 1),
+        "edge": base + torch.tensor([-4.0, 4.0]).view(1, 2, 1, 1),
+    }
+    for name, c in cases.items():
+        out, taps, c_out, c_taps = _lookup_case(ops, pyr, c)
+        assert (taps == c_taps).all(), f"{name}: tap indices differ from the oracle in {(taps != c_taps).sum()} places"
+        ref = orc.corr_lookup(pyr, c)  # the reference's grid_sample route
+        close(out, ref, rtol=2e-6, atol=2e-4, what=f"lookup {name} vs grid_sample")
+        close(out, c_out, rtol=1e-6, atol=1e-5, what=f"lookup {name} vs C oracle")
+        # and the torch replay pinned to ATen's taps by tests/test_oracle_golden.py
+        sizes = [tuple(p.shape[-2:]) for p in pyr]
+        for lvl, (x0, y0, _, _) in enumerate(orc.lookup_taps(c, sizes)):
+            assert (taps[:, lvl, 0] == x0.numpy()).all() and (taps[:, lvl, 1] == y0.numpy()).all()
+
+
+def test_lookup_against_reference_vectors(ops, det_sd):
+    """Reference outputs (golden) for a real pyramid: integer coords (iteration 0) and random coords."""
+    g = load_golden("fwd_shift_128x192_b2_it12")
+    inp = orc.shifted_pair(2, 128, 192, seed=1)
+    taps = {}
+    with torch.no_grad():
+        orc.ffraft_forward(det_sd, *inp, raft_iters=1, test_mode=True, taps=taps)
+    pyr_b0 = [p[:384] for p in taps["pyramid"]]
+    out, _, _, _ = _lookup_case(ops, pyr_b0, torch.from_numpy(g["crand"]))
+    close(out, g["look_rand"], rtol=2e-6, atol=1e-4, what="golden look_rand")
+    out0, _, _, _ = _lookup_case(ops, pyr_b0, orc.coords_grid(1, 16, 24))
+    close(out0, g["look0"], rtol=2e-6, atol=1e-4, what="golden look0")
+
+
+# ----------------------------------------------------------------------------
+# update-block glue
+# ----------------------------------------------------------------------------
+def test_gru_gates_and_coords(ops):
+    g = torch.Generator().manual_seed(5)
+    z, r, q, h = (torch.rand(2, 128, 16, 24, generator=g) for _ in range(4))
+    zr = torch.cat([nhwc(z), nhwc(r)], -1)
+    rh = ops.gru_rh(zr[..., 128:], nhwc(h))
+    assert torch.equal(nchw(rh), r * h)
+    hn = ops.gru_blend(zr[..., :128], nhwc(q), nhwc(h))
+    assert torch.equal(nchw(hn), (1 - z) * h + z * q)
+    finit = torch.randn(2, 2, 16, 24, generator=g)
+    c1 = ops.coords_init(2, 16, 24, zr, finit.to(DEV))
+    ref_c1 = orc.coords_grid(2, 16, 24) + finit
+    assert torch.equal(nchw(c1), ref_c1)
+    delta = torch.randn(2, 2, 16, 24, generator=g)
+    flow4 = torch.empty(2, 16, 24, 4, device=DEV)
+    motion = torch.zeros(2, 16, 24, 128, device=DEV)
+    ops.coords_step(c1, nhwc(delta), flow4, motion[..., 126:])
+    ref_c1 = ref_c1 + delta
+    assert torch.equal(nchw(c1), ref_c1)
+    assert torch.equal(nchw(flow4)[:, :2], ref_c1 - orc.coords_grid(2, 16, 24)) and (flow4[..., 2:] == 0).all()
+    assert torch.equal(motion[..., 126:], flow4[..., :2]) and (motion[..., :126] == 0).all()
+    src = torch.randn(2, 256, 16, 24, generator=g)
+    dst = torch.empty(2, 16, 24, 128, device=DEV)
+    ops.act_copy(nhwc(src)[..., 128:], dst, 1)
+    assert torch.equal(nchw(dst), torch.relu(src[:, 128:]))
+    ops.act_copy(nhwc(src)[..., :128], dst, 3)
+    close(nchw(dst), torch.tanh(src[:, :128]), rtol=1e-6, atol=1e-6, what="tanh")
+
+
+def test_upsample_flow_known_answer(ops):
+    g = load_golden("upsample")  # produced by the reference's RAFT.upsample_flow
+    out = ops.upsample_flow(nhwc(torch.from_numpy(g["flow"])), nhwc(torch.from_numpy(g["mask"])))
+    close(out.cpu(), g["out"], rtol=1e-6, atol=2e-6, what="upsample_flow")
+
+
+# ----------------------------------------------------------------------------
+# encoders and the full model
+# ----------------------------------------------------------------------------
+FWD = {
+    "fwd_rand_128x192_b2_it12": (lambda: orc.synthetic_inputs(2, 128, 192, seed=0), 12),
+    "fwd_shift_128x192_b2_it12": (lambda: orc.shifted_pair(2, 128, 192, seed=1), 12),
+    "fwd_shift_128x160_b1_it4_init": (lambda: orc.shifted_pair(1, 128, 160, seed=2), 4),
+}
+
+
+@pytest.mark.parametrize("name", list(FWD))
+def test_model_matches_reference_vectors(name, det_sd, ops):
+    g = load_golden(name)
+    make, iters = FWD[name]
+    inp = [t.to(DEV) for t in make()]
+    m = _model(det_sd)
+    finit = torch.from_numpy(g["flow_init"]).to(DEV) if "flow_init" in g else None
+    net = m.flow_net
+    with torch.no_grad():
+        b, _, h, w = inp[0].shape
+        i1, i2 = ops.prep_input(inp[0], b, h, w, inp[0]), ops.prep_input(inp[1], b, h, w, inp[0])
+        m1, m2 = ops.prep_input(inp[2], b, h, w, inp[0]), ops.prep_input(None, b, h, w, inp[0], fill=255.0)
+        close(nchw(net.fnet(i1, m1))[:, ::4], g["fmap1"], rtol=2e-5, atol=2e-4, what="fmap1")
+        close(nchw(net.fnet(i2, m2))[:, ::4], g["fmap2"], rtol=2e-5, atol=2e-4, what="fmap2")
+        close(nchw(net.cnet(i1, m1))[:, ::4], g["cnet"], rtol=2e-5, atol=2e-4, what="cnet")
+        flow_low, flow_up = m(*inp, raft_iters=iters, flow_init=finit, test_mode=True)
+        preds = m(*inp, raft_iters=iters, flow_init=finit)
+    assert isinstance(preds, list) and len(preds) == int(g["n_preds"][0])
+    assert flow_low.shape == g["flow_low"].shape and flow_up.shape == g["flow_up"].shape
+    # BASELINE.json north_star: fp32 flow within 1e-3 max-abs of the reference
+    close(flow_up.cpu(), g["flow_up"], rtol=0, atol=1e-3, what="flow_up")
+    close(flow_low.cpu(), g["flow_low"], rtol=0, atol=1e-3, what="flow_low")
+    close(preds[0].cpu(), g["pred_first"], rtol=0, atol=1e-3, what="pred[0]")
+    close(preds[len(preds) // 2].cpu(), g["pred_mid"], rtol=0, atol=1e-3, what="pred[mid]")
+    epe = np.sqrt(((flow_up.cpu().numpy() - g["flow_up"]) ** 2).sum(1)).mean()
+    assert epe < 1e-3
+
+
+def test_update_block_first_iteration(det_sd, ops):
+    g = load_golden("fwd_shift_128x192_b2_it12")
+    inp = [t.to(DEV) for t in orc.shifted_pair(2, 128, 192, seed=1)]
+    m = _model(det_sd)
+    with torch.no_grad():
+        preds = m(*inp, raft_iters=1)
+    close(preds[0].cpu(), g["up1"], rtol=0, atol=2e-4, what="first-iteration flow_up")
+
+
+def test_concat_fusion_variant(det_sd_concat):
+    g = load_golden("fwd_concat_128x160_b1_it4")
+    inp = [t.to(DEV) for t in orc.shifted_pair(1, 128, 160, seed=8)]
+    m = _model(det_sd_concat, "concat")
+    with torch.no_grad():
+        fl, fu = m(*inp, raft_iters=4, test_mode=True)
+    close(fu.cpu(), g["flow_up"], rtol=0, atol=1e-3, what="concat flow_up")
+
+
+def test_config1_384x512_and_batch_consistency(det_sd):
+    """BASELINE config 1 (B=1 384x512 it12) against the reference's vector, then
+    config 2's size (B=8): eight copies of the pair must give eight identical flows
+    equal to the B=1 flow (samples are independent — InstanceNorm, eval BatchNorm)."""
+    g = load_golden("fwd_shift_384x512_b1_it12")
+    inp = [t.to(DEV) for t in orc.shifted_pair(1, 384, 512, seed=6)]
+    m = _model(det_sd)
+    with torch.no_grad():
+        flow_low, flow_up = m(*inp, raft_iters=12, test_mode=True)
+        close(flow_low.cpu(), g["flow_low"], rtol=0, atol=1e-3, what="384x512 flow_low")
+        close(flow_up.cpu()[:, :, ::4, ::4], g["flow_up_sub"], rtol=0, atol=1e-3, what="384x512 flow_up")
+        rep = [t.repeat(8, 1, 1, 1) for t in inp]
+        fl8, fu8 = m(*rep, raft_iters=12, test_mode=True)
+    assert fu8.shape == (8, 2, 384, 512)
+    for i in range(8):
+        close(fu8[i].cpu(), flow_up[0].cpu(), rtol=0, atol=2e-4, what=f"batch sample {i}")
+
+
+def test_full_size_lookup_properties(ops):
+    """Size-independent properties at B=8, 48x64 (BASELINE config 2 shapes)."""
+    g = torch.Generator().manual_seed(0)
+    b, h, w = 8, 48, 64
+    f1 = torch.randn(b, h, w, 256, generator=g).to(DEV)
+    f2 = torch.randn(b, h, w, 256, generator=g).to(DEV)
+    vol = ops.corr_volume(f1, f2)
+    pyr = ops.corr_pyramid(vol, h, w)
+    coords = ops.coords_init(b, h, w, f1)
+    out = ops.corr_lookup(pyr, coords, 4)
+    # centre tap (k=40) of level 0 at integer coords is the volume's own diagonal entry
+    diag = vol.view(b, h * w, h * w).diagonal(dim1=1, dim2=2)
+    assert torch.equal(out.view(b, h * w, 324)[..., 40], diag)
+    # linearity of the volume in fmap1
+    vol2 = ops.corr_volume(f1 * 2, f2)
+    close(vol2.cpu(), (vol * 2).cpu(), rtol=1e-6, atol=1e-5, what="linearity")
+    # pyramid means are preserved level to level (48x64 divides evenly)
+    for lo, hi in zip(pyr[:-1], pyr[1:]):
+        close(hi.mean(dim=(1, 2)).cpu(), lo.mean(dim=(1, 2)).cpu(), rtol=1e-4, atol=1e-4, what="pool mean")

@@ -163,3 +163,26 @@ def test_upsample_known_answer():
     g = load_golden("upsample")
     out = orc.upsample_flow(torch.from_numpy(g["flow"]), torch.from_numpy(g["mask"]))
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=1e-6)
+
+
+def test_c_oracle_matches_reference_vectors(det_sd):
+    """oracle/corr_oracle.c (plain C) against the reference's pyramid / lookup."""
+    from oracle import corr_c
+    g = load_golden("fwd_shift_128x192_b2_it12")
+    inp = orc.shifted_pair(2, 128, 192, seed=1)
+    taps = {}
+    with torch.no_grad():
+        orc.ffraft_forward(det_sd, *inp, raft_iters=1, test_mode=True, taps=taps)
+    f1, f2 = taps["fmap1"][:1].numpy(), taps["fmap2"][:1].numpy()
+    vol = corr_c.corr_volume(f1, f2)
+    pyr = corr_c.pyramid(vol, 16, 24)
+    np.testing.assert_allclose(pyr[0][::37][:11], g["pyr0_rows"][:11, 0], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(pyr[3], g["pyr3"][:384, 0], rtol=2e-5, atol=2e-4)
+    # lookup on the REFERENCE-equivalent pyramid so only the sampler differs
+    ref_pyr = [p[:384, 0].numpy().copy() for p in taps["pyramid"]]
+    out, tp = corr_c.lookup(ref_pyr, g["crand"])
+    np.testing.assert_allclose(out, g["look_rand"], rtol=2e-6, atol=5e-5)
+    # the C taps equal the torch replay's taps (which are pinned to ATen's in the test above)
+    sizes = [tuple(p.shape[-2:]) for p in ref_pyr]
+    for lvl, (x0, y0, _, _) in enumerate(orc.lookup_taps(torch.from_numpy(g["crand"]), sizes)):
+        assert (tp[:, lvl, 0] == x0.numpy()).all() and (tp[:, lvl, 1] == y0.numpy()).all()
