@@ -50,17 +50,36 @@ def synthetic_batch(b, h, w, seed, device):
     return [t.contiguous().to(device) for t in (i1, i2.clamp(0, 255), m1, torch.zeros_like(m1))]
 
 
+def host_cores() -> int:
+    """CPUs this process may really use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(h, w, iters, budget_s=20.0):
     """Time the CPU oracle on the SAME workload shape (B=1), bounded to ~budget_s."""
     from oracle import ffraft_ref as orc
     from oracle.weights import det_tensor
     with open(os.path.join(ROOT, "tests", "golden", "state_dict_spec.json")) as f:
         sd = {k: det_tensor(k, s) for k, s, _ in json.load(f)}
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads")
     inp = orc.shifted_pair(1, h, w, seed=1234)
     with torch.no_grad():
+        t0 = time.perf_counter()
         orc.ffraft_forward(sd, *inp, raft_iters=iters, test_mode=True)  # warm-up
+        log(f"cpu_baseline: warm-up forward {time.perf_counter() - t0:.2f} s")
         times = []
         t_end = time.perf_counter() + budget_s
         while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
@@ -108,8 +127,11 @@ def main():
         with torch.no_grad():
             return model(*batch, raft_iters=args.iters, test_mode=True)
 
-    for _ in range(args.warmup):
+    log(f"rank {rank}/{world}: model + {hi - lo} pairs on {torch.cuda.get_device_name(device)}")
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
     ops.profile_begin("ff_corr_lookup_fwd")          # HIP events around every lookup launch
     if world > 1:
         dist.barrier()
@@ -121,6 +143,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    log(f"{args.steps} timed steps in {elapsed:.3f} s")
     lookup_ms = ops.profile_end()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
