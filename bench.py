@@ -66,6 +66,18 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def pmc_traffic(queries):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_lookup_traffic.json:
+    TCC_EA0_RDREQ x 128 B + WRITE_SIZE), scaled per query; None if the profile is absent.  PMC passes
+    cannot run inside the timed process, so this is the same kernel measured by tools/bench_lookup.py."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_lookup_traffic.json")) as f:
+            d = json.load(f)
+        return int(d["traffic_bytes_per_launch"] / (d["algorithmic_bytes_per_launch"] / LOOKUP_BYTES_PER_QUERY) * queries)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(h, w, iters, budget_s=20.0):
     """Time the CPU oracle on the SAME workload shape (B=1), bounded to ~budget_s."""
     from oracle import ffraft_ref as orc
@@ -92,6 +104,49 @@ def cpu_baseline(h, w, iters, budget_s=20.0):
                       f"oracle/ffraft_ref.py on torch CPU"}
 
 
+def timed_region(step, steps, world, sync, device=None):
+    """Barrier + sync, K steps, sync + barrier; returns MAX elapsed over ranks (contract)."""
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed, out
+
+
+def harness_selftest(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+    lo, hi = shard_units(args.batch * world, world, rank)
+    owned = torch.zeros(args.batch * world, dtype=torch.int64)
+    owned[lo:hi] = 1
+    if world > 1:
+        dist.all_reduce(owned)
+    assert bool((owned == 1).all()), "shards must tile the global batch exactly once"
+    delay = 0.01 * (1 + rank)                       # rank r is slower: MAX must pick the last rank's time
+    elapsed, _ = timed_region(lambda: time.sleep(delay), args.steps, world, lambda: None)
+    assert elapsed >= 0.01 * world * args.steps * 0.95
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        print(json.dumps({"metric": "harness-selftest", "value": pairs / elapsed, "n_gpus": world, "steps": args.steps,
+                          "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak", "shard": [lo, hi]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,7 +157,12 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--harness-selftest", action="store_true",
+                    help="no model: a sleep() stands in for the step so the multi-rank harness (sharding, barrier, "
+                         "max-over-ranks timing, single JSON line) can be tested on CPU with gloo")
     args = ap.parse_args()
+    if args.harness_selftest:
+        return harness_selftest(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,22 +193,9 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     ops.profile_begin("ff_corr_lookup_fwd")          # HIP events around every lookup launch
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, out = timed_region(step, args.steps, world, torch.cuda.synchronize, device)
     log(f"{args.steps} timed steps in {elapsed:.3f} s")
     lookup_ms = ops.profile_end()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
     assert torch.isfinite(out[1]).all()
 
     if rank == 0:
@@ -164,9 +211,9 @@ def main():
             "config": {"workload": f"FF-RAFT forward (test_mode), {args.batch} pairs/GPU {args.height}x{args.width}, "
                                    f"iters={args.iters}, random-init weights, ORB-like masks (BASELINE configs[1])",
                        "pairs_per_gpu": args.batch, "parallelism": f"dp{world} (independent shards, no collective)"},
-            "roofline": {"kernel": "lookup_kernel (ff_corr_lookup_fwd)", "bound": "hbm",
+            "roofline": {"kernel": "lookup_wave_kernel (ff_corr_lookup_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(q),
                          "launches": len(lookup_ms), "avg_launch_us": round(per_launch_ms * 1e3, 2),
                          "algorithmic_bytes_per_launch": LOOKUP_BYTES_PER_QUERY * q},
         }

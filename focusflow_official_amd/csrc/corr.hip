@@ -7,6 +7,7 @@
 // bit-identical to the reference even where the round trip moves an integer
 // coordinate across a pixel boundary.
 #pragma clang fp contract(off)
+#include <cstdlib>
 #include "ff_common.h"
 
 namespace {
@@ -104,6 +105,142 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fast path (4 levels, radius 4): ONE WAVE PER QUERY, software-pipelined.
+//   taps    lanes 0..35 = (level, offset) replay the x- and y- tap chains once
+//           (72 chains per query instead of 648) and publish floor indices
+//           (relative to the staged window) + fractional weights in LDS.
+//   stage   the four source windows go to LDS as [11 rows][16 floats]: rows of
+//           planes whose width is a multiple of 4 are fetched as aligned
+//           16-byte loads (44 lanes x float4 per level), zero padding applied
+//           per load; other widths use dword loads.  11 rows/cols because the
+//           fp32 round trip can move a floor by one.
+//   blend   324 outputs = 4 LDS reads + blend each, stored as coalesced rows.
+// Pipeline: the window loads of query n+1 are issued into registers BEFORE the
+// blend of query n and land in LDS after it; its coords are prefetched one step
+// earlier still.  A block IS one wave, so barriers are wave-local.
+// ---------------------------------------------------------------------------
+constexpr int WROWS = 11, WCOLS = 16, NWIN = WROWS * WCOLS;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void lookup_wave_kernel(const LookupArgs a) {
+    __shared__ __attribute__((aligned(16))) float win[4 * NWIN];
+    __shared__ int tab_i[2][4][2][9];
+    __shared__ float tab_w[2][4][2][9];
+    __shared__ int org[2][4][2];     // [buf][level][x base (aligned), y base]
+    const int lane = threadIdx.x;
+    const int h0 = a.h[0], w0 = a.w[0];
+
+    const int t_lv = min(lane / 9, 3), t_o = lane - (lane / 9) * 9;   // tap role
+    const float t_inv = 1.f / (float)(1 << t_lv);
+    const int t_h = h0 >> t_lv, t_w = w0 >> t_lv;
+    const bool t_vec = (t_w & 3) == 0;
+    const int s_r = lane >> 2, s_g = lane & 3;                        // vector staging role (lane < 44)
+    const int d_r0 = lane / 11, d_c0 = lane - d_r0 * 11;              // dword staging role
+    const int d_r1 = (lane + 64) / 11, d_c1 = (lane + 64) - d_r1 * 11;
+
+    auto publish_taps = [&](long long q, float cx, float cy, int buf) {
+        int x0, y0;
+        float wx, wy;
+        tap_1d(cx, t_inv, t_o - 4, t_w, x0, wx);
+        tap_1d(cy, t_inv, t_o - 4, t_h, y0, wy);
+        const int fx0 = __shfl(x0, t_lv * 9), oy = __shfl(y0, t_lv * 9);   // taps of offset -4 = window origin
+        const int ox = t_vec ? (fx0 & ~3) : fx0;                          // aligned down for 16-byte loads
+        if (lane < 36) {
+            tab_i[buf][t_lv][0][t_o] = min(x0 - ox, WCOLS - 2);
+            tab_i[buf][t_lv][1][t_o] = min(y0 - oy, WROWS - 2);
+            tab_w[buf][t_lv][0][t_o] = wx;
+            tab_w[buf][t_lv][1][t_o] = wy;
+            if (t_o == 0) {
+                org[buf][t_lv][0] = ox;
+                org[buf][t_lv][1] = oy;
+            }
+            if (a.taps) {
+                int* t = a.taps + (q * 4 + t_lv) * 18;
+                t[t_o] = x0;
+                t[9 + t_o] = y0;
+            }
+        }
+    };
+
+    f32x4 rv[4];        // vector path: one float4 per level (lanes < 44)
+    float rd[4][2];     // dword path: two floats per level
+    auto issue_loads = [&](long long q, int buf) {
+#pragma unroll
+        for (int lv = 0; lv < 4; ++lv) {   // compile-time level: plane pointer and sizes stay scalar
+            const int hl = h0 >> lv, wl = w0 >> lv;
+            const float* pl = a.lvl[lv] + q * (long long)(hl * wl);
+            const int gx0 = org[buf][lv][0], gy0 = org[buf][lv][1];
+            if ((wl & 3) == 0) {
+                const int gy = gy0 + s_r, gx = gx0 + 4 * s_g;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (lane < 44 && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl)
+                    v = *reinterpret_cast<const f32x4*>(pl + gy * wl + gx);
+                rv[lv] = v;
+            } else {
+                int gy = gy0 + d_r0, gx = gx0 + d_c0;
+                rd[lv][0] = ((unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl) ? pl[gy * wl + gx] : 0.f;
+                gy = gy0 + d_r1, gx = gx0 + d_c1;
+                rd[lv][1] = (lane < 121 - 64 && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl) ? pl[gy * wl + gx] : 0.f;
+            }
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int lv = 0; lv < 4; ++lv) {
+            if (((w0 >> lv) & 3) == 0) {
+                if (lane < 44) *reinterpret_cast<f32x4*>(&win[lv * NWIN + s_r * WCOLS + 4 * s_g]) = rv[lv];
+            } else {
+                win[lv * NWIN + d_r0 * WCOLS + d_c0] = rd[lv][0];
+                if (lane < 121 - 64) win[lv * NWIN + d_r1 * WCOLS + d_c1] = rd[lv][1];
+            }
+        }
+    };
+
+    long long q = blockIdx.x;
+    if (q >= a.queries) return;
+    int cur = 0;
+    publish_taps(q, a.coords[q * 2], a.coords[q * 2 + 1], 0);
+    __syncthreads();
+    issue_loads(q, 0);
+    for (;;) {
+        const long long qn = q + gridDim.x;
+        const bool has_next = qn < a.queries;
+        float cxn = 0.f, cyn = 0.f;
+        if (has_next) {
+            cxn = a.coords[qn * 2];
+            cyn = a.coords[qn * 2 + 1];
+        }
+        store_window();                                  // waits for this query's window loads
+        if (has_next) publish_taps(qn, cxn, cyn, cur ^ 1);
+        __syncthreads();                                 // win + both table sets visible
+        if (has_next) issue_loads(qn, cur ^ 1);          // in flight during the blend below
+        float* orow = a.out + q * a.out_ld;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int k = lane + 64 * j;
+            if (k < 324) {
+                const int lv = k / 81, rem = k - lv * 81;
+                const int ia = rem / 9, ib = rem - ia * 9;
+                const int xi = tab_i[cur][lv][0][ia], yi = tab_i[cur][lv][1][ib];
+                const float fx = tab_w[cur][lv][0][ia], fy = tab_w[cur][lv][1][ib];
+                const float* p = &win[lv * NWIN + yi * WCOLS + xi];
+                const float v00 = p[0], v01 = p[1], v10 = p[WCOLS], v11 = p[WCOLS + 1];
+                const float ex = __fsub_rn(1.f, fx), sy = __fsub_rn(1.f, fy);
+                float o = __fmul_rn(v00, __fmul_rn(sy, ex));
+                o = __fadd_rn(o, __fmul_rn(v01, __fmul_rn(sy, fx)));
+                o = __fadd_rn(o, __fmul_rn(v10, __fmul_rn(fy, ex)));
+                o = __fadd_rn(o, __fmul_rn(v11, __fmul_rn(fy, fx)));
+                orow[k] = o;
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();                                 // everyone done reading win before it is overwritten
+        q = qn;
+        cur ^= 1;
+    }
+}
+
 }  // namespace
 
 extern "C" int ff_corr_pyramid(const float* l0, float* l1, float* l2, float* l3, long long planes, int h0, int w0,
@@ -145,6 +282,12 @@ extern "C" int ff_corr_lookup_fwd(const float* const* levels, int num_levels, in
     a.out_ld = out_ld;
     a.radius = radius;
     a.num_levels = num_levels;
+    static const int variant = getenv("FF_LOOKUP_GENERIC") ? 0 : 1;   // A/B switch for profiling only
+    if (variant == 1 && num_levels == 4 && radius == 4) {
+        long long blocks = queries < 256 * 32 ? queries : 256 * 32;
+        lookup_wave_kernel<<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
+        return ff::check_launch("ff_corr_lookup_fwd");
+    }
     const long long total = queries * nk;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
