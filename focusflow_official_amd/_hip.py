@@ -47,6 +47,20 @@ _SIGS = {
     "ff_gru_blend": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
     "ff_upsample_flow": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_nhwc_to_nchw": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    # backward
+    "ff_conv2d_wgrad": [C.POINTER(FFConvParams), _fp, _ll, _fp],
+    "ff_unpack_conv_wgrad": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
+    "ff_pack_conv_weight_dgrad": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp],
+    "ff_act_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, C.c_int, C.c_float, _fp],
+    "ff_dilate2": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_norm_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp, _fp,
+                    C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_corr_lookup_bwd": [C.POINTER(_fp), _fp, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
+    "ff_corr_pyramid_bwd": [_fp, _fp, _fp, _fp, _ll, C.c_int, C.c_int, _fp],
+    "ff_gru_rh_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
+    "ff_gru_blend_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                         _fp, C.c_int, _ll, C.c_int, _fp],
+    "ff_upsample_flow_bwd": [_fp, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
 }
 EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version"])
 

@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import fn, ops
 from .ops import ACT_NONE, ACT_RELU
 
 EPS = 1e-5
@@ -38,6 +38,8 @@ class PackedConv:
         self._key = None
         self.w = None
         self.b = None
+        self._dkey = None
+        self.wd = None
 
     def get(self):
         key = tuple((c.weight._version, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()) for c in self.convs)
@@ -52,6 +54,20 @@ class PackedConv:
                 off += c.out_channels
             self._key = key
         return self.w, self.b
+
+    def get_dgrad(self):
+        """Weights of the input-gradient convolution: [cin_pad][KH][KW][cout_pad], flipped + transposed."""
+        key = tuple((c.weight._version, c.weight.data_ptr()) for c in self.convs)
+        if key != self._dkey:
+            cout_pad = (self.cout + 3) // 4 * 4
+            self.wd = torch.zeros((self.cin_pad, self.kh * self.kw * cout_pad), dtype=torch.float32,
+                                  device=self.convs[0].weight.device)
+            off = 0
+            for c in self.convs:
+                ops.pack_conv_weight_dgrad(c.weight.detach(), self.wd, cout_pad, off)
+                off += c.out_channels
+            self._dkey = key
+        return self.wd
 
     def __call__(self, xs, act=ACT_NONE, **kw):
         w, b = self.get()
@@ -117,11 +133,11 @@ class FusionUnit(nn.Module):
 
     def run(self, mask, img):
         if self.fusion_type == "concat":
-            img_out = self.mask2img._p([img, mask])
-            mask_out = self.img2mask._p([mask, img]) if self.img2mask is not None else mask
+            img_out = fn.conv(self.mask2img._p, [img, mask])
+            mask_out = fn.conv(self.img2mask._p, [mask, img]) if self.img2mask is not None else mask
         else:  # out = q + conv1x1(v): the residual add rides in the conv epilogue
-            img_out = self.mask2img._p(mask, res=img)
-            mask_out = self.img2mask._p(img, res=mask) if self.img2mask is not None else mask
+            img_out = fn.conv(self.mask2img._p, mask, res=img)
+            mask_out = fn.conv(self.img2mask._p, img, res=mask) if self.img2mask is not None else mask
         return mask_out, img_out
 
 
@@ -174,20 +190,37 @@ class BasicParallelFusionLayer(nn.Module):
     # -- execution ---------------------------------------------------------
     def _conv_norm(self, x, pc: PackedConv, norm, act, res=None):
         """act(norm(conv(x))) and, with `res`, relu(res + that)."""
+        relu = act == ACT_RELU
+        params = [pc.convs[0].weight, pc.convs[0].bias]
+        if self.norm_fn == "batch":
+            params += [norm.weight, norm.bias]
+        taped = fn.recording(x, res, *params)
         if self.norm_fn == "instance":
-            y = pc(x)
-            st = ops.norm_stats(y, per_sample=True)
+            y = fn.conv(pc, x)
+            st = ops.norm_stats(y.detach(), per_sample=True)
+            if taped:
+                return fn.NormFn.apply(y, None, None, res, True, False, EPS, relu, st)
             return ops.norm_apply(y, st, True, EPS, act=act, res=res, out=y)
         if self.norm_fn == "batch":
             if norm.training:
-                y = pc(x)
-                st = ops.norm_stats(y, per_sample=False)
+                y = fn.conv(pc, x)
+                st = ops.norm_stats(y.detach(), per_sample=False)
                 b, h, w, _ = y.shape
                 ops.bn_update_running(norm, st, b * h * w)
                 norm.num_batches_tracked += 1
+                if taped:
+                    return fn.NormFn.apply(y, norm.weight, norm.bias, res, False, False, norm.eps, relu, st)
                 return ops.norm_apply(y, st, False, norm.eps, norm.weight, norm.bias, act=act, res=res, out=y)
+            if taped:  # frozen BatchNorm inside a training step (raft.py:104-107): fixed statistics
+                y = fn.conv(pc, x)
+                n = float(y.shape[0] * y.shape[1] * y.shape[2])
+                rm, rv = norm.running_mean.double(), norm.running_var.double()
+                st = torch.stack([rm * n, (rv + rm * rm) * n], -1)[None].contiguous()
+                return fn.NormFn.apply(y, norm.weight, norm.bias, res, False, True, norm.eps, relu, st)
             sc, sh = ops.bn_fold(norm)  # eval: scale/shift ride in the conv epilogue
             return pc(x, act=act, ch_scale=sc, ch_shift=sh, res=res, act_res=ACT_RELU)
+        if taped:
+            raise NotImplementedError("norm_fn='none' has no autograd path (unused by the reference configs)")
         return pc(x, act=act, res=res, act_res=ACT_RELU)  # 'none'
 
     def _block(self, blk: ResidualBlock, x):
@@ -209,7 +242,7 @@ class BasicParallelFusionLayer(nn.Module):
         m, x = self.fusion3.run(m, x)
         m, x = self._run_stage(self.mask_layer3, m), self._run_stage(self.layer3, x)
         m, x = self.fusion4.run(m, x)
-        m, x = self._mout(m), self._out(x)
+        m, x = fn.conv(self._mout, m), fn.conv(self._out, x)
         m, x = self.fusion5.run(m, x)
         return x
 

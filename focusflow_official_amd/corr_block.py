@@ -4,7 +4,7 @@ from typing import List
 
 import torch
 
-from . import ops
+from . import fn, ops
 
 
 class CorrBlock:
@@ -21,8 +21,16 @@ class CorrBlock:
         self.num_levels = num_levels
         self.radius = radius
         b, h, w, _ = fmap1.shape
-        vol = ops.corr_volume(fmap1.contiguous(), fmap2.contiguous())
-        self.corr_pyramid: List[torch.Tensor] = ops.corr_pyramid(vol, h, w)
+        self.grad_levels = None
+        self._token = None
+        fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+        if fn.recording(fmap1, fmap2):
+            vol = fn.CorrVolumeFn.apply(fmap1, fmap2)
+            self._token = fn.PyramidFn.apply(vol, self, h, w)      # sets self.corr_pyramid
+        else:
+            self.corr_pyramid: List[torch.Tensor] = ops.corr_pyramid(ops.corr_volume(fmap1, fmap2), h, w)
 
     def __call__(self, coords: torch.Tensor, want_taps: bool = False):
+        if self._token is not None and not want_taps:
+            return fn.LookupFn.apply(self._token, self, coords)
         return ops.corr_lookup(self.corr_pyramid, coords, self.radius, want_taps)

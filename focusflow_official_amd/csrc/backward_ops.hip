@@ -1,0 +1,486 @@
+// Backward kernels of the FF-RAFT hot path other than the convolution GEMMs
+// (SURVEY §3.3): activation masks, Instance/BatchNorm backward, lookup backward
+// (bilinear scatter into the pyramid gradient), pooling backward, GRU gates,
+// convex-upsampling backward.  All HBM-bound.
+#pragma clang fp contract(off)
+#include "ff_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_grad_from_output(float y, int act) {
+    switch (act) {
+        case FF_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case FF_ACT_SIGMOID: return y * (1.f - y);
+        case FF_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+// g[c] = dy[c] * act'(y[c]) * scale for c < C, 0 for C <= c < Cpad
+__global__ void act_bwd_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ y, int y_ld,
+                               float* __restrict__ g, int g_ld, long long npix, int C, int Cpad, int act, float scale) {
+    const long long total = npix * Cpad;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / Cpad;
+        const int c = (int)(i - p * Cpad);
+        float v = 0.f;
+        if (c < C) {
+            v = dy[p * dy_ld + c] * scale;
+            if (act != FF_ACT_NONE) v *= act_grad_from_output(y[p * y_ld + c], act);
+        }
+        g[p * g_ld + c] = v;
+    }
+}
+
+// zero-dilation by 2 (stride-2 dgrad): dst[b][2y][2x] = src[b][y][x], zeros elsewhere
+__global__ void dilate2_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int B, int Ho,
+                               int Wo, int Hd, int Wd, int C) {
+    const int cg = C >> 2;
+    const long long total = (long long)B * Hd * Wd * cg;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % cg);
+        long long t = i / cg;
+        const int x = (int)(t % Wd); t /= Wd;
+        const int y = (int)(t % Hd);
+        const long long b = t / Hd;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!(x & 1) && !(y & 1) && (x >> 1) < Wo && (y >> 1) < Ho)
+            v = *reinterpret_cast<const f32x4*>(src + ((b * Ho + (y >> 1)) * Wo + (x >> 1)) * src_ld + g * 4);
+        *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Norm backward.  xhat = (x-mean)*rstd ; y0 = gamma*xhat+beta ; y1 = relu?(y0) ; y = relu(y1+res)?
+//   g = dy * [y>0 if res] * [y0>0 if relu]
+//   pass 1: S1 = sum g, S2 = sum g*xhat   (fp64, per (sample|batch, channel))
+//   pass 2: dx = rstd*gamma*(g - S1/N - xhat*S2/N)   (fixed_stats: dx = rstd*gamma*g)
+//           dres = dy*[y>0]
+// ---------------------------------------------------------------------------
+struct NormBwdArgs {
+    const float* x; int x_ld;
+    const float* dy; int dy_ld;
+    const float* y; int y_ld;          // forward output (needed only when has_res)
+    const double* fstats;              // forward {sum, sumsq}
+    const float* gamma; const float* beta;
+    double* bstats;                    // {S1, S2}
+    float* dx; int dx_ld;
+    float* dres; int dres_ld;
+    int HW, C, per_sample, relu, has_res, fixed_stats;
+    double inv_count;
+    float eps;
+};
+
+__device__ __forceinline__ void norm_coeffs(const NormBwdArgs& a, int b, int c, float& mean, float& rstd, float& gm, float& bt) {
+    const double* st = a.fstats + ((long long)(a.per_sample ? b : 0) * a.C + c) * 2;
+    const double m = st[0] * a.inv_count;
+    double var = st[1] * a.inv_count - m * m;
+    if (var < 0) var = 0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    gm = a.gamma ? a.gamma[c] : 1.f;
+    bt = a.beta ? a.beta[c] : 0.f;
+}
+
+constexpr int NSLAB = 2048;
+
+__global__ __launch_bounds__(256) void norm_bwd_stats_kernel(const NormBwdArgs a) {
+    __shared__ double red[256 * 8];
+    __shared__ float s_mean[256], s_rstd[256], s_g[256], s_b[256];
+    const int b = blockIdx.y, t = threadIdx.x;
+    if (t < a.C) norm_coeffs(a, b, t, s_mean[t], s_rstd[t], s_g[t], s_b[t]);
+    __syncthreads();
+    const int cg = a.C >> 2, lanes_pix = 256 / cg;
+    const int g4 = t % cg, pl = t / cg;
+    const int p0 = blockIdx.x * NSLAB, p1 = min(p0 + NSLAB, a.HW);
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (pl < lanes_pix) {
+        for (int p = p0 + pl; p < p1; p += lanes_pix) {
+            const long long pix = (long long)b * a.HW + p;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + pix * a.x_ld + g4 * 4);
+            f32x4 gv = *reinterpret_cast<const f32x4*>(a.dy + pix * a.dy_ld + g4 * 4);
+            f32x4 yv = {1.f, 1.f, 1.f, 1.f};
+            if (a.has_res) yv = *reinterpret_cast<const f32x4*>(a.y + pix * a.y_ld + g4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = g4 * 4 + j;
+                const float xhat = (xv[j] - s_mean[c]) * s_rstd[c];
+                float g = gv[j];
+                if (a.has_res && !(yv[j] > 0.f)) g = 0.f;
+                if (a.relu && !(xhat * s_g[c] + s_b[c] > 0.f)) g = 0.f;
+                s1[j] += (double)g;
+                s2[j] += (double)g * (double)xhat;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[t * 8 + j] = s1[j];
+        red[t * 8 + 4 + j] = s2[j];
+    }
+    __syncthreads();
+    if (t < a.C) {
+        const int gg = t >> 2, j = t & 3;
+        double ss = 0, qq = 0;
+        for (int k = 0; k < lanes_pix; ++k) {
+            ss += red[(k * cg + gg) * 8 + j];
+            qq += red[(k * cg + gg) * 8 + 4 + j];
+        }
+        double* dst = a.bstats + ((long long)(a.per_sample ? b : 0) * a.C + t) * 2;
+        atomicAdd(dst, ss);
+        atomicAdd(dst + 1, qq);
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormBwdArgs a) {
+    __shared__ float s_mean[256], s_rstd[256], s_g[256], s_b[256], s_m1[256], s_m2[256];
+    const int b = blockIdx.y, t = threadIdx.x;
+    if (t < a.C) {
+        norm_coeffs(a, b, t, s_mean[t], s_rstd[t], s_g[t], s_b[t]);
+        const double* bs = a.bstats + ((long long)(a.per_sample ? b : 0) * a.C + t) * 2;
+        s_m1[t] = a.fixed_stats ? 0.f : (float)(bs[0] * a.inv_count);
+        s_m2[t] = a.fixed_stats ? 0.f : (float)(bs[1] * a.inv_count);
+    }
+    __syncthreads();
+    const int cg = a.C >> 2;
+    const int total = a.HW * cg;
+    for (int i = blockIdx.x * 256 + t; i < total; i += gridDim.x * 256) {
+        const int g4 = i % cg;
+        const long long pix = (long long)b * a.HW + i / cg;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + pix * a.x_ld + g4 * 4);
+        f32x4 gv = *reinterpret_cast<const f32x4*>(a.dy + pix * a.dy_ld + g4 * 4);
+        f32x4 yv = {1.f, 1.f, 1.f, 1.f};
+        if (a.has_res) yv = *reinterpret_cast<const f32x4*>(a.y + pix * a.y_ld + g4 * 4);
+        f32x4 dxv, drv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = g4 * 4 + j;
+            const float xhat = (xv[j] - s_mean[c]) * s_rstd[c];
+            float g = gv[j];
+            if (a.has_res && !(yv[j] > 0.f)) g = 0.f;
+            drv[j] = g;
+            if (a.relu && !(xhat * s_g[c] + s_b[c] > 0.f)) g = 0.f;
+            dxv[j] = s_rstd[c] * s_g[c] * (g - s_m1[c] - xhat * s_m2[c]);
+        }
+        *reinterpret_cast<f32x4*>(a.dx + pix * a.dx_ld + g4 * 4) = dxv;
+        if (a.dres) *reinterpret_cast<f32x4*>(a.dres + pix * a.dres_ld + g4 * 4) = drv;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Lookup backward: dlevel[l][q][y][x] += dout[q][k] * bilinear weight.
+// One wave per query: the 324 output gradients are scattered into an LDS copy of
+// the four 11x16 windows (ds_add_f32), which is then added to the gradient planes
+// with plain read-modify-write — race free, because inside one launch every
+// (query, plane element) belongs to exactly one lane; launches of successive
+// iterations are ordered by the stream.
+// ---------------------------------------------------------------------------
+struct LookupBwdArgs {
+    float* dlvl[4];
+    const float* coords;
+    const float* dout;
+    long long queries;
+    int h0, w0, dout_ld;
+};
+
+__device__ __forceinline__ void tap_1d_b(float c, float inv_scale, int off, int n, int& i0, float& w1) {
+    const float cl = __fmul_rn(c, inv_scale);
+    const float x = __fadd_rn(cl, (float)off);
+    const float nm1 = (float)(n - 1);
+    const float g = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, x), nm1), 1.f);
+    const float u = __fmul_rn(__fmul_rn(__fadd_rn(g, 1.f), 0.5f), nm1);
+    const float f = floorf(u);
+    i0 = (int)f;
+    w1 = __fsub_rn(u, f);
+}
+
+constexpr int BW_ROWS = 11, BW_COLS = 12, BW_N = BW_ROWS * BW_COLS;
+
+__global__ __launch_bounds__(64) void lookup_bwd_kernel(const LookupBwdArgs a) {
+    __shared__ float win[4 * BW_N];
+    __shared__ int tab_i[4][2][9];
+    __shared__ float tab_w[4][2][9];
+    __shared__ int org[4][2];
+    const int lane = threadIdx.x;
+    const int t_lv = min(lane / 9, 3), t_o = lane - (lane / 9) * 9;
+    const float t_inv = 1.f / (float)(1 << t_lv);
+    const int t_h = a.h0 >> t_lv, t_w = a.w0 >> t_lv;
+    for (long long q = blockIdx.x; q < a.queries; q += gridDim.x) {
+        int x0, y0;
+        float wx, wy;
+        tap_1d_b(a.coords[q * 2], t_inv, t_o - 4, t_w, x0, wx);
+        tap_1d_b(a.coords[q * 2 + 1], t_inv, t_o - 4, t_h, y0, wy);
+        const int ox = __shfl(x0, t_lv * 9), oy = __shfl(y0, t_lv * 9);
+        if (lane < 36) {
+            tab_i[t_lv][0][t_o] = min(x0 - ox, BW_COLS - 2);
+            tab_i[t_lv][1][t_o] = min(y0 - oy, BW_ROWS - 2);
+            tab_w[t_lv][0][t_o] = wx;
+            tab_w[t_lv][1][t_o] = wy;
+            if (t_o == 0) {
+                org[t_lv][0] = x0;
+                org[t_lv][1] = y0;
+            }
+        }
+        for (int e = lane; e < 4 * BW_N; e += 64) win[e] = 0.f;
+        __syncthreads();
+        const float* drow = a.dout + q * a.dout_ld;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int k = lane + 64 * j;
+            if (k < 324) {
+                const int lv = k / 81, rem = k - lv * 81;
+                const int ia = rem / 9, ib = rem - ia * 9;
+                const int xi = tab_i[lv][0][ia], yi = tab_i[lv][1][ib];
+                const float fx = tab_w[lv][0][ia], fy = tab_w[lv][1][ib];
+                const float g = drow[k];
+                const float ex = 1.f - fx, sy = 1.f - fy;
+                float* p = &win[lv * BW_N + yi * BW_COLS + xi];
+                atomicAdd(p, g * (sy * ex));
+                atomicAdd(p + 1, g * (sy * fx));
+                atomicAdd(p + BW_COLS, g * (fy * ex));
+                atomicAdd(p + BW_COLS + 1, g * (fy * fx));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int lv = 0; lv < 4; ++lv) {
+            const int hl = a.h0 >> lv, wl = a.w0 >> lv;
+            float* pl = a.dlvl[lv] + q * (long long)(hl * wl);
+            const int gx0 = org[lv][0], gy0 = org[lv][1];
+            for (int e = lane; e < BW_N; e += 64) {
+                const int r = e / BW_COLS, c = e - r * BW_COLS;
+                const int gy = gy0 + r, gx = gx0 + c;
+                const float v = win[lv * BW_N + e];
+                if (v != 0.f && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl) pl[gy * wl + gx] += v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// pooling backward chain: dl2 += up(dl3)/4 ; dl1 += up(dl2)/4 ; dl0 += up(dl1)/4  (in place)
+__global__ __launch_bounds__(256) void pyramid_bwd_kernel(float* __restrict__ d0, float* __restrict__ d1,
+                                                          float* __restrict__ d2, const float* __restrict__ d3, int h0,
+                                                          int w0) {
+    extern __shared__ float sm[];
+    const int h1 = h0 >> 1, w1 = w0 >> 1, h2 = h1 >> 1, w2 = w1 >> 1, h3 = h2 >> 1, w3 = w2 >> 1;
+    float* s2 = sm;               // h2*w2
+    float* s1 = sm + h2 * w2;     // h1*w1
+    const long long plane = blockIdx.x;
+    for (int i = threadIdx.x; i < h2 * w2; i += 256) {
+        const int y = i / w2, x = i - y * w2;
+        float v = d2[plane * h2 * w2 + i];
+        if ((y >> 1) < h3 && (x >> 1) < w3) v += 0.25f * d3[plane * h3 * w3 + (y >> 1) * w3 + (x >> 1)];
+        s2[i] = v;
+        d2[plane * h2 * w2 + i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < h1 * w1; i += 256) {
+        const int y = i / w1, x = i - y * w1;
+        float v = d1[plane * h1 * w1 + i];
+        if ((y >> 1) < h2 && (x >> 1) < w2) v += 0.25f * s2[(y >> 1) * w2 + (x >> 1)];
+        s1[i] = v;
+        d1[plane * h1 * w1 + i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < h0 * w0; i += 256) {
+        const int y = i / w0, x = i - y * w0;
+        if ((y >> 1) < h1 && (x >> 1) < w1) d0[plane * h0 * w0 + i] += 0.25f * s1[(y >> 1) * w1 + (x >> 1)];
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void gru_rh_bwd_kernel(const float* __restrict__ drh, int drh_ld, const float* __restrict__ r, int r_ld,
+                                  const float* __restrict__ h, int h_ld, float* __restrict__ dr, int dr_ld,
+                                  float* __restrict__ dh, int dh_ld, long long npix, int C) {
+    const int cg = C >> 2;
+    const long long total = npix * cg;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / cg;
+        const int g = (int)(i - p * cg) * 4;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(drh + p * drh_ld + g);
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(r + p * r_ld + g);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(h + p * h_ld + g);
+        *reinterpret_cast<f32x4*>(dr + p * dr_ld + g) = d * hv;
+        *reinterpret_cast<f32x4*>(dh + p * dh_ld + g) = d * rv;
+    }
+}
+
+// h' = (1-z)*h + z*q : dz = dh'*(q-h), dq = dh'*z, dh = dh'*(1-z)
+__global__ void gru_blend_bwd_kernel(const float* __restrict__ dhn, int dhn_ld, const float* __restrict__ z, int z_ld,
+                                     const float* __restrict__ q, int q_ld, const float* __restrict__ h, int h_ld,
+                                     float* __restrict__ dz, int dz_ld, float* __restrict__ dq, int dq_ld,
+                                     float* __restrict__ dh, int dh_ld, long long npix, int C) {
+    const int cg = C >> 2;
+    const long long total = npix * cg;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / cg;
+        const int g = (int)(i - p * cg) * 4;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dhn + p * dhn_ld + g);
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + p * z_ld + g);
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(q + p * q_ld + g);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(h + p * h_ld + g);
+        *reinterpret_cast<f32x4*>(dz + p * dz_ld + g) = d * (qv - hv);
+        *reinterpret_cast<f32x4*>(dq + p * dq_ld + g) = d * zv;
+        *reinterpret_cast<f32x4*>(dh + p * dh_ld + g) = d * (1.f - zv);
+    }
+}
+
+// Convex upsampling backward.  One block per coarse row (b,h); dflow contributions
+// for rows h-1..h+1 are reduced in LDS, then added to dflow with atomics.
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ flow,
+                                                           int flow_ld, const float* __restrict__ mask, int mask_ld,
+                                                           float* __restrict__ dflow, float* __restrict__ dmask, int H,
+                                                           int W) {
+    extern __shared__ float acc[];   // [3][W][2]
+    const int b = blockIdx.y, h = blockIdx.x;
+    for (int i = threadIdx.x; i < 3 * W * 2; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const long long rowpix = ((long long)b * H + h) * W;
+    const int HW8 = 64 * H * W;
+    for (int t = threadIdx.x; t < W * 64; t += 256) {
+        const int w = t >> 6, ij = t & 63, i = ij >> 3, j = ij & 7;
+        const float* m = mask + (rowpix + w) * mask_ld + ij;
+        float pk[9], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            pk[k] = m[k * 64];
+            mx = fmaxf(mx, pk[k]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            pk[k] = expf(pk[k] - mx);
+            den += pk[k];
+        }
+        const long long o = (long long)b * 2 * HW8 + (long long)(8 * h + i) * (8 * W) + 8 * w + j;
+        const float gx = dout[o], gy = dout[o + HW8];
+        float s[9], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            pk[k] /= den;
+            const int yy = h + k / 3 - 1, xx = w + k % 3 - 1;
+            float fx = 0.f, fy = 0.f;
+            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            if (in) {
+                const float* f = flow + (((long long)b * H + yy) * W + xx) * flow_ld;
+                fx = 8.f * f[0];
+                fy = 8.f * f[1];
+                atomicAdd(&acc[((k / 3) * W + xx) * 2], 8.f * pk[k] * gx);
+                atomicAdd(&acc[((k / 3) * W + xx) * 2 + 1], 8.f * pk[k] * gy);
+            }
+            s[k] = gx * fx + gy * fy;
+            dot += pk[k] * s[k];
+        }
+        float* dm = dmask + (rowpix + w) * 576 + ij;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dm[k * 64] = pk[k] * (s[k] - dot);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * W * 2; i += 256) {
+        const int rr = i / (W * 2), rem = i - rr * W * 2;
+        const int yy = h + rr - 1;
+        if ((unsigned)yy < (unsigned)H && acc[i] != 0.f)
+            atomicAdd(dflow + (((long long)b * H + yy) * W) * 2 + rem, acc[i]);
+    }
+}
+
+inline int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int ff_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* g, int g_ld, long long npix,
+                          int C, int Cpad, int act, float scale, void* stream) {
+    FF_REQUIRE(dy && g && npix > 0 && C > 0 && Cpad >= C && g_ld >= Cpad && dy_ld >= C, "ff_act_bwd: bad argument");
+    FF_REQUIRE(act == FF_ACT_NONE || (y && y_ld >= C), "ff_act_bwd: activation needs the forward output");
+    act_bwd_kernel<<<grid_for(npix * Cpad), 256, 0, static_cast<hipStream_t>(stream)>>>(dy, dy_ld, y, y_ld, g, g_ld, npix, C, Cpad, act, scale);
+    return ff::check_launch("ff_act_bwd");
+}
+
+extern "C" int ff_dilate2(const float* src, int src_ld, float* dst, int B, int Ho, int Wo, int Hd, int Wd, int C,
+                          void* stream) {
+    FF_REQUIRE(src && dst && B > 0 && Ho > 0 && Wo > 0 && Hd >= 2 * Ho - 1 && Wd >= 2 * Wo - 1 && C % 4 == 0 && src_ld % 4 == 0 &&
+               ff::aligned16(src) && ff::aligned16(dst), "ff_dilate2: bad argument");
+    dilate2_kernel<<<grid_for((long long)B * Hd * Wd * (C / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(src, src_ld, dst, B, Ho, Wo, Hd, Wd, C);
+    return ff::check_launch("ff_dilate2");
+}
+
+extern "C" int ff_norm_bwd(const float* x, int x_ld, const float* dy, int dy_ld, const float* y, int y_ld,
+                           const double* fstats, double* bstats, int per_sample, int fixed_stats, float eps,
+                           const float* gamma, const float* beta, int relu, float* dx, int dx_ld, float* dres,
+                           int dres_ld, int B, int HW, int C, void* stream) {
+    FF_REQUIRE(x && dy && fstats && bstats && dx, "ff_norm_bwd: null pointer");
+    FF_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 256, "ff_norm_bwd: C=%d unsupported", C);
+    FF_REQUIRE(x_ld % 4 == 0 && dy_ld % 4 == 0 && dx_ld % 4 == 0 && ff::aligned16(x) && ff::aligned16(dy) && ff::aligned16(dx), "ff_norm_bwd: alignment");
+    FF_REQUIRE(!dres || (y && y_ld % 4 == 0 && dres_ld % 4 == 0 && ff::aligned16(y) && ff::aligned16(dres)), "ff_norm_bwd: residual needs y and aligned dres");
+    NormBwdArgs a;
+    a.x = x; a.x_ld = x_ld; a.dy = dy; a.dy_ld = dy_ld; a.y = y; a.y_ld = y_ld;
+    a.fstats = fstats; a.gamma = gamma; a.beta = beta; a.bstats = bstats;
+    a.dx = dx; a.dx_ld = dx_ld; a.dres = dres; a.dres_ld = dres_ld;
+    a.HW = HW; a.C = C; a.per_sample = per_sample; a.relu = relu; a.has_res = dres != nullptr; a.fixed_stats = fixed_stats;
+    a.inv_count = 1.0 / ((double)HW * (per_sample ? 1 : B));
+    a.eps = eps;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 g1((HW + NSLAB - 1) / NSLAB, B);
+    norm_bwd_stats_kernel<<<g1, 256, 0, s>>>(a);
+    int gx = (int)(((long long)HW * (C / 4) + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    norm_bwd_apply_kernel<<<dim3(gx, B), 256, 0, s>>>(a);
+    return ff::check_launch("ff_norm_bwd");
+}
+
+extern "C" int ff_corr_lookup_bwd(float* const* dlevels, const float* coords, const float* dout, int dout_ld,
+                                  long long queries, int h0, int w0, void* stream) {
+    FF_REQUIRE(dlevels && coords && dout && queries > 0 && dout_ld >= 324, "ff_corr_lookup_bwd: bad argument");
+    FF_REQUIRE((h0 >> 3) >= 2 && (w0 >> 3) >= 2, "ff_corr_lookup_bwd: level 3 must be at least 2x2");
+    LookupBwdArgs a;
+    for (int i = 0; i < 4; ++i) {
+        FF_REQUIRE(dlevels[i] != nullptr, "ff_corr_lookup_bwd: level %d null", i);
+        a.dlvl[i] = dlevels[i];
+    }
+    a.coords = coords; a.dout = dout; a.queries = queries; a.h0 = h0; a.w0 = w0; a.dout_ld = dout_ld;
+    const long long blocks = queries < 256 * 32 ? queries : 256 * 32;
+    lookup_bwd_kernel<<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
+    return ff::check_launch("ff_corr_lookup_bwd");
+}
+
+extern "C" int ff_corr_pyramid_bwd(float* d0, float* d1, float* d2, const float* d3, long long planes, int h0, int w0,
+                                   void* stream) {
+    FF_REQUIRE(d0 && d1 && d2 && d3 && planes > 0 && planes < (1ll << 31) && h0 >= 8 && w0 >= 8, "ff_corr_pyramid_bwd: bad argument");
+    const int h1 = h0 / 2, w1 = w0 / 2, h2 = h1 / 2, w2 = w1 / 2;
+    const size_t lds = (size_t)(h1 * w1 + h2 * w2) * sizeof(float);
+    FF_REQUIRE(lds <= 64 * 1024, "ff_corr_pyramid_bwd: plane too large");
+    pyramid_bwd_kernel<<<(unsigned)planes, 256, lds, static_cast<hipStream_t>(stream)>>>(d0, d1, d2, d3, h0, w0);
+    return ff::check_launch("ff_corr_pyramid_bwd");
+}
+
+extern "C" int ff_gru_rh_bwd(const float* drh, int drh_ld, const float* r, int r_ld, const float* h, int h_ld, float* dr,
+                             int dr_ld, float* dh, int dh_ld, long long npix, int C, void* stream) {
+    FF_REQUIRE(drh && r && h && dr && dh && npix > 0 && C % 4 == 0, "ff_gru_rh_bwd: bad argument");
+    FF_REQUIRE((drh_ld | r_ld | h_ld | dr_ld | dh_ld) % 4 == 0 && ff::aligned16(drh) && ff::aligned16(r) && ff::aligned16(h) && ff::aligned16(dr) && ff::aligned16(dh), "ff_gru_rh_bwd: alignment");
+    gru_rh_bwd_kernel<<<grid_for(npix * (C / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(drh, drh_ld, r, r_ld, h, h_ld, dr, dr_ld, dh, dh_ld, npix, C);
+    return ff::check_launch("ff_gru_rh_bwd");
+}
+
+extern "C" int ff_gru_blend_bwd(const float* dhn, int dhn_ld, const float* z, int z_ld, const float* q, int q_ld,
+                                const float* h, int h_ld, float* dz, int dz_ld, float* dq, int dq_ld, float* dh,
+                                int dh_ld, long long npix, int C, void* stream) {
+    FF_REQUIRE(dhn && z && q && h && dz && dq && dh && npix > 0 && C % 4 == 0, "ff_gru_blend_bwd: bad argument");
+    FF_REQUIRE((dhn_ld | z_ld | q_ld | h_ld | dz_ld | dq_ld | dh_ld) % 4 == 0 && ff::aligned16(dhn) && ff::aligned16(z) && ff::aligned16(q) && ff::aligned16(h) && ff::aligned16(dz) && ff::aligned16(dq) && ff::aligned16(dh), "ff_gru_blend_bwd: alignment");
+    gru_blend_bwd_kernel<<<grid_for(npix * (C / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(dhn, dhn_ld, z, z_ld, q, q_ld, h, h_ld, dz, dz_ld, dq, dq_ld, dh, dh_ld, npix, C);
+    return ff::check_launch("ff_gru_blend_bwd");
+}
+
+extern "C" int ff_upsample_flow_bwd(const float* dout_nchw, const float* flow, int flow_ld, const float* mask,
+                                    int mask_ld, float* dflow, float* dmask, int B, int H, int W, void* stream) {
+    FF_REQUIRE(dout_nchw && flow && mask && dflow && dmask && B > 0 && H > 0 && W > 0 && flow_ld >= 2 && mask_ld >= 576,
+               "ff_upsample_flow_bwd: bad argument");
+    const size_t lds = (size_t)3 * W * 2 * sizeof(float);
+    upsample_bwd_kernel<<<dim3(H, B), 256, lds, static_cast<hipStream_t>(stream)>>>(dout_nchw, flow, flow_ld, mask, mask_ld, dflow, dmask, H, W);
+    return ff::check_launch("ff_upsample_flow_bwd");
+}

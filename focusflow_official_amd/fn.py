@@ -1,0 +1,255 @@
+"""torch.autograd.Function wrappers: every forward AND backward is a sequence of
+libfocusflow_hip launches.  PyTorch contributes the tape (which node feeds which)
+and gradient accumulation into `.grad`, nothing else.
+
+The dispatchers at the bottom (`conv`, `norm`, ...) pick the fused inference
+launch when no gradient is being recorded and the autograd node otherwise.
+"""
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU
+
+Tensor = torch.Tensor
+
+
+def _dense(t: Tensor) -> Tensor:
+    """Gradients may arrive as arbitrary views; kernels want pixel-dense NHWC with ld % 4 == 0."""
+    if t.stride(-1) == 1 and t.is_contiguous():
+        return t
+    return t.contiguous()
+
+
+# ----------------------------------------------------------------------------
+class ConvFn(torch.autograd.Function):
+    """y = act(conv(cat(xs)) + bias) * ... (+ res).  tensors = xs..., [res], (w_i, b_i)..."""
+
+    @staticmethod
+    def forward(ctx, pc, act, out_scale, nseg, has_res, pad_out, fill_tail, *tensors):
+        xs = list(tensors[:nseg])
+        res = tensors[nseg] if has_res else None
+        assert not (has_res and act != ACT_NONE), "residual + activation is only fused on the inference path"
+        w, b = pc.get()
+        out = None
+        if pad_out:  # allocate the channel-padded tensor; the caller owns channels >= Cout (filled by fill_tail)
+            bsz, h, wd, _ = xs[0].shape
+            ho = (h + 2 * pc.pad[0] - pc.kh) // pc.stride + 1
+            wo = (wd + 2 * pc.pad[1] - pc.kw) // pc.stride + 1
+            full = ops.empty_nhwc(bsz, ho, wo, (pc.cout + 3) // 4 * 4, xs[0])
+            out = full[..., :pc.cout]
+        y = ops.conv2d(xs, w, b, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, act=act, out=out, res=res,
+                       out_scale=out_scale)
+        if pad_out:
+            if fill_tail is not None:
+                fill_tail(full)
+            y = full
+        ctx.pc, ctx.act, ctx.out_scale, ctx.nseg, ctx.has_res = pc, act, out_scale, nseg, has_res
+        ctx.save_for_backward(*xs, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pc, act, nseg = ctx.pc, ctx.act, ctx.nseg
+        saved = ctx.saved_tensors
+        xs, y = list(saved[:nseg]), saved[nseg]
+        dy = _dense(dy)
+        g = ops.act_bwd(dy, y, act, ctx.out_scale, pc.cout)            # (B,Ho,Wo,Cpad), zero padded
+        grads: List[Optional[Tensor]] = [None] * 7
+        # input gradient: forward conv over g with flipped/transposed weights
+        need_dx = any(ctx.needs_input_grad[7 + i] for i in range(nseg))
+        dxs = [None] * nseg
+        if need_dx:
+            wd = pc.get_dgrad()
+            cin_tot = sum(x.shape[3] for x in xs)
+            b, h, w, _ = xs[0].shape
+            gi = g
+            if pc.stride == 2:
+                gi = ops.dilate2(g, h + 2 * pc.pad[0] - pc.kh + 1, w + 2 * pc.pad[1] - pc.kw + 1)
+            elif pc.stride != 1:
+                raise NotImplementedError("stride > 2")
+            dx = ops.conv2d([gi], wd, None, cin_tot, pc.kh, pc.kw, 1, (pc.kh - 1 - pc.pad[0], pc.kw - 1 - pc.pad[1]))
+            off = 0
+            for i, x in enumerate(xs):
+                if ctx.needs_input_grad[7 + i]:
+                    dxs[i] = dx[..., off:off + x.shape[3]]
+                off += x.shape[3]
+        grads += dxs
+        if ctx.has_res:
+            grads.append(dy)                                           # y = conv + res
+        # parameter gradients
+        base = 7 + nseg + (1 if ctx.has_res else 0)
+        need_w = any(ctx.needs_input_grad[base:])
+        dwp = ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad) if need_w else None
+        db = ops.channel_sum(g, pc.cout) if need_w else None
+        off = 0
+        for j, cv in enumerate(pc.convs):
+            co = cv.out_channels
+            gw = gb = None
+            if ctx.needs_input_grad[base + 2 * j]:
+                gw = ops.unpack_conv_wgrad(dwp, co, pc.cin, pc.kh, pc.kw, pc.cin_pad, off)
+            if ctx.needs_input_grad[base + 2 * j + 1]:
+                gb = db[off:off + co]
+            grads += [gw, gb]
+            off += co
+        return tuple(grads)
+
+
+class NormFn(torch.autograd.Function):
+    """y = relu?(norm(x)) ; with res: y = relu(y + res).  Instance (per-sample) or batch statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, per_sample, fixed, eps, relu, stats):
+        y = ops.norm_apply(x, stats, per_sample, eps, gamma, beta, act=ACT_RELU if relu else ACT_NONE, res=res)
+        ctx.meta = (per_sample, fixed, eps, relu, res is not None)
+        ctx.save_for_backward(x, gamma, beta, y if res is not None else None, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        per_sample, fixed, eps, relu, has_res = ctx.meta
+        x, gamma, beta, y, stats = ctx.saved_tensors
+        dx, dres, bst = ops.norm_bwd(x, _dense(dy), y, stats, per_sample, fixed, eps, gamma, beta, relu, has_res)
+        dgamma = dbeta = None
+        if gamma is not None and ctx.needs_input_grad[1]:
+            dgamma = bst[0, :, 1].float()
+        if beta is not None and ctx.needs_input_grad[2]:
+            dbeta = bst[0, :, 0].float()
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
+
+
+class ActFn(torch.autograd.Function):
+    """dst = act(src) on a channel slice (torch.split + tanh/relu of raft.py:205-207)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        y = ops.empty_nhwc(*x.shape, x)
+        ops.act_copy(x, y, act)
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.act_bwd(_dense(dy), y, ctx.act, 1.0, y.shape[3]), None
+
+
+class GruRhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r, h):
+        ctx.save_for_backward(r, h)
+        return ops.gru_rh(r, h)
+
+    @staticmethod
+    def backward(ctx, drh):
+        r, h = ctx.saved_tensors
+        return ops.gru_rh_bwd(_dense(drh), r, h)
+
+
+class GruBlendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, q, h):
+        ctx.save_for_backward(z, q, h)
+        return ops.gru_blend(z, q, h)
+
+    @staticmethod
+    def backward(ctx, dhn):
+        z, q, h = ctx.saved_tensors
+        return ops.gru_blend_bwd(_dense(dhn), z, q, h)
+
+
+class UpsampleFn(torch.autograd.Function):
+    """flow_up = convex_upsample(flow, mask); flow = flow_prev.detach() + delta, so d(delta) = d(flow)."""
+
+    @staticmethod
+    def forward(ctx, flow4, delta, up_mask):
+        ctx.save_for_backward(flow4, up_mask)
+        return ops.upsample_flow(flow4, up_mask)
+
+    @staticmethod
+    def backward(ctx, dout):
+        flow4, up_mask = ctx.saved_tensors
+        dflow, dmask = ops.upsample_flow_bwd(dout, flow4, up_mask)
+        return None, dflow, dmask
+
+
+# ---- CorrBlock -------------------------------------------------------------
+class CorrVolumeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2):
+        ctx.save_for_backward(f1, f2)
+        return ops.corr_volume(f1, f2)
+
+    @staticmethod
+    def backward(ctx, dvol):
+        f1, f2 = ctx.saved_tensors
+        return ops.corr_volume_bwd(dvol, f1, f2)
+
+
+class PyramidFn(torch.autograd.Function):
+    """vol -> token.  The pooled levels live on `block`; lookups accumulate their gradients into
+    block.grad_levels (no per-iteration volume-sized autograd buffers), and this node — which autograd
+    runs after every LookupFn because of the token edge — folds them down to d(vol)."""
+
+    @staticmethod
+    def forward(ctx, vol, block, h, w):
+        block.corr_pyramid = ops.corr_pyramid(vol, h, w)
+        block.grad_levels = None
+        ctx.block = block
+        ctx.shape = vol.shape
+        return torch.zeros(1, device=vol.device)
+
+    @staticmethod
+    def backward(ctx, dtoken):
+        gl = ctx.block.grad_levels
+        if gl is None:
+            return torch.zeros(ctx.shape, device=dtoken.device), None, None, None
+        ops.corr_pyramid_bwd(gl)
+        ctx.block.grad_levels = None
+        return gl[0].view(ctx.shape), None, None, None
+
+
+class LookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, token, block, coords):
+        ctx.block = block
+        ctx.save_for_backward(coords)
+        return ops.corr_lookup(block.corr_pyramid, coords, block.radius)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (coords,) = ctx.saved_tensors
+        blk = ctx.block
+        if blk.grad_levels is None:
+            blk.grad_levels = [torch.zeros_like(lv) for lv in blk.corr_pyramid]
+        ops.corr_lookup_bwd(blk.grad_levels, coords, _dense(dout))
+        return torch.zeros(1, device=dout.device), None, None
+
+
+# ----------------------------------------------------------------------------
+# dispatchers
+# ----------------------------------------------------------------------------
+def recording(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail=None):
+    """Convolution through a PackedConv group.  pad_out: return the channel-padded tensor."""
+    if not isinstance(xs, (list, tuple)):
+        xs = [xs]
+    params = [t for cv in pc.convs for t in (cv.weight, cv.bias)]
+    if recording(*xs, res, *params):
+        args = list(xs) + ([res] if res is not None else []) + params
+        return ConvFn.apply(pc, act, out_scale, len(xs), res is not None, pad_out, fill_tail, *args)
+    if pad_out:
+        b, h, w, _ = xs[0].shape
+        ho = (h + 2 * pc.pad[0] - pc.kh) // pc.stride + 1
+        wo = (w + 2 * pc.pad[1] - pc.kw) // pc.stride + 1
+        full = ops.empty_nhwc(b, ho, wo, (pc.cout + 3) // 4 * 4, xs[0])
+        pc(xs, act=act, res=res, out_scale=out_scale, out=full[..., :pc.cout])
+        if fill_tail is not None:
+            fill_tail(full)
+        return full
+    return pc(xs, act=act, res=res, out_scale=out_scale)

@@ -273,3 +273,156 @@ def nhwc_to_nchw(x: Tensor) -> Tensor:
     out = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
     _hip.call("ff_nhwc_to_nchw", _p(x), _ld(x), _p(out), b, h, w, c, _stream())
     return out
+
+
+# ----------------------------------------------------------------------------
+# backward wrappers
+# ----------------------------------------------------------------------------
+def _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo):
+    p = FFConvParams()
+    for i, x in enumerate(xs):
+        p.x[i], p.x_ld[i], p.x_c[i], p.x_gstride[i] = x.data_ptr(), _ld(x), x.shape[3], 0
+    p.groups, p.B, p.H, p.W = 1, b, h, w
+    p.Ho, p.Wo, p.Cout = ho, wo, cout
+    p.KH, p.KW, p.stride, p.pad_h, p.pad_w = kh, kw, stride, pad[0], pad[1]
+    p.out_scale = 1.0
+    return p
+
+
+def conv2d_wgrad(xs: Sequence[Tensor], g: Tensor, cout: int, kh: int, kw: int, stride: int, pad) -> Tensor:
+    """packed dW [cout][kh*kw*cin] from inputs `xs` and output gradient g (B,Ho,Wo,>=cout, ld % 4 == 0)."""
+    b, h, w, _ = xs[0].shape
+    _, ho, wo, _ = g.shape
+    cin = sum(x.shape[3] for x in xs)
+    dw = torch.zeros((cout, kh * kw * cin), dtype=torch.float32, device=g.device)
+    p = _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo)
+    p.y, p.y_ld = g.data_ptr(), _ld(g)
+    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(dw), 0, _stream())
+    return dw
+
+
+def unpack_conv_wgrad(packed: Tensor, cout, cin, kh, kw, cin_pad, cout_offset) -> Tensor:
+    dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=packed.device)
+    _hip.call("ff_unpack_conv_wgrad", _p(packed), cout, cin, kh, kw, cin_pad, cout_offset, _p(dw), _stream())
+    return dw
+
+
+def pack_conv_weight_dgrad(w_oihw: Tensor, dst: Tensor, cout_pad: int, cout_offset: int):
+    co, ci, kh, kw = w_oihw.shape
+    assert dst.is_contiguous() and dst.shape == (ci, kh * kw * cout_pad)
+    _hip.call("ff_pack_conv_weight_dgrad", _p(w_oihw.contiguous()), co, ci, kh, kw, _p(dst), cout_pad, cout_offset, _stream())
+
+
+def act_bwd(dy: Tensor, y: Optional[Tensor], act: int, scale: float, c: int) -> Tensor:
+    """g = dy*act'(y)*scale over the first c channels, zero-padded to a multiple of 4."""
+    b, h, w, _ = dy.shape
+    cpad = (c + 3) // 4 * 4
+    g = empty_nhwc(b, h, w, cpad, dy)
+    _hip.call("ff_act_bwd", _p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(g), cpad, b * h * w, c, cpad,
+              act, scale, _stream())
+    return g
+
+
+def dilate2(g: Tensor, hd: int, wd: int) -> Tensor:
+    b, ho, wo, c = g.shape
+    out = empty_nhwc(b, hd, wd, c, g)
+    _hip.call("ff_dilate2", _p(g), _ld(g), _p(out), b, ho, wo, hd, wd, c, _stream())
+    return out
+
+
+def channel_sum(g: Tensor, c: int) -> Tensor:
+    """sum over pixels of the first c channels (bias gradient); fp64 accumulation in ff_norm_stats."""
+    b, h, w, cp = g.shape
+    outs = []
+    for lo in range(0, c, 256):          # ff_norm_stats handles <= 256 channels per call
+        hi = min(cp, lo + 256)
+        st = norm_stats(g[..., lo:hi], per_sample=False)
+        outs.append(st[0, :, 0])
+    return torch.cat(outs)[:c].float()
+
+
+def norm_bwd(x, dy, y, fstats, per_sample, fixed_stats, eps, gamma, beta, relu, want_dres):
+    b, h, w, c = x.shape
+    bstats = torch.zeros((b if per_sample else 1, c, 2), dtype=torch.float64, device=x.device)
+    dx = empty_nhwc(b, h, w, c, x)
+    dres = empty_nhwc(b, h, w, c, x) if want_dres else None
+    _hip.call("ff_norm_bwd", _p(x), _ld(x), _p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(fstats),
+              _p(bstats), int(per_sample), int(fixed_stats), eps, _p(gamma), _p(beta), int(relu), _p(dx), c,
+              _p(dres), c if want_dres else 0, b, h * w, c, _stream())
+    return dx, dres, bstats
+
+
+def corr_lookup_bwd(dlevels: List[Tensor], coords: Tensor, dout: Tensor):
+    b, h, w, _ = coords.shape
+    arr = (C.c_void_p * 4)(*[lv.data_ptr() for lv in dlevels])
+    h0, w0 = dlevels[0].shape[-2:]
+    _hip.call("ff_corr_lookup_bwd", arr, _p(coords), _p(dout), _ld(dout), b * h * w, h0, w0, _stream())
+
+
+def corr_pyramid_bwd(dlevels: List[Tensor]):
+    n, h0, w0 = dlevels[0].shape
+    _hip.call("ff_corr_pyramid_bwd", _p(dlevels[0]), _p(dlevels[1]), _p(dlevels[2]), _p(dlevels[3]), n, h0, w0, _stream())
+
+
+def grouped_1x1(x: Tensor, wt: Tensor, out_scale: float) -> Tensor:
+    """y[g] = x[g] (M x K) @ wt[g]^T (N x K)^T * out_scale, all contiguous (G, M, K), (G, N, K)."""
+    g, m, k = x.shape
+    n = wt.shape[1]
+    y = torch.empty((g, m, n), dtype=torch.float32, device=x.device)
+    p = FFConvParams()
+    p.x[0], p.x_ld[0], p.x_c[0], p.x_gstride[0] = x.data_ptr(), k, k, m * k
+    p.groups, p.B, p.H, p.W = g, 1, 1, m
+    p.w, p.w_gstride = wt.data_ptr(), n * k
+    p.out_scale = out_scale
+    p.y, p.y_ld, p.y_gstride = y.data_ptr(), n, m * n
+    p.Ho, p.Wo, p.Cout = 1, m, n
+    p.KH = p.KW = p.stride = 1
+    _require_gpu(x)
+    _hip.call("ff_conv2d_fwd", C.byref(p), _stream())
+    return y
+
+
+def corr_volume_bwd(dvol: Tensor, f1: Tensor, f2: Tensor):
+    """BmmBackward of corr.py:58: df1 = dvol @ f2 / sqrt(C), df2 = dvol^T @ f1 / sqrt(C)."""
+    b, h, w, c = f1.shape
+    q = h * w
+    s = 1.0 / math.sqrt(c)
+    dvol = dvol.contiguous().view(b, q, q)
+    f2t = torch.zeros((b, c, q), dtype=torch.float32, device=f1.device)       # [c][j] = f2[j][c]
+    for i in range(b):
+        _hip.call("ff_pack_conv_weight_dgrad", _p(f2[i]), q, c, 1, 1, _p(f2t[i]), q, 0, _stream())
+    df1 = grouped_1x1(dvol, f2t, s).view(b, h, w, c)
+    df2 = torch.zeros((b, q, c), dtype=torch.float32, device=f1.device)
+    p = FFConvParams()
+    p.x[0], p.x_ld[0], p.x_c[0], p.x_gstride[0] = f1.data_ptr(), c, c, q * c
+    p.groups, p.B, p.H, p.W = b, 1, 1, q
+    p.Ho, p.Wo, p.Cout = 1, q, q
+    p.KH = p.KW = p.stride = 1
+    p.out_scale = s
+    p.y, p.y_ld, p.y_gstride = dvol.data_ptr(), q, q * q
+    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(df2), q * c, _stream())
+    return df1, df2.view(b, h, w, c)
+
+
+def gru_rh_bwd(drh, r, h):
+    b, hh, ww, c = h.shape
+    dr, dh = empty_nhwc(b, hh, ww, c, h), empty_nhwc(b, hh, ww, c, h)
+    _hip.call("ff_gru_rh_bwd", _p(drh), _ld(drh), _p(r), _ld(r), _p(h), _ld(h), _p(dr), c, _p(dh), c, b * hh * ww, c, _stream())
+    return dr, dh
+
+
+def gru_blend_bwd(dhn, z, q, h):
+    b, hh, ww, c = h.shape
+    dz, dq, dh = (empty_nhwc(b, hh, ww, c, h) for _ in range(3))
+    _hip.call("ff_gru_blend_bwd", _p(dhn), _ld(dhn), _p(z), _ld(z), _p(q), _ld(q), _p(h), _ld(h), _p(dz), c, _p(dq), c,
+              _p(dh), c, b * hh * ww, c, _stream())
+    return dz, dq, dh
+
+
+def upsample_flow_bwd(dout: Tensor, flow: Tensor, mask: Tensor):
+    b, h, w, _ = flow.shape
+    dflow = torch.zeros((b, h, w, 2), dtype=torch.float32, device=flow.device)
+    dmask = empty_nhwc(b, h, w, 576, flow)
+    _hip.call("ff_upsample_flow_bwd", _p(dout.contiguous()), _p(flow), _ld(flow), _p(mask), _ld(mask), _p(dflow), _p(dmask),
+              b, h, w, _stream())
+    return dflow, dmask

@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import fn, ops
 from .cce import BasicParallelFusionLayer
 from .corr_block import CorrBlock
 from .ops import ACT_RELU, ACT_TANH
@@ -66,22 +66,33 @@ class RAFT(nn.Module):
         self.fmap = fmap1
         corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius)
         cnet = self.cnet(image1, mask1)
-        net = ops.empty_nhwc(b, h8, w8, 128, cnet)
-        inp = ops.empty_nhwc(b, h8, w8, 128, cnet)
-        ops.act_copy(cnet[..., :128], net, ACT_TANH)
-        ops.act_copy(cnet[..., 128:], inp, ACT_RELU)
-        coords1 = ops.coords_init(b, h8, w8, cnet, flow_init)
-        flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
+        taped = fn.recording(cnet)
+        if taped:
+            net = fn.ActFn.apply(cnet[..., :128], ACT_TANH)
+            inp = fn.ActFn.apply(cnet[..., 128:], ACT_RELU)
+        else:
+            net = ops.empty_nhwc(b, h8, w8, 128, cnet)
+            inp = ops.empty_nhwc(b, h8, w8, 128, cnet)
+            ops.act_copy(cnet[..., :128], net, ACT_TANH)
+            ops.act_copy(cnet[..., 128:], inp, ACT_RELU)
+        coords1 = ops.coords_init(b, h8, w8, cnet, flow_init)      # never differentiated (raft.py:216)
         flow_predictions = []
-        delta = None
         flow_up = None
+        flow4 = None
         for _ in range(iters):
-            corr = corr_fn(coords1)
-            motion = ops.empty_nhwc(b, h8, w8, 128, cnet)
-            ops.coords_step(coords1, None, flow4, motion[..., 126:])      # flow = coords1 - coords0
-            net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, motion)
-            ops.coords_step(coords1, delta, flow4, None)                  # coords1 += delta
-            flow_up = ops.upsample_flow(flow4, up_mask)
+            # coords1 is advanced in place by ff_coords_step (raw pointer: autograd cannot see it), so a
+            # recorded lookup keeps its own snapshot for the backward scatter
+            corr = corr_fn(coords1.clone() if taped else coords1)
+            flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
+            ops.coords_step(coords1, None, flow4, None)                   # flow = coords1 - coords0
+            fill = lambda motion, c=coords1: ops.coords_step(c, None, None, motion[..., 126:])  # noqa: E731
+            net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill)
+            flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
+            ops.coords_step(coords1, delta.detach(), flow4, None)         # coords1 += delta
+            if fn.recording(delta, up_mask):
+                flow_up = fn.UpsampleFn.apply(flow4, delta, up_mask)
+            else:
+                flow_up = ops.upsample_flow(flow4, up_mask)
             flow_predictions.append(flow_up)
         if test_mode:
             return ops.nhwc_to_nchw(flow4[..., :2]), flow_up

@@ -10,7 +10,7 @@ launches + 4 gate kernels per iteration:
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import fn, ops
 from .cce import PackedConv
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 
@@ -40,10 +40,11 @@ class SepConvGRU(nn.Module):
         """h: (B,H,W,128); xs: list of NHWC segments forming x.  update.py:45-60."""
         c = self.hidden_dim
         for zr_conv, q_conv in zip(self._zr, self._q):
-            zr = zr_conv([h] + xs, act=ACT_SIGMOID)             # z = zr[..., :c], r = zr[..., c:]
-            rh = ops.gru_rh(zr[..., c:], h)
-            q = q_conv([rh] + xs, act=ACT_TANH)
-            h = ops.gru_blend(zr[..., :c], q, h)
+            zr = fn.conv(zr_conv, [h] + xs, act=ACT_SIGMOID)    # z = zr[..., :c], r = zr[..., c:]
+            taped = fn.recording(zr, h)
+            rh = fn.GruRhFn.apply(zr[..., c:], h) if taped else ops.gru_rh(zr[..., c:], h)
+            q = fn.conv(q_conv, [rh] + xs, act=ACT_TANH)
+            h = fn.GruBlendFn.apply(zr[..., :c], q, h) if taped else ops.gru_blend(zr[..., :c], q, h)
         return h
 
 
@@ -60,13 +61,12 @@ class BasicMotionEncoder(nn.Module):
         self._f1, self._f2 = PackedConv([self.convf1], 4), PackedConv([self.convf2])
         self._cv = PackedConv([self.conv])
 
-    def run(self, flow4, corr, motion):
-        """flow4: (B,H,W,4) zero-padded flow; motion: (B,H,W,128) whose channels
-        126:128 already hold the flow (torch.cat([out, flow]) of update.py:97)."""
-        cor = self._c2(self._c1(corr, act=ACT_RELU), act=ACT_RELU)
-        flo = self._f2(self._f1(flow4, act=ACT_RELU), act=ACT_RELU)
-        self._cv([cor, flo], act=ACT_RELU, out=motion[..., :126])
-        return motion
+    def run(self, flow4, corr, fill_flow):
+        """flow4: (B,H,W,4) zero-padded flow.  Returns motion (B,H,W,128): 126 conv channels, and
+        `fill_flow(motion)` writes the flow into channels 126:128 (torch.cat([out, flow]), update.py:97)."""
+        cor = fn.conv(self._c2, fn.conv(self._c1, corr, act=ACT_RELU), act=ACT_RELU)
+        flo = fn.conv(self._f2, fn.conv(self._f1, flow4, act=ACT_RELU), act=ACT_RELU)
+        return fn.conv(self._cv, [cor, flo], act=ACT_RELU, pad_out=True, fill_tail=fill_flow)
 
 
 class BasicUpdateBlock(nn.Module):
@@ -81,13 +81,13 @@ class BasicUpdateBlock(nn.Module):
         self._flow2 = PackedConv([self.flow_head.conv2])
         self._mask2 = PackedConv([self.mask[2]])
 
-    def run(self, net, inp, corr, flow4, motion):
+    def run(self, net, inp, corr, flow4, fill_flow):
         """-> (net, up_mask, delta_flow), all NHWC.  update.py:126-135."""
-        motion = self.encoder.run(flow4, corr, motion)
+        motion = self.encoder.run(flow4, corr, fill_flow)
         net = self.gru.run(net, [inp, motion])
-        hid = self._heads(net, act=ACT_RELU)                      # [flow-head 256 | mask-head 256]
-        delta = self._flow2(hid[..., :256])
-        up_mask = self._mask2(hid[..., 256:], out_scale=0.25)     # ".25 * self.mask(net)"
+        hid = fn.conv(self._heads, net, act=ACT_RELU)                      # [flow-head 256 | mask-head 256]
+        delta = fn.conv(self._flow2, hid[..., :256])
+        up_mask = fn.conv(self._mask2, hid[..., 256:], out_scale=0.25)     # ".25 * self.mask(net)"
         return net, up_mask, delta
 
     def freeze_self(self, mode):

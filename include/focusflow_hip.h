@@ -158,6 +158,50 @@ int ff_upsample_flow(const float* flow, int flow_ld, const float* mask, int mask
 /* NHWC [npix][ld] (C ch) -> NCHW (B,C,H,W) */
 int ff_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int H, int W, int C, void* stream);
 
+/* ========================================================================
+ * Backward (autograd of raft.py:173-236).
+ * ======================================================================== */
+/* dW[co][kh][kw][ci] (packed layout, fp32 atomics, CALLER ZEROES dw) =
+ *   out_scale * sum_pixels dY[pix][co] * x[pix @ (kh,kw)][ci].
+ * `p` describes the forward conv (x segments, geometry); p->y / p->y_ld carry dY
+ * (channels rounded up to a multiple of 4).  groups = B with a 1x1 kernel gives
+ * d(corr volume)/d(fmap2) (BmmBackward of corr.py:58). */
+int ff_conv2d_wgrad(const FFConvParams* p, float* dw, long long dw_gstride, void* stream);
+/* packed dW rows [cout_offset, cout_offset+Cout) -> OIHW gradient of one nn.Conv2d */
+int ff_unpack_conv_wgrad(const float* packed, int Cout, int Cin, int KH, int KW, int cin_pad,
+                         int cout_offset, float* dw_oihw, void* stream);
+/* input gradient = ff_conv2d_fwd over dY with these weights:
+ * dst[ci][KH-1-kh][KW-1-kw][cout_offset+co] = w[co][ci][kh][kw]  (CALLER ZEROES dst) */
+int ff_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int KH, int KW, float* dst,
+                              int cout_pad, int cout_offset, void* stream);
+/* g = dy * act'(y) * scale (activation derivative from the forward OUTPUT), zero-padded to Cpad */
+int ff_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* g, int g_ld,
+               long long npix, int C, int Cpad, int act, float scale, void* stream);
+/* zero-dilation by 2: dst[b][2y][2x][:] = src[b][y][x][:] (input gradient of stride-2 convs) */
+int ff_dilate2(const float* src, int src_ld, float* dst, int B, int Ho, int Wo, int Hd, int Wd, int C,
+               void* stream);
+/* Instance/BatchNorm backward for y = relu?(norm(x)) [; y = relu(y + res)].
+ * bstats (fp64 [S][C][2], CALLER ZEROES) returns {sum g, sum g*xhat} = {dbeta, dgamma}. */
+int ff_norm_bwd(const float* x, int x_ld, const float* dy, int dy_ld, const float* y, int y_ld,
+                const double* fstats, double* bstats, int per_sample, int fixed_stats, float eps,
+                const float* gamma, const float* beta, int relu, float* dx, int dx_ld,
+                float* dres, int dres_ld, int B, int HW, int C, void* stream);
+/* GridSampler2DBackward (w.r.t. the pyramid only: coords are detached, raft.py:216):
+ * dlevels[l] += scatter(dout); 4 levels, radius 4. */
+int ff_corr_lookup_bwd(float* const* dlevels /* HOST array of 4 device ptrs */, const float* coords,
+                       const float* dout, int dout_ld, long long queries, int h0, int w0, void* stream);
+/* AvgPool2DBackward chain, in place: d2 += up(d3)/4 ; d1 += up(d2)/4 ; d0 += up(d1)/4 */
+int ff_corr_pyramid_bwd(float* d0, float* d1, float* d2, const float* d3, long long planes,
+                        int h0, int w0, void* stream);
+int ff_gru_rh_bwd(const float* drh, int drh_ld, const float* r, int r_ld, const float* h, int h_ld,
+                  float* dr, int dr_ld, float* dh, int dh_ld, long long npix, int C, void* stream);
+int ff_gru_blend_bwd(const float* dhn, int dhn_ld, const float* z, int z_ld, const float* q, int q_ld,
+                     const float* h, int h_ld, float* dz, int dz_ld, float* dq, int dq_ld,
+                     float* dh, int dh_ld, long long npix, int C, void* stream);
+/* convex upsampling backward: dflow NHWC [B*H*W][2] (CALLER ZEROES), dmask NHWC [B*H*W][576] */
+int ff_upsample_flow_bwd(const float* dout_nchw, const float* flow, int flow_ld, const float* mask,
+                         int mask_ld, float* dflow, float* dmask, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
