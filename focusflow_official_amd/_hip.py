@@ -11,6 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libfocusflow_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+W_F32, W_F16X3, W_F16 = 0, 1, 2
 MAX_SEG = 3
 _fp = C.c_void_p
 _ll = C.c_longlong
@@ -24,7 +25,7 @@ class FFConvParams(C.Structure):
         ("out_scale", C.c_float), ("res", _fp), ("res_ld", C.c_int), ("y", _fp), ("y_ld", C.c_int),
         ("y_gstride", _ll), ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
         ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
-        ("act", C.c_int), ("act_res", C.c_int),
+        ("act", C.c_int), ("act_res", C.c_int), ("w_format", C.c_int),
     ]
 
 
@@ -32,6 +33,7 @@ class FFConvParams(C.Structure):
 _SIGS = {
     "ff_conv2d_fwd": [C.POINTER(FFConvParams), _fp],
     "ff_pack_conv_weight": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp],
+    "ff_pack_split_f16": [_fp, _fp, _ll, C.c_int, _fp],
     "ff_norm_stats": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "ff_norm_apply": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_float,
                       _fp, _fp, C.c_int, _fp, C.c_int, _fp],

@@ -42,7 +42,8 @@ class PackedConv:
         self.wd = None
 
     def get(self):
-        key = tuple((c.weight._version, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()) for c in self.convs)
+        key = (ops.conv_precision(),) + tuple(
+            (c.weight._version, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()) for c in self.convs)
         if key != self._key:
             dev = self.convs[0].weight.device
             self.w = torch.empty((self.cout, self.kh * self.kw * self.cin_pad), dtype=torch.float32, device=dev)
@@ -52,6 +53,9 @@ class PackedConv:
                 ops.pack_conv_weight(c.weight.detach(), self.w, self.cin_pad, off)
                 self.b[off:off + c.out_channels].copy_(c.bias.detach())  # device memcpy
                 off += c.out_channels
+            self.fmt = ops.w_format()
+            if self.fmt != 0:
+                self.w = ops.pack_split(self.w)
             self._key = key
         return self.w, self.b
 
@@ -73,7 +77,7 @@ class PackedConv:
         w, b = self.get()
         if not isinstance(xs, (list, tuple)):
             xs = [xs]
-        return ops.conv2d(xs, w, b, self.cout, self.kh, self.kw, self.stride, self.pad, act=act, **kw)
+        return ops.conv2d(xs, w, b, self.cout, self.kh, self.kw, self.stride, self.pad, act=act, w_fmt=self.fmt, **kw)
 
 
 def _make_norm(kind: str, c: int):

@@ -275,13 +275,15 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     const long long M = (long long)p.B * Ho * Wo;
     FF_REQUIRE(M < (1ll << 30) && (long long)p.B * p.H * p.W < (1ll << 30), "ff_conv2d_fwd: too many pixels");
 
+    FF_REQUIRE(p.w_format >= FF_W_F32 && p.w_format <= FF_W_F16, "ff_conv2d_fwd: bad w_format %d", p.w_format);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p.w_format != FF_W_F32) return ff::conv2d_fwd_split(p, (int)M, cin, s);
     KernArgs a;
     a.p = p;
     a.M = (int)M;
     a.Cin = cin;
     a.K = p.KH * p.KW * cin;
     a.m_tiles = a.n_tiles = 0;
-    hipStream_t s = static_cast<hipStream_t>(stream);
 
     // Tile choice: widest N tile that Cout fills, then shrink M while the grid
     // would leave most of the 256 CUs idle.

@@ -1,0 +1,289 @@
+// fp32-accurate convolution on the HALF-PRECISION matrix pipe (v_mfma_f32_32x32x16_f16).
+//
+// CDNA4 has no TF32/xf32 and its fp32 MFMA runs at 1/16 of the f16 rate.  Every fp32
+// operand is therefore split into two fp16 numbers,
+//        x = x0 + 2^-11 * x1 ,   x0 = fp16(x),  x1 = fp16((x - x0) * 2^11)
+// (11+11 = 22 significand bits; the 2^11 pre-scale keeps x1 out of the fp16 subnormals), and
+//        x*w = x0*w0 + 2^-11 * (x0*w1 + x1*w0) + O(2^-22)
+// costs three f16 MFMAs (fp32 accumulate, products exact) instead of eight fp32 MFMAs of
+// twice the latency: 5.3x the matrix throughput at a relative error of ~2^-22 per product —
+// measured end to end it is as close to an fp64 evaluation as the fp32 reference itself.
+// TERMS = 1 keeps only x0*w0 (plain fp16 operands: a reduced-precision throughput mode).
+//
+// Same implicit-GEMM skeleton as conv_mfma.hip (tiles, XOR-swizzled 128-byte LDS rows, one
+// barrier per 32-k chunk).  A 128-byte LDS row now holds [x0: 32 fp16 | x1: 32 fp16] for the
+// chunk, so one ds_read_b128 is exactly one MFMA operand (8 consecutive k).  Weights arrive
+// pre-split in that row format (ff_pack_split_f16); activations stay fp32 in HBM and are split
+// in registers on their way to LDS.  Operands must satisfy |x| < 65504.
+#include "ff_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int ROWB = 128;   // bytes per LDS row = per 32-k chunk of one packed weight row
+
+struct KernArgs {
+    FFConvParams p;
+    int M, K, Cin;
+    int m_tiles, n_tiles;
+    long long w_row_bytes;   // packed split weights: bytes per output channel
+};
+
+__device__ __forceinline__ int swz(int row, int piece) { return piece ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 a = (_Float16)v[j];
+        h0[j] = a;
+        h1[j] = (_Float16)((v[j] - (float)a) * 2048.f);
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int TERMS>
+__global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int LA = BM / 32, LB = BN / 32;
+    static_assert(WM * WN == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                        // [2][BM][128 B]
+    char* sB = smem + 2 * BM * ROWB;        // [2][BN][128 B]
+
+    const FFConvParams& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int grp = blockIdx.y;
+    const int mt = bid / a.n_tiles, nt = bid - mt * a.n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int H = p.H, W = p.W, Wo = p.Wo, HoWo = p.Ho * p.Wo;
+    const int kq = tid & 7, rbase = tid >> 3;
+
+    int hi0[LA], wi0[LA], img[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int m = m0 + rbase + 32 * i;
+        if (m < a.M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            hi0[i] = ho * p.stride - p.pad_h;
+            wi0[i] = wo * p.stride - p.pad_w;
+            img[i] = b * H * W;
+        } else {
+            hi0[i] = -(1 << 28);
+            wi0[i] = 0;
+            img[i] = 0;
+        }
+    }
+    const char* wbase = reinterpret_cast<const char*>(p.w) + (long long)grp * p.w_gstride * 4;
+    const float* xs0 = p.x[0] + (long long)grp * p.x_gstride[0];
+    const float* xs1 = p.x[1] ? p.x[1] + (long long)grp * p.x_gstride[1] : nullptr;
+    const float* xs2 = p.x[2] ? p.x[2] + (long long)grp * p.x_gstride[2] : nullptr;
+    const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
+
+    f32x4 ra[LA], rb[LB];
+    auto stage_load = [&](int kc) {
+        const int k = kc * BK + kq * 4;
+        const bool kok = k < a.K;
+        const int tap = kok ? k / a.Cin : 0;
+        int ci = k - tap * a.Cin;
+        const int dy = tap / p.KW, dx = tap - dy * p.KW;
+        const float* xp;
+        int ld;
+        if (ci < c0) { xp = xs0; ld = p.x_ld[0]; }
+        else if (ci < c01) { xp = xs1; ld = p.x_ld[1]; ci -= c0; }
+        else { xp = xs2; ld = p.x_ld[2]; ci -= c01; }
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int hi = hi0[i] + dy, wi = wi0[i] + dx;
+            const bool ok = kok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(xp + (long long)(img[i] + hi * W + wi) * ld + ci);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {   // weights: 16-byte piece kq of this chunk's 128-byte row, already split
+            const int n = n0 + rbase + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(wbase + (long long)n * a.w_row_bytes + (long long)kc * ROWB + kq * 16);
+            rb[i] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char* dA = sA + buf * BM * ROWB;
+        char* dB = sB + buf * BN * ROWB;
+        const int pc = kq >> 1, half = (kq & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int row = rbase + 32 * i;
+            f16x4 h0, h1;
+            split4(ra[i], h0, h1);
+            *reinterpret_cast<f16x4*>(dA + row * ROWB + swz(row, pc) * 16 + half) = h0;
+            if (TERMS == 3) *reinterpret_cast<f16x4*>(dA + row * ROWB + swz(row, 4 + pc) * 16 + half) = h1;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int row = rbase + 32 * i;
+            *reinterpret_cast<f32x4*>(dB + row * ROWB + swz(row, kq) * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN], accx[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    const int nk = (a.K + BK - 1) / BK;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    const int li = lane & 31, lh = lane >> 5;
+    int cur = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 1 < nk) stage_load(kc + 1);
+        const char* cA = sA + cur * BM * ROWB;
+        const char* cB = sB + cur * BN * ROWB;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {    // two k16 steps per chunk: piece 2s+lh holds k = 16s + 8lh .. +7
+            f16x8 a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 32 + li;
+                a0[i] = *reinterpret_cast<const f16x8*>(cA + row * ROWB + swz(row, 2 * s + lh) * 16);
+                if (TERMS == 3) a1[i] = *reinterpret_cast<const f16x8*>(cA + row * ROWB + swz(row, 4 + 2 * s + lh) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 32 + li;
+                b0[j] = *reinterpret_cast<const f16x8*>(cB + row * ROWB + swz(row, 2 * s + lh) * 16);
+                if (TERMS == 3) b1[j] = *reinterpret_cast<const f16x8*>(cB + row * ROWB + swz(row, 4 + 2 * s + lh) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                    if (TERMS == 3) {
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[i], b1[j], accx[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b0[j], accx[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        if (kc + 1 < nk) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* yb = p.y + (long long)grp * p.y_gstride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + li;
+        if (n >= p.Cout) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float cs = p.ch_scale ? p.ch_scale[n] : 1.f;
+        const float ct = p.ch_scale ? p.ch_shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + (wm * TM + i) * 32 + row;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r];
+                if (TERMS == 3) v += accx[i][j][r] * (1.f / 2048.f);
+                v += bias;
+                v *= p.out_scale;
+                if (p.ch_scale) v = v * cs + ct;
+                v = ff::apply_act(v, p.act);
+                if (p.res) v = ff::apply_act(v + p.res[(long long)m * p.res_ld + n], p.act_res);
+                yb[(long long)m * p.y_ld + n] = v;
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int TERMS>
+int launch(const KernArgs& a, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr size_t lds = 2 * (BM + BN) * ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<WM, WN, TM, TN, TERMS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    KernArgs k = a;
+    k.m_tiles = (a.M + BM - 1) / BM;
+    k.n_tiles = (a.p.Cout + BN - 1) / BN;
+    dim3 grid(k.m_tiles * k.n_tiles, a.p.groups);
+    conv_split_kernel<WM, WN, TM, TN, TERMS><<<grid, 256, lds, s>>>(k);
+    return ff::check_launch("ff_conv2d_fwd(split)");
+}
+
+template <int TERMS>
+int dispatch(const KernArgs& a, hipStream_t s) {
+    const FFConvParams& p = a.p;
+    const long long M = a.M, g = p.groups;
+    auto blocks = [&](int bm, int bn) { return g * ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
+    if (p.Cout > 96 && (p.Cout % 128 == 0 || p.Cout > 192) && blocks(128, 128) >= 200) return launch<2, 2, 2, 2, TERMS>(a, s);
+    if (p.Cout > 64 && p.Cout <= 96 && blocks(128, 96) >= 200) return launch<4, 1, 1, 3, TERMS>(a, s);
+    if (blocks(128, 64) >= 400) return launch<2, 2, 2, 1, TERMS>(a, s);
+    return launch<2, 2, 1, 1, TERMS>(a, s);
+}
+
+// fp32 rows [rows][K] -> split rows [rows][ceil(K/32)][x0: 32 fp16 | x1: 32 fp16], zero padded
+__global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long rows, int K,
+                                  int nchunks) {
+    const long long total = rows * nchunks * 32;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int kk = (int)(i % 32);
+        const long long rc = i / 32;
+        const int c = (int)(rc % nchunks);
+        const long long r = rc / nchunks;
+        const int k = c * 32 + kk;
+        const float v = k < K ? src[r * K + k] : 0.f;
+        const _Float16 h0 = (_Float16)v;
+        dst[rc * 64 + kk] = h0;
+        dst[rc * 64 + 32 + kk] = (_Float16)((v - (float)h0) * 2048.f);
+    }
+}
+
+}  // namespace
+
+namespace ff {
+// called from ff_conv2d_fwd after argument validation
+int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s) {
+    KernArgs a;
+    a.p = p;
+    a.M = M;
+    a.Cin = cin;
+    a.K = p.KH * p.KW * cin;
+    a.m_tiles = a.n_tiles = 0;
+    a.w_row_bytes = (long long)((a.K + BK - 1) / BK) * ROWB;
+    return p.w_format == FF_W_F16 ? dispatch<1>(a, s) : dispatch<3>(a, s);
+}
+}  // namespace ff
+
+extern "C" int ff_pack_split_f16(const float* src, void* dst, long long rows, int K, void* stream) {
+    FF_REQUIRE(src && dst && rows > 0 && K > 0, "ff_pack_split_f16: bad argument");
+    FF_REQUIRE(ff::aligned16(dst), "ff_pack_split_f16: dst not 16-byte aligned");
+    const int nchunks = (K + 31) / 32;
+    const long long total = rows * nchunks * 32;
+    long long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    pack_split_kernel<<<(unsigned)g, 256, 0, static_cast<hipStream_t>(stream)>>>(src, static_cast<_Float16*>(dst), rows, K, nchunks);
+    return ff::check_launch("ff_pack_split_f16");
+}

@@ -28,6 +28,8 @@ inline int check_launch(const char* what) {
     return FF_OK;
 }
 
+int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s);  // conv_split.hip
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -40,7 +40,7 @@ class ConvFn(torch.autograd.Function):
             full = ops.empty_nhwc(bsz, ho, wo, (pc.cout + 3) // 4 * 4, xs[0])
             out = full[..., :pc.cout]
         y = ops.conv2d(xs, w, b, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, act=act, out=out, res=res,
-                       out_scale=out_scale)
+                       out_scale=out_scale, w_fmt=pc.fmt)
         if pad_out:
             if fill_tail is not None:
                 fill_tail(full)

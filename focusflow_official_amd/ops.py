@@ -7,6 +7,7 @@ in libfocusflow_hip.so.
 """
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -19,6 +20,38 @@ Tensor = torch.Tensor
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Arithmetic of the forward convolutions / correlation volume:
+#   "f16x3" (default) fp16-split operands, 3 f16 MFMAs: fp32-level accuracy (see csrc/conv_split.hip)
+#   "fp32"  exact fp32 MFMA            "f16"  plain fp16 operands (reduced precision, throughput mode)
+_PRECISIONS = {"fp32": _hip.W_F32, "f16x3": _hip.W_F16X3, "f16": _hip.W_F16}
+_conv_precision = os.environ.get("FF_CONV_PRECISION", "f16x3")
+
+
+def set_conv_precision(name: str):
+    global _conv_precision
+    if name not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+    _conv_precision = name
+
+
+def conv_precision() -> str:
+    return _conv_precision
+
+
+def w_format() -> int:
+    return _PRECISIONS[_conv_precision]
+
+
+def pack_split(rows_f32: Tensor) -> Tensor:
+    """fp32 [rows][K] -> split fp16 rows (uint8 view [rows][ceil(K/32)*128])."""
+    _require_gpu(rows_f32)
+    rows, k = rows_f32.shape
+    assert rows_f32.is_contiguous()
+    dst = torch.empty((rows, (k + 31) // 32 * 128), dtype=torch.uint8, device=rows_f32.device)
+    _hip.call("ff_pack_split_f16", _p(rows_f32), _p(dst), rows, k, _stream())
+    return dst
 
 
 # Optional per-launch timing of ONE entry point with HIP events recorded on the
@@ -92,8 +125,9 @@ def pack_conv_weight(w_oihw: Tensor, dst: Tensor, cin_pad: int, cout_offset: int
 def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: int, kh: int, kw: int,
            stride: int = 1, pad=(0, 0), act: int = ACT_NONE, out: Optional[Tensor] = None,
            res: Optional[Tensor] = None, act_res: int = ACT_NONE, ch_scale: Optional[Tensor] = None,
-           ch_shift: Optional[Tensor] = None, out_scale: float = 1.0) -> Tensor:
-    """Convolution over the channel-concatenation of `xs` (see FFConvParams)."""
+           ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0) -> Tensor:
+    """Convolution over the channel-concatenation of `xs` (see FFConvParams).  `wpack` is fp32
+    [Cout][K] (w_fmt 0) or the split rows of pack_split (w_fmt 1/2)."""
     if isinstance(pad, int):
         pad = (pad, pad)
     x0 = xs[0]
@@ -111,8 +145,9 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
         p.x_c[i] = x.shape[3]
         p.x_gstride[i] = 0
         cin += x.shape[3]
-    assert wpack.is_contiguous() and wpack.shape[-1] == kh * kw * cin and wpack.shape[0] >= cout, \
-        f"packed weight {tuple(wpack.shape)} vs Cout {cout}, K {kh * kw * cin}"
+    kdim = kh * kw * cin if w_fmt == 0 else (kh * kw * cin + 31) // 32 * 128
+    assert wpack.is_contiguous() and wpack.shape[-1] == kdim and wpack.shape[0] >= cout, \
+        f"packed weight {tuple(wpack.shape)} vs Cout {cout}, K {kh * kw * cin} (format {w_fmt})"
     p.groups, p.B, p.H, p.W = 1, b, h, w
     p.w, p.w_gstride = wpack.data_ptr(), 0
     p.bias = bias.data_ptr() if bias is not None else None
@@ -124,7 +159,7 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     p.y, p.y_ld, p.y_gstride = out.data_ptr(), _ld(out), 0
     p.Ho, p.Wo, p.Cout = ho, wo, cout
     p.KH, p.KW, p.stride, p.pad_h, p.pad_w = kh, kw, stride, pad[0], pad[1]
-    p.act, p.act_res = act, act_res
+    p.act, p.act_res, p.w_format = act, act_res, w_fmt
     assert out.shape[:3] == (b, ho, wo) and out.shape[3] >= cout
     _hip.call("ff_conv2d_fwd", C.byref(p), _stream())
     return out
@@ -140,7 +175,12 @@ def corr_volume(fmap1: Tensor, fmap2: Tensor) -> Tensor:
     p = FFConvParams()
     p.x[0], p.x_ld[0], p.x_c[0], p.x_gstride[0] = fmap1.data_ptr(), c, c, q * c
     p.groups, p.B, p.H, p.W = b, 1, h, w
-    p.w, p.w_gstride = fmap2.data_ptr(), q * c
+    p.w_format = w_format()
+    if p.w_format == 0:
+        p.w, p.w_gstride = fmap2.data_ptr(), q * c
+    else:  # fmap2 plays the weights: split it once per pair
+        f2s = pack_split(fmap2.view(b * q, c))
+        p.w, p.w_gstride = f2s.data_ptr(), q * f2s.shape[1] // 4
     p.out_scale = 1.0 / math.sqrt(c)
     p.y, p.y_ld, p.y_gstride = vol.data_ptr(), q, q * q
     p.Ho, p.Wo, p.Cout = h, w, q

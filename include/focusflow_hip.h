@@ -37,6 +37,12 @@ extern "C" {
 
 #define FF_MAX_SEG 3
 
+/* weight formats of FFConvParams.w */
+#define FF_W_F32 0     /* fp32 rows [Cout][K]: exact fp32 MFMA (v_mfma_f32_32x32x2_f32)            */
+#define FF_W_F16X3 1   /* rows from ff_pack_split_f16: x = x0 + 2^-11*x1 in fp16, 3 f16 MFMAs per  */
+                       /* product term set — fp32-level accuracy at 5.3x the matrix rate           */
+#define FF_W_F16 2     /* same rows, only the x0*w0 term: plain fp16 operands (reduced precision)  */
+
 const char* ff_last_error(void);
 int ff_abi_version(void);
 
@@ -74,6 +80,7 @@ typedef struct FFConvParams {
     int KH, KW, stride, pad_h, pad_w;
     int act;                           /* FF_ACT_*, before the residual add             */
     int act_res;                       /* FF_ACT_*, after the residual add              */
+    int w_format;                      /* FF_W_*; for the split formats w_gstride counts 4-byte words */
 } FFConvParams;
 
 int ff_conv2d_fwd(const FFConvParams* p, void* stream);
@@ -83,6 +90,9 @@ int ff_conv2d_fwd(const FFConvParams* p, void* stream);
  * holding `dst_rows` rows (lets convz|convr share one packed matrix). */
 int ff_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW,
                         float* dst, int cin_pad, int cout_offset, void* stream);
+/* fp32 rows [rows][K] -> split rows [rows][ceil(K/32)]{x0: 32 fp16, x1: 32 fp16} (128 B per
+ * 32-k chunk, zero padded) for FF_W_F16X3 / FF_W_F16.  Values must satisfy |x| < 65504. */
+int ff_pack_split_f16(const float* src_rows, void* dst, long long rows, int K, void* stream);
 
 /* ------------------------------------------------------------------------
  * Normalisation: nn.InstanceNorm2d (extractor.py:28-32, per-sample statistics,

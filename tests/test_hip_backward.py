@@ -267,4 +267,4 @@ def test_frozen_bn_training_step_gives_gradients(det_sd):
     for name in ["flow_net.cnet.norm1.weight", "flow_net.cnet.layer2.0.downsample.1.bias", "flow_net.cnet.conv1.weight",
                  "flow_net.update_block.gru.convq1.weight", "flow_net.fnet.fusion3.img2mask.conv.weight"]:
         ref_g = sd[name].grad
-        close(params[name].grad.cpu(), ref_g, rtol=2e-3, atol_rel=2e-3, what=name)
+        close(params[name].grad.cpu(), ref_g, rtol=3e-3, atol_rel=3e-3, what=name)

@@ -79,8 +79,9 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("fmt", ["fp32", "f16x3", "f16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"c{'+'.join(map(str, c[0]))}-o{c[1]}-k{c[2]}x{c[3]}-s{c[4]}")
-def test_conv2d(ops, case):
+def test_conv2d(ops, case, fmt):
     segs, cout, kh, kw, stride, pad, b, h, w, act, use_res = case
     g = torch.Generator().manual_seed(hash(str(case)) & 0xFFFF)
     cin = sum(segs)
@@ -102,10 +103,14 @@ def test_conv2d(ops, case):
         buf = torch.zeros(b, h, w, cp + 8, device=DEV)
         buf[..., 4:4 + x.shape[1]] = nhwc(x)
         xd.append(buf[..., 4:4 + cp])
+    w_fmt = {"fp32": 0, "f16x3": 1, "f16": 2}[fmt]
+    if w_fmt:
+        wp = ops.pack_split(wp)     # fp16-split rows for the half-precision matrix pipe
     out = ops.conv2d(xd, wp, bias.to(DEV), cout, kh, kw, stride, pad, act=act,
-                     res=nhwc(res) if use_res else None, act_res=1 if use_res else 0)
+                     res=nhwc(res) if use_res else None, act_res=1 if use_res else 0, w_fmt=w_fmt)
     torch.cuda.synchronize()
-    close(nchw(out), ref, what="conv2d")
+    # f16x3 must hold the fp32 tolerance; plain fp16 operands are the reduced-precision mode
+    close(nchw(out), ref, rtol=2e-5 if fmt != "f16" else 4e-3, what=f"conv2d[{fmt}]")
 
 
 def test_conv_epilogue_scale_shift_and_outscale(ops):
