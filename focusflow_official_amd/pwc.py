@@ -1,0 +1,58 @@
+"""FF-PWC's native component on the HIP path: `FunctionCorrelation` (the reference's
+`_FunctionCorrelation` autograd Function, correlation.py:276-381) and `backwarp`
+(ff_pwcnet.py:27-47), NHWC fp32.  The full FF_PWCNET module is a later row."""
+import torch
+
+from . import _hip, ops
+from .ops import _ld, _p, _stream, empty_nhwc
+
+
+def _cv_fwd(one, two):
+    b, h, w, c = one.shape
+    out = empty_nhwc(b, h, w, 81, one)
+    _hip.call("ff_pwc_costvolume_fwd", _p(one), _ld(one), _p(two), _ld(two), _p(out), 81, b, h, w, c, _stream())
+    return out
+
+
+def _cv_bwd(g, other):
+    b, h, w, c = other.shape
+    grad = empty_nhwc(b, h, w, c, other)
+    _hip.call("ff_pwc_costvolume_bwd", _p(g), _ld(g), _p(other), _ld(other), _p(grad), c, b, h, w, c, _stream())
+    return grad
+
+
+class _FunctionCorrelation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, one, two):
+        one, two = one.contiguous(), two.contiguous()
+        ctx.save_for_backward(one, two)
+        return _cv_fwd(one, two)
+
+    @staticmethod
+    def backward(ctx, gout):
+        one, two = ctx.saved_tensors
+        gout = gout.contiguous()
+        b, h, w, _ = gout.shape
+        g_one = _cv_bwd(gout, two) if ctx.needs_input_grad[0] else None
+        g_two = None
+        if ctx.needs_input_grad[1]:
+            gt = empty_nhwc(b, h, w, 81, gout)
+            _hip.call("ff_pwc_gout_transpose", _p(gout), 81, _p(gt), 81, b, h, w, _stream())
+            g_two = _cv_bwd(gt, one)
+        return g_one, g_two
+
+
+def FunctionCorrelation(tenOne: torch.Tensor, tenTwo: torch.Tensor) -> torch.Tensor:
+    """NHWC (B,H,W,C) x2 -> (B,H,W,81); channel (p+4)*9+(o+4), p = y-, o = x-displacement."""
+    assert tenOne.shape == tenTwo.shape and tenOne.shape[3] % 4 == 0
+    if not tenOne.is_cuda:  # the reference raises NotImplementedError on CPU as well (correlation.py:320-321)
+        raise _hip.FocusFlowHipError("FunctionCorrelation runs on a HIP device only")
+    return _FunctionCorrelation.apply(tenOne, tenTwo)
+
+
+def backwarp(tenInput: torch.Tensor, tenFlow: torch.Tensor) -> torch.Tensor:
+    """NHWC input (B,H,W,C), flow (B,H,W,2) [x,y] in pixels -> warped (B,H,W,C) with validity mask applied."""
+    b, h, w, c = tenInput.shape
+    out = empty_nhwc(b, h, w, c, tenInput)
+    _hip.call("ff_pwc_backwarp", _p(tenInput), _ld(tenInput), _p(tenFlow), _ld(tenFlow), _p(out), c, b, h, w, c, _stream())
+    return out

@@ -212,6 +212,23 @@ int ff_gru_blend_bwd(const float* dhn, int dhn_ld, const float* z, int z_ld, con
 int ff_upsample_flow_bwd(const float* dout_nchw, const float* flow, int flow_ld, const float* mask,
                          int mask_ld, float* dflow, float* dmask, int B, int H, int W, void* stream);
 
+/* ========================================================================
+ * FF-PWC native component (core/models/ff-pwcnet/PWCNet_Core/): the 81-channel cost volume
+ * of correlation.py:7-232 (the reference's CuPy CUDA kernels) and backwarp, ff_pwcnet.py:27-47.
+ * NHWC fp32, C a multiple of 4.
+ *   fwd : out[b,y,x,(p+4)*9+(o+4)] = 1/C sum_c one[b,y,x,c] * two[b,y+p,x+o,c], p,o in [-4,4]
+ *   bwd : grad[b,y,x,c] = 1/C sum_{p,o} g[b,y,x,(p,o)] * other[b,y+p,x+o,c]
+ *         gradOne = bwd(gOut, two) ; gradTwo = bwd(ff_pwc_gout_transpose(gOut), one)
+ * ======================================================================== */
+int ff_pwc_costvolume_fwd(const float* one, int one_ld, const float* two, int two_ld, float* out,
+                          int out_ld, int B, int H, int W, int C, void* stream);
+int ff_pwc_costvolume_bwd(const float* g, int g_ld, const float* other, int other_ld, float* grad,
+                          int grad_ld, int B, int H, int W, int C, void* stream);
+int ff_pwc_gout_transpose(const float* g, int g_ld, float* gt, int gt_ld, int B, int H, int W, void* stream);
+/* out = grid_sample(in, grid + flow, bilinear, zeros, align_corners=False) * (warped ones > 0.999) */
+int ff_pwc_backwarp(const float* in, int in_ld, const float* flow, int flow_ld, float* out, int out_ld,
+                    int B, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
