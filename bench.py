@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+DTYPES = {"f16x3": "f32 via fp16x3 split operands on the f16 MFMA pipe (f32 accumulate, fp32-level accuracy)",
+          "fp32": "f32", "f16": "f16 operands, f32 accumulate (reduced precision)"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 LOOKUP_BYTES_PER_QUERY = 2904  # 4*100*4 (windows) + 4*81*4 (output) + 8 (coords)
 
@@ -207,10 +209,11 @@ def main():
             "metric": "frame-pairs/sec FF-RAFT 384x512 iters=12", "value": round(pairs / elapsed, 3),
             "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPES[ops.conv_precision()], "data": "synthetic",
             "config": {"workload": f"FF-RAFT forward (test_mode), {args.batch} pairs/GPU {args.height}x{args.width}, "
                                    f"iters={args.iters}, random-init weights, ORB-like masks (BASELINE configs[1])",
-                       "pairs_per_gpu": args.batch, "parallelism": f"dp{world} (independent shards, no collective)"},
+                       "pairs_per_gpu": args.batch, "conv_precision": ops.conv_precision(),
+                       "parallelism": f"dp{world} (independent shards, no collective)"},
             "roofline": {"kernel": "lookup_wave_kernel (ff_corr_lookup_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(q),
