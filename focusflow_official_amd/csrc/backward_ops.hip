@@ -84,7 +84,7 @@ __device__ __forceinline__ void norm_coeffs(const NormBwdArgs& a, int b, int c, 
     bt = a.beta ? a.beta[c] : 0.f;
 }
 
-constexpr int NSLAB = 2048;
+constexpr int NSLAB = 256;
 
 __global__ __launch_bounds__(256) void norm_bwd_stats_kernel(const NormBwdArgs a) {
     __shared__ double red[256 * 8];

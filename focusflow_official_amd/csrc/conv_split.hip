@@ -15,6 +15,7 @@
 // chunk, so one ds_read_b128 is exactly one MFMA operand (8 consecutive k).  Weights arrive
 // pre-split in that row format (ff_pack_split_f16); activations stay fp32 in HBM and are split
 // in registers on their way to LDS.  Operands must satisfy |x| < 65504.
+#include <cstdlib>
 #include "ff_common.h"
 
 namespace {
@@ -237,10 +238,18 @@ template <int TERMS>
 int dispatch(const KernArgs& a, hipStream_t s) {
     const FFConvParams& p = a.p;
     const long long M = a.M, g = p.groups;
+    static const int force = getenv("FF_SPLIT_TILE") ? atoi(getenv("FF_SPLIT_TILE")) : -1;   // tuning only
+    if (force == 0) return launch<2, 2, 1, 1, TERMS>(a, s);
+    if (force == 1) return launch<2, 2, 2, 1, TERMS>(a, s);
+    if (force == 2) return launch<2, 2, 2, 2, TERMS>(a, s);
+    if (force == 3) return p.Cout > 64 && p.Cout <= 96 ? launch<4, 1, 1, 3, TERMS>(a, s) : launch<2, 2, 2, 1, TERMS>(a, s);
+    // With f16-rate MFMAs a chunk of compute no longer hides a global-load round trip, so residency
+    // (blocks per CU) beats tile size: the 128x128 three-term tile needs 270 registers = 1 block/CU and
+    // measured 1.8x slower end to end than 128x64 (3 blocks/CU).  Keep 128x128 for the 1-term mode only.
     auto blocks = [&](int bm, int bn) { return g * ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
-    if (p.Cout > 96 && (p.Cout % 128 == 0 || p.Cout > 192) && blocks(128, 128) >= 200) return launch<2, 2, 2, 2, TERMS>(a, s);
-    if (p.Cout > 64 && p.Cout <= 96 && blocks(128, 96) >= 200) return launch<4, 1, 1, 3, TERMS>(a, s);
-    if (blocks(128, 64) >= 400) return launch<2, 2, 2, 1, TERMS>(a, s);
+    if (TERMS == 1 && p.Cout > 96 && (p.Cout % 128 == 0 || p.Cout > 192) && blocks(128, 128) >= 512) return launch<2, 2, 2, 2, TERMS>(a, s);
+    if (p.Cout > 64 && p.Cout <= 96 && blocks(128, 96) >= 512) return launch<4, 1, 1, 3, TERMS>(a, s);
+    if (blocks(128, 64) >= 512) return launch<2, 2, 2, 1, TERMS>(a, s);
     return launch<2, 2, 1, 1, TERMS>(a, s);
 }
 

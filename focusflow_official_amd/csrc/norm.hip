@@ -9,7 +9,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int SLAB = 2048;  // pixels per block
+constexpr int SLAB = 256;   // pixels per block (>= 1500 blocks at 192x256xB8: fills 256 CUs)
 
 __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, int ld, int HW, int C,
                                                          int per_sample, double* __restrict__ stats) {
