@@ -27,6 +27,7 @@ import torch.distributed as dist  # noqa: E402
 
 DTYPES = {"f16x3": "f32 via fp16x3 split operands on the f16 MFMA pipe (f32 accumulate, fp32-level accuracy)",
           "fp32": "f32", "f16": "f16 operands, f32 accumulate (reduced precision)"}
+MFMA_PEAK_TFLOPS = {"f16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense f16/bf16 MFMA, fp32 MFMA
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 LOOKUP_BYTES_PER_QUERY = 2904  # 4*100*4 (windows) + 4*81*4 (output) + 8 (coords)
 
@@ -194,10 +195,11 @@ def main():
         step()
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
-    ops.profile_begin("ff_corr_lookup_fwd")          # HIP events around every lookup launch
+    ops.profile_begin("lookup", "corr_volume")       # HIP events around every lookup / corr-build launch
     elapsed, out = timed_region(step, args.steps, world, torch.cuda.synchronize, device)
     log(f"{args.steps} timed steps in {elapsed:.3f} s")
-    lookup_ms = ops.profile_end()
+    prof = ops.profile_end()
+    lookup_ms, vol_ms = prof["lookup"], prof["corr_volume"]
     assert torch.isfinite(out[1]).all()
 
     if rank == 0:
@@ -220,6 +222,18 @@ def main():
                          "launches": len(lookup_ms), "avg_launch_us": round(per_launch_ms * 1e3, 2),
                          "algorithmic_bytes_per_launch": LOOKUP_BYTES_PER_QUERY * q},
         }
+        # corr-volume build (BASELINE.md "also reported"): dense HWxC x CxHW contraction on the matrix pipe
+        q1 = (args.height // 8) * (args.width // 8)
+        vol_flop = 2.0 * (hi - lo) * q1 * q1 * 256
+        vol_avg_ms = sum(vol_ms) / max(1, len(vol_ms))
+        terms = {"f16x3": 3, "f16": 1, "fp32": 1}[ops.conv_precision()]
+        peak = MFMA_PEAK_TFLOPS["fp32" if ops.conv_precision() == "fp32" else "f16"]
+        issued = vol_flop * terms / (vol_avg_ms * 1e-3) / 1e12 if vol_avg_ms > 0 else 0.0
+        line["roofline_corr_build"] = {
+            "kernel": "conv kernel, groups=B (ff_conv2d_fwd via ops.corr_volume)", "bound": "mfma",
+            "achieved": round(issued, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(issued / peak, 4),
+            "note": f"{terms} MFMA term(s) per fp32-accurate product; useful rate {vol_flop / (vol_avg_ms * 1e-3) / 1e12:.1f} TFLOP/s",
+            "launches": len(vol_ms), "avg_launch_us": round(vol_avg_ms * 1e3, 1)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.height, args.width, args.iters)
         print(json.dumps(line), flush=True)

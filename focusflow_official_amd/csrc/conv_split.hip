@@ -15,6 +15,7 @@
 // chunk, so one ds_read_b128 is exactly one MFMA operand (8 consecutive k).  Weights arrive
 // pre-split in that row format (ff_pack_split_f16); activations stay fp32 in HBM and are split
 // in registers on their way to LDS.  Operands must satisfy |x| < 65504.
+#include <algorithm>
 #include <cstdlib>
 #include "ff_common.h"
 
@@ -46,7 +47,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, int TERMS>
+template <int WM, int WN, int TM, int TN, int TERMS, int NST, bool UNI>
 __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LA = BM / 32, LB = BN / 32;
@@ -86,14 +87,70 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
             img[i] = 0;
         }
     }
+    // ---- UNI fast path (Cin and every segment a multiple of 32): a 32-k chunk lies in ONE tap of ONE
+    // segment, so tap / segment / channel bookkeeping is block-uniform (scalar registers), each row
+    // carries a precomputed bitmask of the taps that fall inside the image, and loads are buffer loads
+    // whose hardware range check returns 0 for masked rows (offset forced out of range) — no
+    // divisions, no 64-bit multiplies, no exec-masked branches in the K loop.
+    unsigned long long vmask[LA];
+    int pixoff[LA];
+    if (UNI) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            unsigned long long mk = 0;
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                const int hi = hi0[i] + t / p.KW, wi = wi0[i] + t % p.KW;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) mk |= 1ull << t;
+            }
+            vmask[i] = mk;
+            pixoff[i] = img[i] + hi0[i] * W + wi0[i];
+        }
+    }
     const char* wbase = reinterpret_cast<const char*>(p.w) + (long long)grp * p.w_gstride * 4;
     const float* xs0 = p.x[0] + (long long)grp * p.x_gstride[0];
     const float* xs1 = p.x[1] ? p.x[1] + (long long)grp * p.x_gstride[1] : nullptr;
     const float* xs2 = p.x[2] ? p.x[2] + (long long)grp * p.x_gstride[2] : nullptr;
     const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
 
-    f32x4 ra[LA], rb[LB];
-    auto stage_load = [&](int kc) {
+    // buffer resources (wave-uniform): one per input segment + the packed weights
+    const long long pix_total = (long long)p.B * H * W;
+    __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs0), 0, (int)(pix_total * p.x_ld[0] * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs1 ? xs1 : xs0), 0, xs1 ? (int)(pix_total * p.x_ld[1] * 4) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs2 ? xs2 : xs0), 0, xs2 ? (int)(pix_total * p.x_ld[2] * 4) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase), 0, (int)((long long)p.Cout * a.w_row_bytes), 0x00020000);
+    int woff[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int n = n0 + rbase + 32 * i;
+        woff[i] = n < p.Cout ? (int)(n * a.w_row_bytes) + kq * 16 : 0x7fffffff;   // out of range -> zeros
+    }
+    auto stage_load_uni = [&](int kc, f32x4 (&ra)[LA], f32x4 (&rb)[LB]) {
+        // block-uniform decode of chunk kc (scalar unit): K order is (tap, ci)
+        const int k0 = kc * BK;
+        const int tap = k0 / a.Cin;                 // uniform: SALU
+        int ci0 = k0 - tap * a.Cin;
+        const int dy = tap / p.KW, dx = tap - dy * p.KW;
+        __amdgpu_buffer_rsrc_t rs;
+        int ld;
+        if (ci0 < c0) { rs = rs0; ld = p.x_ld[0]; }
+        else if (ci0 < c01) { rs = rs1; ld = p.x_ld[1]; ci0 -= c0; }
+        else { rs = rs2; ld = p.x_ld[2]; ci0 -= c01; }
+        const int dpix = dy * W + dx;
+        const int cib = (ci0 + kq * 4) * 4;          // byte offset of this thread's 4 channels
+        const int ldb = ld * 4;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const bool ok = (vmask[i] >> tap) & 1ull;
+            const int off = ok ? (pixoff[i] + dpix) * ldb + cib : 0x7fffffff;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[i], kc * ROWB, 0));
+    };
+    // NST = chunks of global loads kept in flight per thread (register ring depth)
+    f32x4 ra[NST][LA], rb[NST][LB];
+    auto stage_load = [&](int kc, f32x4 (&ra)[LA], f32x4 (&rb)[LB]) {
         const int k = kc * BK + kq * 4;
         const bool kok = k < a.K;
         const int tap = kok ? k / a.Cin : 0;
@@ -120,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
             rb[i] = v;
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, const f32x4 (&ra)[LA], const f32x4 (&rb)[LB]) {
         char* dA = sA + buf * BM * ROWB;
         char* dB = sB + buf * BN * ROWB;
         const int pc = kq >> 1, half = (kq & 1) * 8;
@@ -148,13 +205,8 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
     const int nk = (a.K + BK - 1) / BK;
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
     const int li = lane & 31, lh = lane >> 5;
-    int cur = 0;
-    for (int kc = 0; kc < nk; ++kc) {
-        if (kc + 1 < nk) stage_load(kc + 1);
+    auto compute = [&](int cur) {
         const char* cA = sA + cur * BM * ROWB;
         const char* cB = sB + cur * BN * ROWB;
 #pragma unroll
@@ -183,9 +235,29 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
                     }
                 }
         }
-        if (kc + 1 < nk) stage_store(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    };
+    // Register ring: chunk c lives in stage c % NST from its load until it is written to LDS.
+    // Iteration kc: issue the loads of chunk kc+NST (its stage was freed when chunk kc went to LDS),
+    // MFMA on chunk kc from LDS, then move chunk kc+1 (loaded NST-1 iterations ago) into the other
+    // LDS buffer.  hipcc's counted vmcnt waits only for that oldest stage.
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+        if (st < nk) { if (UNI) stage_load_uni(st, ra[st], rb[st]); else stage_load(st, ra[st], rb[st]); }
+    stage_store(0, ra[0], rb[0]);
+    __syncthreads();
+    int cur = 0;
+    for (int kc0 = 0; kc0 < nk; kc0 += NST) {
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int kc = kc0 + st;
+            if (kc < nk) {
+                if (kc + NST < nk) { if (UNI) stage_load_uni(kc + NST, ra[st], rb[st]); else stage_load(kc + NST, ra[st], rb[st]); }
+                compute(cur);
+                if (kc + 1 < nk) stage_store(cur ^ 1, ra[(st + 1) % NST], rb[(st + 1) % NST]);
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
     }
 
     float* yb = p.y + (long long)grp * p.y_gstride;
@@ -216,13 +288,13 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, int TERMS>
-int launch(const KernArgs& a, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, int TERMS, int NST, bool UNI>
+int launch_u(const KernArgs& a, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t lds = 2 * (BM + BN) * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<WM, WN, TM, TN, TERMS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<WM, WN, TM, TN, TERMS, NST, UNI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
@@ -230,8 +302,33 @@ int launch(const KernArgs& a, hipStream_t s) {
     k.m_tiles = (a.M + BM - 1) / BM;
     k.n_tiles = (a.p.Cout + BN - 1) / BN;
     dim3 grid(k.m_tiles * k.n_tiles, a.p.groups);
-    conv_split_kernel<WM, WN, TM, TN, TERMS><<<grid, 256, lds, s>>>(k);
+    conv_split_kernel<WM, WN, TM, TN, TERMS, NST, UNI><<<grid, 256, lds, s>>>(k);
     return ff::check_launch("ff_conv2d_fwd(split)");
+}
+
+template <int WM, int WN, int TM, int TN, int TERMS, int NST>
+int launch_n(const KernArgs& a, hipStream_t s) {
+    const FFConvParams& p = a.p;
+    static const bool allow = !getenv("FF_SPLIT_NO_UNI");
+    bool uni = allow && a.Cin % 32 == 0 && p.KH * p.KW <= 64;
+    long long max_bytes = (long long)p.Cout * a.w_row_bytes;
+    for (int i = 0; i < FF_MAX_SEG; ++i) {
+        if (p.x_c[i] % 32) uni = false;
+        if (p.x_c[i]) max_bytes = std::max(max_bytes, (long long)p.B * p.H * p.W * p.x_ld[i] * 4);
+    }
+    if (max_bytes >= (1ll << 31)) uni = false;      // buffer resources address < 2 GiB each
+    return uni ? launch_u<WM, WN, TM, TN, TERMS, NST, true>(a, s) : launch_u<WM, WN, TM, TN, TERMS, NST, false>(a, s);
+}
+
+template <int WM, int WN, int TM, int TN, int TERMS>
+int launch(const KernArgs& a, hipStream_t s) {
+    // Ring depth 1 = plain double buffering.  Depth 3 was measured SLOWER end to end for the 128-row
+    // tiles (200+ registers -> 2 blocks/CU instead of 3) and +3% for the 64x64 tile; FF_SPLIT_NST
+    // overrides for tuning runs.
+    static const int nst = getenv("FF_SPLIT_NST") ? atoi(getenv("FF_SPLIT_NST")) : (TM * TN == 1 ? 3 : 1);
+    if (nst >= 3) return launch_n<WM, WN, TM, TN, TERMS, 3>(a, s);
+    if (nst == 2) return launch_n<WM, WN, TM, TN, TERMS, 2>(a, s);
+    return launch_n<WM, WN, TM, TN, TERMS, 1>(a, s);
 }
 
 template <int TERMS>

@@ -56,33 +56,36 @@ def pack_split(rows_f32: Tensor) -> Tensor:
 
 # Optional per-launch timing of ONE entry point with HIP events recorded on the
 # launch stream (bench.py's roofline leg).  Off unless profile_begin() is called.
-_prof_name = None
-_prof_events = []
+_prof_on = False
+_prof_events = {}
 
 
-def profile_begin(name: str):
-    global _prof_name
-    _prof_name = name
+def profile_begin(*labels: str):
+    """Time every launch carrying one of `labels` with a HIP event pair on the launch stream."""
+    global _prof_on
+    _prof_on = True
     _prof_events.clear()
+    for lb in labels:
+        _prof_events[lb] = []
 
 
 def profile_end():
-    """-> list of per-launch milliseconds (synchronises)."""
-    global _prof_name
-    _prof_name = None
+    """-> {label: [per-launch milliseconds]} (synchronises)."""
+    global _prof_on
+    _prof_on = False
     torch.cuda.synchronize()
-    ms = [a.elapsed_time(b) for a, b in _prof_events]
+    out = {lb: [a.elapsed_time(b) for a, b in ev] for lb, ev in _prof_events.items()}
     _prof_events.clear()
-    return ms
+    return out
 
 
-def _timed_call(name, *args):
-    if _prof_name == name:
+def _timed_call(label, name, *args):
+    if _prof_on and label in _prof_events:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         _hip.call(name, *args)
         b.record()
-        _prof_events.append((a, b))
+        _prof_events[label].append((a, b))
     else:
         _hip.call(name, *args)
 
@@ -186,7 +189,7 @@ def corr_volume(fmap1: Tensor, fmap2: Tensor) -> Tensor:
     p.Ho, p.Wo, p.Cout = h, w, q
     p.KH = p.KW = p.stride = 1
     _require_gpu(fmap1)
-    _hip.call("ff_conv2d_fwd", C.byref(p), _stream())
+    _timed_call("corr_volume", "ff_conv2d_fwd", C.byref(p), _stream())
     return vol
 
 
@@ -213,7 +216,7 @@ def corr_lookup(levels: List[Tensor], coords: Tensor, radius: int = 4, want_taps
     taps = torch.empty((b * h * w, nl, 2, 2 * radius + 1), dtype=torch.int32, device=coords.device) if want_taps else None
     arr = (C.c_void_p * 4)(*[lv.data_ptr() for lv in levels] + [0] * (4 - nl))
     h0, w0 = levels[0].shape[-2:]
-    _timed_call("ff_corr_lookup_fwd", arr, nl, radius, _p(coords), b * h * w, h0, w0, _p(out), nk, _p(taps), _stream())
+    _timed_call("lookup", "ff_corr_lookup_fwd", arr, nl, radius, _p(coords), b * h * w, h0, w0, _p(out), nk, _p(taps), _stream())
     return (out, taps) if want_taps else out
 
 
