@@ -68,6 +68,11 @@ _SIGS = {
     "ff_pwc_costvolume_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_pwc_gout_transpose": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_pwc_backwarp": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    # fused sequence loss
+    "ff_loss_prepare": [_fp, _fp, _fp, _fp, C.c_int, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_loss_accumulate": [_fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, C.c_int, C.c_int,
+                           C.c_int, _fp],
+    "ff_epe_metric": [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
 }
 EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version"])
 

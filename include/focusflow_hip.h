@@ -229,6 +229,24 @@ int ff_pwc_gout_transpose(const float* g, int g_ld, float* gt, int gt_ld, int B,
 int ff_pwc_backwarp(const float* in, int in_ld, const float* flow, int flow_ld, float* out, int out_ld,
                     int B, int H, int W, int C, void* stream);
 
+/* ========================================================================
+ * Fused sequence loss (core/models/ff-raft/losses/losses.py:18-130: EPELoss, CPCL, MixLoss).
+ * All tensors NCHW fp32 as the reference's loss receives them: preds/flow_gt (B,2,H,W),
+ * valid (B,H,W), mask (B,1,H,W).
+ *   ff_loss_prepare    vmap = (valid>=0.5)&(|gt|<max_flow); gconv = G*(mask>0) (zero padded),
+ *                      *gsum += sum(gconv)  (fp64, CALLER ZEROES); mask == NULL skips the G part
+ *   ff_loss_accumulate *loss += weight * sum w*|pred-gt|, w = vmap*(a_mean + lam*gconv/gsum);
+ *                      grad (nullable) = weight * w * sign(pred-gt)     (*loss fp64, CALLER ZEROES)
+ *   ff_epe_metric      out2 += {sum of end-point errors over vmap, count}
+ * ======================================================================== */
+int ff_loss_prepare(const float* flow_gt, const float* valid, const float* mask, const float* gauss, int ks,
+                    float max_flow, float* vmap, float* gconv, double* gsum, int B, int H, int W, void* stream);
+int ff_loss_accumulate(const float* pred, const float* flow_gt, const float* vmap, const float* gconv,
+                       const double* gsum, float a_mean, float lam, float weight, float* grad, double* loss,
+                       int B, int H, int W, void* stream);
+int ff_epe_metric(const float* pred, const float* flow_gt, const float* vmap, double* out2, int B, int H, int W,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -341,3 +341,47 @@ def shifted_pair(b, h, w, seed=0, shift=(3, -5), n_points=500, smooth=4):
     image2 = image2.clamp(0, 255)
     mask1 = (torch.rand(b, 1, h, w, generator=g) < n_points / (h * w)).float() * 255
     return image1.contiguous(), image2.contiguous(), mask1, torch.zeros_like(mask1)
+
+
+def gaussian_box(kernel_size, sigma):
+    """losses.py:7-15."""
+    import numpy as np
+    s3 = 3 * sigma
+    xs = np.linspace(-s3, s3, kernel_size)
+    x, y = np.meshgrid(xs, xs)
+    gauss = 1 / (2 * np.pi * sigma ** 2) * np.exp(-(x ** 2 + y ** 2) / (2 * sigma ** 2))
+    return torch.FloatTensor((1 / gauss.sum()) * gauss).view(1, 1, kernel_size, kernel_size)
+
+
+def sequence_loss(kind, preds, flow_gt, valid, mask, gamma=0.8, max_flow=400.0, kernel_size=5, sigma=1.7, lamda=0.8):
+    """EPELoss / CPCL / MixLoss, losses.py:18-130 (kind in {'EPELoss','CPCL','MixLoss'})."""
+    n = len(preds)
+    mag = torch.sum(flow_gt ** 2, dim=1).sqrt()
+    ok = (valid >= 0.5) & (mag < max_flow)
+    if kind != "EPELoss":
+        m = (mask > 0).float()
+        pad = kernel_size // 2
+        m = F.conv2d(F.pad(m, [pad, pad, pad, pad]), gaussian_box(kernel_size, sigma))
+    loss = 0.0
+    for i, pr in enumerate(preds):
+        wgt = gamma ** (n - i - 1)
+        l1 = (pr - flow_gt).abs()
+        if kind == "CPCL":
+            loss = loss + wgt * (ok[:, None] * m * l1).sum() / m.sum()
+        elif kind == "MixLoss":
+            loss = loss + lamda * wgt * (ok[:, None] * m * l1).sum() / m.sum()
+            loss = loss + wgt * (ok[:, None] * l1).mean()
+        else:
+            loss = loss + wgt * (ok[:, None] * l1).mean()
+    epe = torch.sum((preds[-1] - flow_gt) ** 2, dim=1).sqrt().view(-1)[ok.view(-1)]
+    return loss, {"epe": epe.mean().item(), "loss": float(loss.detach())}
+
+
+def loss_inputs(seed=0, b=2, h=48, w=64, n=3):
+    g = torch.Generator().manual_seed(seed)
+    flow_gt = torch.randn(b, 2, h, w, generator=g) * 4
+    flow_gt[0, :, :4, :4] = 500.0                       # beyond max_flow: excluded
+    preds = [flow_gt + torch.randn(b, 2, h, w, generator=g) * (n - i) for i in range(n)]
+    valid = (torch.rand(b, h, w, generator=g) > 0.1).float()
+    mask = (torch.rand(b, 1, h, w, generator=g) < 0.05).float() * 255
+    return preds, flow_gt, valid, mask

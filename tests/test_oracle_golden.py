@@ -186,3 +186,20 @@ def test_c_oracle_matches_reference_vectors(det_sd):
     sizes = [tuple(p.shape[-2:]) for p in ref_pyr]
     for lvl, (x0, y0, _, _) in enumerate(orc.lookup_taps(torch.from_numpy(g["crand"]), sizes)):
         assert (tp[:, lvl, 0] == x0.numpy()).all() and (tp[:, lvl, 1] == y0.numpy()).all()
+
+
+LOSS_KINDS = {"EPELoss": {}, "CPCL": dict(kernel_size=5, sigma=1.7), "MixLoss": dict(kernel_size=5, sigma=1.7, lamda=0.8),
+              "MixLoss_k1": dict(kernel_size=1, sigma=0.01, lamda=1)}
+
+
+@pytest.mark.parametrize("kind", list(LOSS_KINDS))
+def test_loss_oracle_matches_reference(kind):
+    g = load_golden("losses")
+    preds, gt, valid, mask = orc.loss_inputs()
+    preds = [p.requires_grad_(True) for p in preds]
+    loss, metrics = orc.sequence_loss(kind.split("_")[0], preds, gt, valid, mask, **LOSS_KINDS[kind])
+    loss.backward()
+    assert abs(loss.item() - g[kind + ":loss"][0]) < 1e-6 * max(1, abs(g[kind + ":loss"][0]))
+    assert abs(metrics["epe"] - g[kind + ":epe"][0]) < 1e-5
+    for i, p in enumerate(preds):
+        np.testing.assert_allclose(p.grad[:, :, ::3, ::3].numpy(), g[f"{kind}:g{i}"], rtol=1e-5, atol=1e-9)
