@@ -150,6 +150,63 @@ def harness_selftest(args):
         dist.destroy_process_group()
 
 
+def train_mode(args, world, rank, local_rank, device):
+    """One training step = train.py:291-328 on synthetic FlyingChairs-shaped data: forward (train mode),
+    MixLoss (ffraft_chairs_orb.yaml:35-39), loss *= world_size, backward (+ DDP all-reduce over RCCL),
+    clip_grad_norm_(1.0), AdamW + OneCycleLR step.  Optimiser/scheduler are stock PyTorch as in the reference."""
+    from torch.nn.parallel import DistributedDataParallel
+    from focusflow_official_amd import FF_RAFT_FUSION
+    from focusflow_official_amd.losses import build_losses
+    h, w = (368, 496) if (args.height, args.width) == (384, 512) else (args.height, args.width)
+    torch.manual_seed(1234)
+    model = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).train()
+    net = DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False) if world > 1 else model
+    opt = torch.optim.AdamW(model.parameters(), lr=4e-4, weight_decay=1e-5, eps=1e-8)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, 4e-4, 100000, pct_start=0.05, cycle_momentum=False, anneal_strategy="linear")
+    crit = build_losses("MixLoss", gamma=0.8, max_flow=400, kernel_size=1, sigma=0.01, lamda=1)
+    batch = synthetic_batch(args.batch, h, w, 1234 + rank, device)
+    g = torch.Generator().manual_seed(99 + rank)
+    flow_gt = (torch.randn(args.batch, 2, h, w, generator=g) * 5).clamp(-400, 400).to(device)
+    valid = torch.ones(args.batch, h, w, device=device)
+
+    def step():
+        preds = net(*batch, raft_iters=args.iters)
+        loss, _ = crit(preds, flow_gt, valid, batch[2])
+        opt.zero_grad(set_to_none=True)
+        (loss * world).backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        sched.step()
+        return loss
+
+    log(f"train mode rank {rank}/{world}: {args.batch} pairs {h}x{w}")
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    elapsed, loss = timed_region(step, args.steps, world, torch.cuda.synchronize, device)
+    assert torch.isfinite(loss)
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        print(json.dumps({
+            "metric": "training frame-pairs/sec FF-RAFT 368x496 iters=12 (fwd+MixLoss+bwd+AdamW)",
+            "value": round(pairs / elapsed, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (forward convs: " + ops_precision() + "; backward fp32 MFMA)",
+            "data": "synthetic",
+            "config": {"workload": f"FF-RAFT training step, {args.batch} pairs/GPU {h}x{w}, iters={args.iters}, MixLoss "
+                                   f"(k=1, sigma=0.01, lamda=1), AdamW + OneCycleLR, clip 1.0 (BASELINE configs[2] shape)",
+                       "pairs_per_gpu": args.batch, "parallelism": f"dp{world}" + (" DDP/RCCL all-reduce 30.65 MB" if world > 1 else "")},
+            "final_loss": loss.detach().item()}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def ops_precision():
+    from focusflow_official_amd import ops
+    return ops.conv_precision()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +217,9 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward = BASELINE configs[1] (the headline metric); train = configs[2]-shaped step "
+                         "(forward + MixLoss + backward + clip + AdamW, DDP over RCCL when --gpus > 1)")
     ap.add_argument("--harness-selftest", action="store_true",
                     help="no model: a sleep() stands in for the step so the multi-rank harness (sharding, barrier, "
                          "max-over-ranks timing, single JSON line) can be tested on CPU with gloo")
@@ -180,6 +240,8 @@ def main():
     torch.cuda.set_device(device)
 
     from focusflow_official_amd import FF_RAFT_FUSION, ops
+    if args.mode == "train":
+        return train_mode(args, world, rank, local_rank, device)
     torch.manual_seed(1234)
     model = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
     # weak scaling: every rank owns args.batch independent pairs of the global batch
