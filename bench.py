@@ -217,6 +217,7 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = BASELINE configs[1] (the headline metric); train = configs[2]-shaped step "
                          "(forward + MixLoss + backward + clip + AdamW, DDP over RCCL when --gpus > 1)")
@@ -252,6 +253,11 @@ def main():
         with torch.no_grad():
             return model(*batch, raft_iters=args.iters, test_mode=True)
 
+    if args.graph:
+        from focusflow_official_amd.graph import GraphedForward
+        graphed = GraphedForward(model, batch, raft_iters=args.iters)
+        step = lambda: graphed(*batch)  # noqa: E731
+
     log(f"rank {rank}/{world}: model + {hi - lo} pairs on {torch.cuda.get_device_name(device)}")
     for i in range(args.warmup):
         step()
@@ -267,6 +273,12 @@ def main():
     if rank == 0:
         pairs = args.batch * world * args.steps
         q = (hi - lo) * (args.height // 8) * (args.width // 8)
+        if args.graph:   # per-launch events cannot be recorded inside a replayed graph: time the kernels eagerly
+            ops.profile_begin("lookup", "corr_volume")
+            with torch.no_grad():
+                model(*batch, raft_iters=args.iters, test_mode=True)
+            prof = ops.profile_end()
+            lookup_ms, vol_ms = prof["lookup"], prof["corr_volume"]
         per_launch_ms = sum(lookup_ms) / max(1, len(lookup_ms))
         achieved = LOOKUP_BYTES_PER_QUERY * q / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         line = {
@@ -276,7 +288,7 @@ def main():
             "vs_baseline": None, "dtype": DTYPES[ops.conv_precision()], "data": "synthetic",
             "config": {"workload": f"FF-RAFT forward (test_mode), {args.batch} pairs/GPU {args.height}x{args.width}, "
                                    f"iters={args.iters}, random-init weights, ORB-like masks (BASELINE configs[1])",
-                       "pairs_per_gpu": args.batch, "conv_precision": ops.conv_precision(),
+                       "pairs_per_gpu": args.batch, "conv_precision": ops.conv_precision(), "hipgraph": bool(args.graph),
                        "parallelism": f"dp{world} (independent shards, no collective)"},
             "roofline": {"kernel": "lookup_wave_kernel (ff_corr_lookup_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

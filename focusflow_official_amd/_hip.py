@@ -73,6 +73,7 @@ _SIGS = {
     "ff_loss_accumulate": [_fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, C.c_int, C.c_int,
                            C.c_int, _fp],
     "ff_epe_metric": [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_mask_prepare": [C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
 }
 EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version"])
 

@@ -1,9 +1,39 @@
 """FF_RAFT_FUSION: the drop-in nn.Module (ff_raft.py:75-164) on the HIP path."""
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import _hip, ops
 from .raft_net import RAFT
+
+MASK_MODES = {"neighborG": 0, "neighborE": 1, "context": 2}
+
+
+def gaussian_table(kernel_size, sigma):
+    """ff_raft.py:13-21 (host-side numpy) restated."""
+    s3 = 3 * sigma
+    xs = np.linspace(-s3, s3, kernel_size)
+    x, y = np.meshgrid(xs, xs)
+    gauss = 1 / (2 * np.pi * sigma ** 2) * np.exp(-(x ** 2 + y ** 2) / (2 * sigma ** 2))
+    return torch.FloatTensor((1 / gauss.sum()) * gauss).contiguous()
+
+
+def ellipse_table(k):
+    """cv.getStructuringElement(cv.MORPH_ELLIPSE, (k, k)) as OpenCV 4.7 (requirements.txt pins
+    opencv_python==4.7.0.72) computes it: row i spans columns c-dx .. c+dx with
+    dx = round(c * sqrt((r*r - dy*dy) / (r*r))), r = c = k // 2, dy = i - r.  cv2 is absent from this
+    image, so this is a restatement of the published algorithm (parity unpinned)."""
+    r = c = k // 2
+    el = np.zeros((k, k), np.float32)
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    for i in range(k):
+        dy = i - r
+        if abs(dy) <= r:
+            dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))
+            el[i, max(c - dx, 0):min(c + dx + 1, k)] = 1.0
+    if k == 1:
+        el[:] = 1.0
+    return torch.from_numpy(el).contiguous()
 
 
 class FF_RAFT_FUSION(nn.Module):
@@ -25,8 +55,10 @@ class FF_RAFT_FUSION(nn.Module):
         self.freeze_flownet = freeze_flownet
         self.cfg = cfg
         modal = getattr(cfg.TRAIN, "MASK_MODAL", "point")
-        if modal != "point":
-            raise NotImplementedError(f"MASK_MODAL={modal!r} is a 'next' row (SURVEY §8f-3); 'point' is built")
+        if modal not in ("point", "frame") and modal not in MASK_MODES:
+            raise ValueError(f"MASK_MODAL={modal!r} is not one of point/frame/neighborG/neighborE/context")
+        self.mask_modal = modal
+        self._table = None
         self.flow_net = RAFT(in_channels=fusion_channels, small=raft_small, dropout=dropout,
                              alternate_corr=alternate_corr, abandon_fnet=abandon_fnet,
                              inside_fusion="parallel", fuse_cnet=fuse_cnet, cfg=cfg)
@@ -49,8 +81,19 @@ class FF_RAFT_FUSION(nn.Module):
         # 'point' mode ignores the caller's mask2 and uses a constant 255 plane.
         i1 = ops.prep_input(image1, b, h, w, image1)
         i2 = ops.prep_input(image2, b, h, w, image1)
-        m1 = ops.prep_input(mask1, b, h, w, image1)
-        m2 = ops.prep_input(None, b, h, w, image1, fill=255.0)
+        modal = self.mask_modal
+        if modal == "point":
+            m1 = ops.prep_input(mask1, b, h, w, image1)
+            m2 = ops.prep_input(None, b, h, w, image1, fill=255.0)
+        elif modal == "frame":                      # ff_raft.py:68-70: the masks are the frames themselves
+            m1, m2 = i1, i2
+        else:                                       # ff_raft.py:24-30, 40-66
+            if self._table is None or self._table.device != image1.device:
+                t = self.cfg.TRAIN
+                tab = gaussian_table(t.KERNEL_SIZE, t.KERNEL_SIGMA) if modal == "neighborG" else ellipse_table(t.MASK_DILATE)
+                self._table = tab.to(image1.device)
+            m1 = ops.mask_prepare(MASK_MODES[modal], mask1, image1, self._table)
+            m2 = i2 if modal == "context" else ops.prep_input(None, b, h, w, image1, fill=255.0)
         return self.flow_net(i1, i2, m1, m2, iters=raft_iters, flow_init=flow_init, test_mode=test_mode)
 
     def freeze_self(self):

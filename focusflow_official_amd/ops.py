@@ -265,6 +265,18 @@ def prep_input(src_nchw: Optional[Tensor], b, h, w, like: Tensor, fill: float = 
     return dst
 
 
+def mask_prepare(mode: int, mask_nchw: Tensor, image_nchw: Tensor, table: Tensor) -> Tensor:
+    """init_mask modes neighborG(0)/neighborE(1)/context(2) + scaling -> NHWC4."""
+    _require_gpu(mask_nchw)
+    b, _, h, w = mask_nchw.shape
+    dst = empty_nhwc(b, h, w, 4, mask_nchw)
+    tmp = torch.empty((b, h, w), dtype=torch.float32, device=mask_nchw.device)
+    gmax = torch.empty(1, dtype=torch.int32, device=mask_nchw.device)
+    _hip.call("ff_mask_prepare", mode, _p(mask_nchw.contiguous()), _p(image_nchw.contiguous()), _p(table), table.shape[0],
+              _p(tmp), _p(gmax), _p(dst), b, h, w, _stream())
+    return dst
+
+
 def act_copy(src: Tensor, dst: Tensor, act: int):
     b, h, w, c = src.shape
     assert dst.shape == src.shape

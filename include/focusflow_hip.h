@@ -247,6 +247,13 @@ int ff_loss_accumulate(const float* pred, const float* flow_gt, const float* vma
 int ff_epe_metric(const float* pred, const float* flow_gt, const float* vmap, double* out2, int B, int H, int W,
                   void* stream);
 
+/* init_mask modes neighborG (0) / neighborE (1) / context (2), ff_raft.py:23-72, fused with the
+ * [0,255] -> [-1,1] scaling: mask (B,1,H,W) [+ image (B,3,H,W)] -> NHWC4.  `table` = host-built k x k
+ * Gaussian (get_kernel, :13-21) or ellipse structuring element; tmp (B*H*W floats) and gmax (1 word)
+ * are caller-provided scratch. */
+int ff_mask_prepare(int mode, const float* mask, const float* image, const float* table, int ks, float* tmp,
+                    unsigned int* gmax, float* dst_nhwc4, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -385,3 +385,43 @@ def loss_inputs(seed=0, b=2, h=48, w=64, n=3):
     valid = (torch.rand(b, h, w, generator=g) > 0.1).float()
     mask = (torch.rand(b, 1, h, w, generator=g) < 0.05).float() * 255
     return preds, flow_gt, valid, mask
+
+
+# ----------------------------------------------------------------------------
+# init_mask modes (ff_raft.py:23-72)
+# ----------------------------------------------------------------------------
+def ellipse_element(k):
+    """cv.getStructuringElement(MORPH_ELLIPSE, (k,k)) per OpenCV 4.7.0 (requirements.txt:
+    opencv_python==4.7.0.72; cv2 is absent here -> published algorithm restated, PARITY UNPINNED)."""
+    import numpy as np
+    r = c = k // 2
+    el = np.zeros((k, k), np.float32)
+    for i in range(k):
+        dy = i - r
+        if abs(dy) <= r and r:
+            dx = int(np.rint(c * np.sqrt((r * r - dy * dy) / float(r * r))))
+            el[i, max(c - dx, 0):min(c + dx + 1, k)] = 1.0
+    if k == 1:
+        el[:] = 1.0
+    return torch.from_numpy(el)
+
+
+def init_mask(image1, image2, mask1, modal, mask_channel=3, dilate=31, kernel_size=31, kernel_sigma=5):
+    """-> (mask1, mask2) in [0,255] as ff_raft.py:23-72 builds them."""
+    if modal == "point":
+        m1 = mask1.repeat(1, mask_channel, 1, 1)
+        return m1, torch.ones_like(m1) * 255
+    if modal == "frame":
+        return image1.clone(), image2.clone()
+    if modal == "neighborG":
+        m = F.conv2d(mask1, gaussian_box(kernel_size, kernel_sigma), padding=kernel_size // 2)
+        m = (m * 255 / m.max()).repeat(1, mask_channel, 1, 1)
+        return m, torch.ones_like(m) * 255
+    el = ellipse_element(dilate)[None, None]
+    dil = F.conv2d(mask1 / 255, el, padding=dilate // 2) > 0
+    if modal == "neighborE":
+        m = (dil * 255).float().repeat(1, mask_channel, 1, 1)
+        return m, torch.ones_like(m) * 255
+    if modal == "context":
+        return dil * image1, image2.clone()
+    raise ValueError(modal)

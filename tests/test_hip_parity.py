@@ -371,3 +371,61 @@ def test_full_size_lookup_properties(ops):
     # pyramid means are preserved level to level (48x64 divides evenly)
     for lo, hi in zip(pyr[:-1], pyr[1:]):
         close(hi.mean(dim=(1, 2)).cpu(), lo.mean(dim=(1, 2)).cpu(), rtol=1e-4, atol=1e-4, what="pool mean")
+
+
+def test_hipgraph_replay_matches_eager(det_sd):
+    """The captured forward (focusflow_official_amd/graph.py) replays bit-identically and tracks new inputs."""
+    from focusflow_official_amd.graph import GraphedForward
+    m = _model(det_sd)
+    a = [t.to(DEV) for t in orc.shifted_pair(1, 128, 192, seed=31)]
+    b = [t.to(DEV) for t in orc.shifted_pair(1, 128, 192, seed=32)]
+    with torch.no_grad():
+        ea = [t.clone() for t in m(*a, raft_iters=4, test_mode=True)]
+        eb = [t.clone() for t in m(*b, raft_iters=4, test_mode=True)]
+    gf = GraphedForward(m, a, raft_iters=4)
+    ga = [t.clone() for t in gf(*a)]
+    gb = [t.clone() for t in gf(*b)]
+    ga2 = [t.clone() for t in gf(*a)]
+    torch.cuda.synchronize()
+    for x, y in zip(ea, ga):
+        assert torch.equal(x, y)
+    for x, y in zip(eb, gb):
+        assert torch.equal(x, y)
+    for x, y in zip(ga, ga2):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("modal", ["frame", "neighborG", "neighborE", "context"])
+def test_mask_modes(modal, det_sd):
+    """init_mask modes (ff_raft.py:23-72): prepared mask tensors and the resulting flow vs the oracle."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    from focusflow_official_amd import ops as _ops
+    cfg = _cfg()
+    cfg.TRAIN.MASK_MODAL, cfg.TRAIN.MASK_DILATE, cfg.TRAIN.KERNEL_SIZE, cfg.TRAIN.KERNEL_SIGMA = modal, 31, 31, 5
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg)
+    m.load_state_dict(det_sd)
+    m = m.to(DEV).eval()
+    inp = orc.shifted_pair(2, 128, 160, seed=17)
+    r1, r2 = orc.init_mask(inp[0], inp[1], inp[2], modal)
+    ref_in = tuple(2 * (t / 255.0) - 1.0 for t in (inp[0], inp[1], r1, r2))
+    if modal in MASK_TABLE_MODES:
+        from focusflow_official_amd.model import MASK_MODES, ellipse_table, gaussian_table
+        tab = gaussian_table(31, 5) if modal == "neighborG" else ellipse_table(31)
+        got = _ops.mask_prepare(MASK_MODES[modal], inp[2].to(DEV), inp[0].to(DEV), tab.to(DEV))
+        close(nchw(got)[:, :3], ref_in[2], rtol=0, atol=2e-5, what=f"{modal} mask tensor")
+    with torch.no_grad():
+        _, fu = m(*[t.to(DEV) for t in inp], raft_iters=3, test_mode=True)
+        _, ref = orc.raft_forward(det_sd, *ref_in, iters=3, test_mode=True, prefix="flow_net.")
+    close(fu.cpu(), ref, rtol=0, atol=1e-3, what=f"{modal} flow")
+
+
+MASK_TABLE_MODES = ("neighborG", "neighborE", "context")
+
+
+def test_input_padder_roundtrip():
+    from focusflow_official_amd.utils import InputPadder
+    x = torch.arange(2 * 3 * 436 * 1022, dtype=torch.float32).view(2, 3, 436, 1022)
+    for mode in ("sintel", "kitti"):
+        p = InputPadder(x.shape, mode)
+        (y,) = p.pad(x)
+        assert y.shape[-2] % 8 == 0 and y.shape[-1] % 8 == 0 and torch.equal(p.unpad(y), x)
