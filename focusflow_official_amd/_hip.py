@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libfocusflow_hip.so")
 
-ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 W_F32, W_F16X3, W_F16 = 0, 1, 2
 MAX_SEG = 3
 _fp = C.c_void_p
@@ -26,6 +26,7 @@ class FFConvParams(C.Structure):
         ("y_gstride", _ll), ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
         ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
         ("act", C.c_int), ("act_res", C.c_int), ("w_format", C.c_int),
+        ("dil_h", C.c_int), ("dil_w", C.c_int),
     ]
 
 
@@ -67,12 +68,14 @@ _SIGS = {
     "ff_pwc_costvolume_fwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_pwc_costvolume_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_pwc_gout_transpose": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
-    "ff_pwc_backwarp": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_pwc_backwarp": [_fp, C.c_int, _fp, C.c_int, C.c_float, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     # fused sequence loss
     "ff_loss_prepare": [_fp, _fp, _fp, _fp, C.c_int, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_loss_accumulate": [_fp, _fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, C.c_int, C.c_int,
                            C.c_int, _fp],
     "ff_epe_metric": [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_nchw_to_nhwc4": [_fp, C.c_int, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_resize_bilinear": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp],
     "ff_mask_prepare": [C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
 }
 EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version"])

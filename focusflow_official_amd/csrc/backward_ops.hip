@@ -14,6 +14,7 @@ __device__ __forceinline__ float act_grad_from_output(float y, int act) {
         case FF_ACT_RELU: return y > 0.f ? 1.f : 0.f;
         case FF_ACT_SIGMOID: return y * (1.f - y);
         case FF_ACT_TANH: return 1.f - y * y;
+        case FF_ACT_LEAKY: return y > 0.f ? 1.f : 0.1f;
         default: return 1.f;
     }
 }

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const KernArgs a) {
     const float* xs1 = p.x[1] ? p.x[1] + (long long)grp * p.x_gstride[1] : nullptr;
     const float* xs2 = p.x[2] ? p.x[2] + (long long)grp * p.x_gstride[2] : nullptr;
     const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
 
     f32x4 ra[LA], rb[LB];
     auto stage_load = [&](int kc) {
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const KernArgs a) {
         else { xp = xs2; ld = p.x_ld[2]; ci -= c01; }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int hi = hi0[i] + dy, wi = wi0[i] + dx;
+            const int hi = hi0[i] + dy * dlh, wi = wi0[i] + dx * dlw;
             const bool ok = kok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *reinterpret_cast<const f32x4*>(xp + (long long)(img[i] + hi * W + wi) * ld + ci);
@@ -265,13 +266,15 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     }
     FF_REQUIRE(cin > 0, "ff_conv2d_fwd: no input channels");
     FF_REQUIRE(ff::aligned16(p.w) && p.w_gstride % 4 == 0, "ff_conv2d_fwd: weights not 16-byte aligned");
-    const int Ho = (p.H + 2 * p.pad_h - p.KH) / p.stride + 1, Wo = (p.W + 2 * p.pad_w - p.KW) / p.stride + 1;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
+    FF_REQUIRE(dlh >= 1 && dlw >= 1, "ff_conv2d_fwd: bad dilation");
+    const int Ho = (p.H + 2 * p.pad_h - dlh * (p.KH - 1) - 1) / p.stride + 1, Wo = (p.W + 2 * p.pad_w - dlw * (p.KW - 1) - 1) / p.stride + 1;
     FF_REQUIRE(Ho == p.Ho && Wo == p.Wo, "ff_conv2d_fwd: output %dx%d does not match conv arithmetic %dx%d", p.Ho, p.Wo, Ho, Wo);
     FF_REQUIRE(p.y_ld >= p.Cout, "ff_conv2d_fwd: y_ld %d < Cout %d", p.y_ld, p.Cout);
     FF_REQUIRE(!p.res || p.res_ld >= p.Cout, "ff_conv2d_fwd: res_ld too small");
     FF_REQUIRE((p.ch_scale == nullptr) == (p.ch_shift == nullptr), "ff_conv2d_fwd: ch_scale/ch_shift must come together");
-    FF_REQUIRE(p.act >= FF_ACT_NONE && p.act <= FF_ACT_TANH, "ff_conv2d_fwd: bad act %d", p.act);
-    FF_REQUIRE(p.act_res >= FF_ACT_NONE && p.act_res <= FF_ACT_TANH, "ff_conv2d_fwd: bad act_res %d", p.act_res);
+    FF_REQUIRE(p.act >= FF_ACT_NONE && p.act <= FF_ACT_LEAKY, "ff_conv2d_fwd: bad act %d", p.act);
+    FF_REQUIRE(p.act_res >= FF_ACT_NONE && p.act_res <= FF_ACT_LEAKY, "ff_conv2d_fwd: bad act_res %d", p.act_res);
     const long long M = (long long)p.B * Ho * Wo;
     FF_REQUIRE(M < (1ll << 30) && (long long)p.B * p.H * p.W < (1ll << 30), "ff_conv2d_fwd: too many pixels");
 

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
     const int m0 = mt * BM, n0 = nt * BN;
     const int H = p.H, W = p.W, Wo = p.Wo, HoWo = p.Ho * p.Wo;
     const int kq = tid & 7, rbase = tid >> 3;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
 
     int hi0[LA], wi0[LA], img[LA];
 #pragma unroll
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
         for (int i = 0; i < LA; ++i) {
             unsigned long long mk = 0;
             for (int t = 0; t < p.KH * p.KW; ++t) {
-                const int hi = hi0[i] + t / p.KW, wi = wi0[i] + t % p.KW;
+                const int hi = hi0[i] + (t / p.KW) * dlh, wi = wi0[i] + (t % p.KW) * dlw;
                 if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) mk |= 1ull << t;
             }
             vmask[i] = mk;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
         if (ci0 < c0) { rs = rs0; ld = p.x_ld[0]; }
         else if (ci0 < c01) { rs = rs1; ld = p.x_ld[1]; ci0 -= c0; }
         else { rs = rs2; ld = p.x_ld[2]; ci0 -= c01; }
-        const int dpix = dy * W + dx;
+        const int dpix = dy * dlh * W + dx * dlw;
         const int cib = (ci0 + kq * 4) * 4;          // byte offset of this thread's 4 channels
         const int ldb = ld * 4;
 #pragma unroll
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
         else { xp = xs2; ld = p.x_ld[2]; ci -= c01; }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int hi = hi0[i] + dy, wi = wi0[i] + dx;
+            const int hi = hi0[i] + dy * dlh, wi = wi0[i] + dx * dlw;
             const bool ok = kok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *reinterpret_cast<const f32x4*>(xp + (long long)(img[i] + hi * W + wi) * ld + ci);

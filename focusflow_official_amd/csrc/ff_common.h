@@ -37,6 +37,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case FF_ACT_RELU: return v > 0.f ? v : 0.f;
         case FF_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case FF_ACT_TANH: return tanhf(v);
+        case FF_ACT_LEAKY: return v > 0.f ? v : 0.1f * v;
         default: return v;
     }
 }

@@ -157,7 +157,7 @@ __global__ void gout_transpose_kernel(const float* __restrict__ g, int g_ld, flo
 // backwarp (ff_pwcnet.py:27-47): bilinear, zeros padding, align_corners=False, validity mask
 // from the warped ones-channel (> 0.999 -> 1 else 0).
 __global__ void backwarp_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ flow, int flow_ld,
-                                float* __restrict__ out, int out_ld, int B, int H, int W, int C) {
+                                float fscale, float* __restrict__ out, int out_ld, int B, int H, int W, int C) {
     const int cg = C >> 2;
     const long long total = (long long)B * H * W * cg;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -165,7 +165,7 @@ __global__ void backwarp_kernel(const float* __restrict__ in, int in_ld, const f
         const long long pix = i / cg;
         const int x = (int)(pix % W), y = (int)((pix / W) % H);
         const long long b = pix / ((long long)W * H);
-        const float fx = flow[pix * flow_ld], fy = flow[pix * flow_ld + 1];
+        const float fx = flow[pix * flow_ld] * fscale, fy = flow[pix * flow_ld + 1] * fscale;   // tenFlow * fltBackwarp
         // grid = linspace(-1+1/W, 1-1/W, W)[x] + flow / ((W-1)/2) ; unnormalise: ((g+1)*W-1)/2
         const float gx = (-1.f + 1.f / W) + x * ((2.f - 2.f / W) / (W - 1)) + fx / ((W - 1.f) / 2.f);
         const float gy = (-1.f + 1.f / H) + y * ((2.f - 2.f / H) / (H - 1)) + fy / ((H - 1.f) / 2.f);
@@ -230,13 +230,13 @@ extern "C" int ff_pwc_gout_transpose(const float* g, int g_ld, float* gt, int gt
     return ff::check_launch("ff_pwc_gout_transpose");
 }
 
-extern "C" int ff_pwc_backwarp(const float* in, int in_ld, const float* flow, int flow_ld, float* out, int out_ld, int B,
-                               int H, int W, int C, void* stream) {
+extern "C" int ff_pwc_backwarp(const float* in, int in_ld, const float* flow, int flow_ld, float flow_scale, float* out,
+                               int out_ld, int B, int H, int W, int C, void* stream) {
     FF_REQUIRE(in && flow && out && B > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "ff_pwc_backwarp: bad shape");
     FF_REQUIRE(in_ld % 4 == 0 && out_ld % 4 == 0 && in_ld >= C && out_ld >= C && flow_ld >= 2 && ff::aligned16(in) && ff::aligned16(out),
                "ff_pwc_backwarp: ld/alignment");
     long long n = ((long long)B * H * W * (C / 4) + 255) / 256;
     if (n > 4096) n = 4096;
-    backwarp_kernel<<<(unsigned)n, 256, 0, static_cast<hipStream_t>(stream)>>>(in, in_ld, flow, flow_ld, out, out_ld, B, H, W, C);
+    backwarp_kernel<<<(unsigned)n, 256, 0, static_cast<hipStream_t>(stream)>>>(in, in_ld, flow, flow_ld, flow_scale, out, out_ld, B, H, W, C);
     return ff::check_launch("ff_pwc_backwarp");
 }

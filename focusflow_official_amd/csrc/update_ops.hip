@@ -170,6 +170,45 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float
     }
 }
 
+// raw NCHW (1 or 3 channels, or a constant) -> NHWC4, no scaling: FF-PWC consumes [0,255] (ff_pwcnet.py:405-410)
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ src, int src_c, float fill, float* __restrict__ dst, int B,
+                                     int HW) {
+    const long long total = (long long)B * HW;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / HW, p = i - b * HW;
+        f32x4 o;
+        if (!src) o = (f32x4){fill, fill, fill, 0.f};
+        else if (src_c == 1) { const float v = src[b * HW + p]; o = (f32x4){v, v, v, 0.f}; }
+        else { const float* q = src + b * 3 * HW + p; o = (f32x4){q[0], q[HW], q[2ll * HW], 0.f}; }
+        *reinterpret_cast<f32x4*>(dst + i * 4) = o;
+    }
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) from NHWC (ld) to NCHW, channel c scaled by mul[c]
+__global__ void resize_bilinear_kernel(const float* __restrict__ src, int ld, int C, int Hi, int Wi, float* __restrict__ dst,
+                                       int B, int Ho, int Wo, float mul0, float mul1) {
+    const long long total = (long long)B * C * Ho * Wo;
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % Wo);
+        long long t = i / Wo;
+        const int y = (int)(t % Ho); t /= Ho;
+        const int c = (int)(t % C);
+        const long long b = t / C;
+        float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* base = src + (b * Hi * Wi) * ld + c;
+        const float v00 = base[((long long)y0 * Wi + x0) * ld], v01 = base[((long long)y0 * Wi + x1) * ld];
+        const float v10 = base[((long long)y1 * Wi + x0) * ld], v11 = base[((long long)y1 * Wi + x1) * ld];
+        const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        dst[i] = v * (c == 0 ? mul0 : (c == 1 ? mul1 : 1.f));
+    }
+}
+
 inline int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -238,4 +277,17 @@ extern "C" int ff_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int 
     FF_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && ld >= C, "ff_nhwc_to_nchw: bad argument");
     nhwc_to_nchw_kernel<<<grid_for((long long)B * H * W * C), 256, 0, static_cast<hipStream_t>(stream)>>>(src, ld, dst, B, H * W, C);
     return ff::check_launch("ff_nhwc_to_nchw");
+}
+
+extern "C" int ff_nchw_to_nhwc4(const float* src, int src_c, float fill, float* dst, int B, int H, int W, void* stream) {
+    FF_REQUIRE(dst && B > 0 && H > 0 && W > 0 && (!src || src_c == 1 || src_c == 3) && ff::aligned16(dst), "ff_nchw_to_nhwc4: bad argument");
+    nchw_to_nhwc4_kernel<<<grid_for((long long)B * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(src, src_c, fill, dst, B, H * W);
+    return ff::check_launch("ff_nchw_to_nhwc4");
+}
+
+extern "C" int ff_resize_bilinear(const float* src_nhwc, int ld, int C, int Hi, int Wi, float* dst_nchw, int B, int Ho, int Wo,
+                                  float mul0, float mul1, void* stream) {
+    FF_REQUIRE(src_nhwc && dst_nchw && B > 0 && C > 0 && ld >= C && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "ff_resize_bilinear: bad argument");
+    resize_bilinear_kernel<<<grid_for((long long)B * C * Ho * Wo), 256, 0, static_cast<hipStream_t>(stream)>>>(src_nhwc, ld, C, Hi, Wi, dst_nchw, B, Ho, Wo, mul0, mul1);
+    return ff::check_launch("ff_resize_bilinear");
 }

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _hip
-from ._hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, FFConvParams  # noqa: F401
+from ._hip import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, FFConvParams  # noqa: F401
 
 Tensor = torch.Tensor
 
@@ -128,15 +128,15 @@ def pack_conv_weight(w_oihw: Tensor, dst: Tensor, cin_pad: int, cout_offset: int
 def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: int, kh: int, kw: int,
            stride: int = 1, pad=(0, 0), act: int = ACT_NONE, out: Optional[Tensor] = None,
            res: Optional[Tensor] = None, act_res: int = ACT_NONE, ch_scale: Optional[Tensor] = None,
-           ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0) -> Tensor:
+           ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0, dilation: int = 1) -> Tensor:
     """Convolution over the channel-concatenation of `xs` (see FFConvParams).  `wpack` is fp32
     [Cout][K] (w_fmt 0) or the split rows of pack_split (w_fmt 1/2)."""
     if isinstance(pad, int):
         pad = (pad, pad)
     x0 = xs[0]
     b, h, w, _ = x0.shape
-    ho = (h + 2 * pad[0] - kh) // stride + 1
-    wo = (w + 2 * pad[1] - kw) // stride + 1
+    ho = (h + 2 * pad[0] - dilation * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * pad[1] - dilation * (kw - 1) - 1) // stride + 1
     if out is None:
         out = empty_nhwc(b, ho, wo, (cout + 3) // 4 * 4, x0)[..., :cout] if cout % 4 else empty_nhwc(b, ho, wo, cout, x0)
     p = FFConvParams()
@@ -163,6 +163,7 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     p.Ho, p.Wo, p.Cout = ho, wo, cout
     p.KH, p.KW, p.stride, p.pad_h, p.pad_w = kh, kw, stride, pad[0], pad[1]
     p.act, p.act_res, p.w_format = act, act_res, w_fmt
+    p.dil_h = p.dil_w = dilation
     assert out.shape[:3] == (b, ho, wo) and out.shape[3] >= cout
     _hip.call("ff_conv2d_fwd", C.byref(p), _stream())
     return out

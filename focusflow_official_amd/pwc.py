@@ -7,10 +7,11 @@ from . import _hip, ops
 from .ops import _ld, _p, _stream, empty_nhwc
 
 
-def _cv_fwd(one, two):
+def _cv_fwd(one, two, out=None):
     b, h, w, c = one.shape
-    out = empty_nhwc(b, h, w, 81, one)
-    _hip.call("ff_pwc_costvolume_fwd", _p(one), _ld(one), _p(two), _ld(two), _p(out), 81, b, h, w, c, _stream())
+    if out is None:
+        out = empty_nhwc(b, h, w, 81, one)
+    _hip.call("ff_pwc_costvolume_fwd", _p(one), _ld(one), _p(two), _ld(two), _p(out), _ld(out), b, h, w, c, _stream())
     return out
 
 
@@ -50,9 +51,11 @@ def FunctionCorrelation(tenOne: torch.Tensor, tenTwo: torch.Tensor) -> torch.Ten
     return _FunctionCorrelation.apply(tenOne, tenTwo)
 
 
-def backwarp(tenInput: torch.Tensor, tenFlow: torch.Tensor) -> torch.Tensor:
-    """NHWC input (B,H,W,C), flow (B,H,W,2) [x,y] in pixels -> warped (B,H,W,C) with validity mask applied."""
+def backwarp(tenInput: torch.Tensor, tenFlow: torch.Tensor, flow_scale: float = 1.0) -> torch.Tensor:
+    """NHWC input (B,H,W,C), flow (B,H,W,>=2) [x,y] in pixels (times flow_scale) -> warped (B,H,W,C) with the
+    validity mask applied."""
     b, h, w, c = tenInput.shape
     out = empty_nhwc(b, h, w, c, tenInput)
-    _hip.call("ff_pwc_backwarp", _p(tenInput), _ld(tenInput), _p(tenFlow), _ld(tenFlow), _p(out), c, b, h, w, c, _stream())
+    _hip.call("ff_pwc_backwarp", _p(tenInput), _ld(tenInput), _p(tenFlow), _ld(tenFlow), float(flow_scale), _p(out), c,
+              b, h, w, c, _stream())
     return out

@@ -1,0 +1,236 @@
+"""FF_PWCNET on the HIP path (core/models/ff-pwcnet/PWCNet_Core/ff_pwcnet.py:113-434) — inference.
+
+Module tree and state_dict keys follow the reference (`netExtractor.{netOne..netSix, mask_net*, fusion1..6}`,
+decoders `netTwo..netSix` with `netUpflow/netUpfeat/netOne..netSix`, `netRefiner.netMain`); the
+nn.Conv2d / nn.ConvTranspose2d objects only hold parameters.  Execution: NHWC fp32 tensors through
+libfocusflow_hip — LeakyReLU in the conv epilogue, dilated convs in the refiner, transposed convs as
+zero-dilation + flipped-weight conv, the 81-channel cost volume and backwarp kernels of pwc.hip.
+
+DenseNet-style `torch.cat([new, old], 1)` (ff_pwcnet.py:331-337) never materialises: each decoder level
+owns ONE wide buffer laid out in the reference's final channel order, every piece padded to a multiple of
+4 channels ([netFiv 32 | netFou 64 | netThr 96 | netTwo 128 | netOne 128 | volume 81+3 | tenOne C | flow 2+2 |
+upfeat 2+2]); a conv reads the suffix starting at its own offset and writes its output slot in front of
+it.  Packed weights get zero columns at the pad channels.
+
+Built: 'point' masks, fusion type 1x1conv / concat, inputs whose H and W are multiples of 64 (the
+reference bilinearly resizes other sizes first; BASELINE config 4 is 448x1024).  Training (backward of
+transposed conv / backwarp) is a later row.
+"""
+import torch
+import torch.nn as nn
+
+from . import _hip, ops, pwc
+from .cce import FusionUnit
+from .ops import ACT_LEAKY, ACT_NONE, _p, _stream
+
+LEVEL_CH = [16, 32, 64, 96, 128, 196]
+BACKWARP_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}
+GROWTH = [("netFiv", 32), ("netFou", 64), ("netThr", 96), ("netTwo", 128), ("netOne", 128)]   # buffer order (front to back)
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class _Packed:
+    """Packed weights of one conv whose input is a padded-piece buffer: `pieces` = [(real, padded), ...]."""
+
+    def __init__(self, conv, pieces, transposed=False):
+        self.conv, self.pieces, self.transposed = conv, pieces, transposed
+        self.key = None
+
+    def get(self):
+        cv = self.conv
+        key = (ops.conv_precision(), cv.weight._version, cv.weight.data_ptr(), cv.bias._version)
+        if key != self.key:
+            w = cv.weight.detach()
+            if self.transposed:   # ConvTranspose2d [Cin][Cout][k][k] -> equivalent forward conv [Cout][Cin][k][k], flipped
+                w = w.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+            co, ci, kh, kw = w.shape
+            cpad = sum(p for _, p in self.pieces)
+            assert ci == sum(r for r, _ in self.pieces)
+            wp = torch.zeros((co, cpad, kh, kw), dtype=torch.float32, device=w.device)
+            src = dst = 0
+            for real, padded in self.pieces:       # scatter real channels to their padded positions (load-time plumbing)
+                wp[:, dst:dst + real] = w[:, src:src + real]
+                src, dst = src + real, dst + padded
+            packed = torch.empty((co, kh * kw * cpad), dtype=torch.float32, device=w.device)
+            ops.pack_conv_weight(wp, packed, cpad, 0)
+            self.fmt = ops.w_format()
+            self.w = ops.pack_split(packed) if self.fmt else packed
+            self.b = cv.bias.detach()
+            self.cout, self.k = co, kh
+            self.key = key
+        return self.w, self.b
+
+    def __call__(self, x, act=ACT_NONE, pad=1, dilation=1, stride=1, out=None, res=None):
+        w, b = self.get()
+        return ops.conv2d([x], w, b, self.cout, self.k, self.k, stride, pad, act=act, out=out, res=res, w_fmt=self.fmt,
+                          dilation=dilation)
+
+
+def _stage(cin, c):
+    return nn.Sequential(nn.Conv2d(cin, c, 3, 2, 1), nn.LeakyReLU(0.1), nn.Conv2d(c, c, 3, 1, 1), nn.LeakyReLU(0.1),
+                         nn.Conv2d(c, c, 3, 1, 1), nn.LeakyReLU(0.1))
+
+
+class Extractor(nn.Module):
+    NAMES = ["netOne", "netTwo", "netThr", "netFou", "netFiv", "netSix"]
+
+    def __init__(self, fusion_type):
+        super().__init__()
+        cin = 3
+        self._packs = {}
+        for lvl, name in enumerate(self.NAMES):
+            c = LEVEL_CH[lvl]
+            for prefix in ("", "mask_"):
+                st = _stage(cin, c)
+                setattr(self, prefix + name, st)
+                self._packs[prefix + name] = [_Packed(st[0], [(cin, _pad4(cin))]), _Packed(st[2], [(c, c)]), _Packed(st[4], [(c, c)])]
+            setattr(self, f"fusion{lvl + 1}", FusionUnit(c, fusion_type, lvl < 5))
+            cin = c
+
+    def run(self, x, mask):
+        feats = []
+        for lvl, name in enumerate(self.NAMES):
+            for i, pk in enumerate(self._packs[name]):
+                x = pk(x, act=ACT_LEAKY, stride=2 if i == 0 else 1)
+            for i, pk in enumerate(self._packs["mask_" + name]):
+                mask = pk(mask, act=ACT_LEAKY, stride=2 if i == 0 else 1)
+            mask, x = getattr(self, f"fusion{lvl + 1}").run(mask, x)
+            feats.append(x)
+        return feats
+
+
+class Decoder(nn.Module):
+    def __init__(self, level):
+        super().__init__()
+        self.level = level
+        cur = {6: 81, 5: 81 + 128 + 4, 4: 81 + 96 + 4, 3: 81 + 64 + 4, 2: 81 + 32 + 4}
+        c_one = {6: 0, 5: 128, 4: 96, 3: 64, 2: 32}[level]
+        self.base = [(81, 84)] + ([(c_one, c_one), (2, 4), (2, 4)] if level < 6 else [])
+        if level < 6:
+            prev_c1 = {5: 0, 4: 128, 3: 96, 2: 64}[level]     # tenOne channels of the PREVIOUS (coarser) level
+            self.netUpflow = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+            self.netUpfeat = nn.ConvTranspose2d(cur[level + 1] + 448, 2, 4, 2, 1)
+            prev_base = [(81, 84)] + ([(prev_c1, prev_c1), (2, 4), (2, 4)] if level + 1 < 6 else [])
+            self._upflow = _Packed(self.netUpflow, [(2, 4)], transposed=True)
+            self._upfeat = _Packed(self.netUpfeat, [(c, c) for _, c in GROWTH] + prev_base, transposed=True)
+        c = cur[level]
+        grown = []
+        self._convs = []
+        for name, co in reversed(GROWTH):          # netOne first
+            conv = nn.Conv2d(c + sum(g for g, _ in grown), co, 3, 1, 1)
+            setattr(self, name, nn.Sequential(conv, nn.LeakyReLU(0.1)))
+            self._convs.append((name, _Packed(conv, grown + self.base)))
+            grown = [(co, co)] + grown
+        self.netSix = nn.Sequential(nn.Conv2d(c + 448, 2, 3, 1, 1))
+        self._six = _Packed(self.netSix[0], grown + self.base)
+        self.width = 448 + sum(p for _, p in self.base)
+
+    def run(self, one, two, prev):
+        """-> dict(tenFlow (B,h,w,4 padded), tenFeat = the level buffer)."""
+        b, h, w, _ = one.shape
+        buf = torch.zeros((b, h, w, self.width), dtype=torch.float32, device=one.device)
+        if prev is None:
+            warped = two
+        else:
+            flow_slot = buf[..., 448 + 84 + one.shape[3]: 448 + 84 + one.shape[3] + 4]
+            feat_slot = buf[..., 448 + 84 + one.shape[3] + 4:]
+            pf, pb = prev["tenFlow"], prev["tenFeat"]
+            hp, wp = pf.shape[1], pf.shape[2]
+            self._upflow(ops.dilate2(pf, 2 * hp - 1, 2 * wp - 1), pad=2, out=flow_slot[..., :2])      # ConvTranspose2d
+            self._upfeat(ops.dilate2(pb, 2 * hp - 1, 2 * wp - 1), pad=2, out=feat_slot[..., :2])
+            warped = pwc.backwarp(two, flow_slot, BACKWARP_SCALE[self.level])
+            ops.act_copy(one, buf[..., 448 + 84: 448 + 84 + one.shape[3]], ACT_NONE)
+        vol = buf[..., 448:448 + 84]
+        pwc._cv_fwd(one, warped, out=vol[..., :81])
+        ops.act_copy(vol, vol, ACT_LEAKY)                     # leaky_relu(volume); the 3 pad channels stay 0
+        off = 448
+        for (name, pk), (_, co) in zip(self._convs, reversed(GROWTH)):
+            pk(buf[..., off:], act=ACT_LEAKY, out=buf[..., off - co:off])
+            off -= co
+        flow4 = torch.zeros((b, h, w, 4), dtype=torch.float32, device=one.device)   # 2 flow channels + 2 zero pads
+        self._six(buf, out=flow4[..., :2])
+        return {"tenFlow": flow4, "tenFeat": buf}
+
+
+class Refiner(nn.Module):
+    def __init__(self):
+        super().__init__()
+        chans = [(565, 128), (128, 128), (128, 128), (128, 96), (96, 64), (64, 32), (32, 2)]
+        self.dils = [1, 2, 4, 8, 16, 1, 1]
+        layers = []
+        for i, ((ci, co), d) in enumerate(zip(chans, self.dils)):
+            layers.append(nn.Conv2d(ci, co, 3, 1, d, d))
+            if i < 6:
+                layers.append(nn.LeakyReLU(0.1))
+        self.netMain = nn.Sequential(*layers)
+        first = [(c, c) for _, c in GROWTH] + [(81, 84), (32, 32), (2, 4), (2, 4)]
+        self._packs = [_Packed(self.netMain[0], first)] + [_Packed(self.netMain[2 * i], [(chans[i][0], chans[i][0])]) for i in range(1, 7)]
+
+    def run(self, feat, flow):
+        x = feat
+        for i, (pk, d) in enumerate(zip(self._packs, self.dils)):
+            if i < 6:
+                x = pk(x, act=ACT_LEAKY, pad=d, dilation=d)
+            else:
+                out4 = torch.zeros_like(flow)
+                pk(x, pad=d, dilation=d, res=flow[..., :2], out=out4[..., :2])   # tenFlow + netRefiner(tenFeat), ff_pwcnet.py:424
+                return out4
+
+
+class FF_PWCNET(nn.Module):
+    """Same constructor and call as the reference: `model(im1, im2, mask1, mask2, test_mode=False)`, images
+    (B,3,H,W) in [0,255] (NOT normalised), masks (B,1,H,W); returns 5 flows (1/4 ... 1/64 resolution, NCHW)
+    or, in test_mode, the 1/4-resolution flow bilinearly resized to the input size."""
+
+    def __init__(self, cfg, pretrain=None, load_pwcnet=None):
+        super().__init__()
+        _hip.load()
+        if cfg.MODEL.FUSION != "parallel":
+            raise NotImplementedError(f"FF_PWCNET only support parallel fusion, but got {cfg.MODEL.FUSION}")
+        if getattr(cfg.TRAIN, "MASK_MODAL", "point") != "point":
+            raise NotImplementedError("FF_PWCNET on HIP: only MASK_MODAL='point' is built")
+        self.fusion_type = cfg.MODEL.FUSION_TYPE
+        self.cfg = cfg
+        self.netExtractor = Extractor(self.fusion_type)
+        self.netTwo, self.netThr, self.netFou, self.netFiv, self.netSix = (Decoder(l) for l in (2, 3, 4, 5, 6))
+        self.netRefiner = Refiner()
+        if pretrain is not None:
+            self.load_state_dict(torch.load(pretrain), strict=True)
+        if load_pwcnet is not None:
+            self.load_state_dict(torch.load(load_pwcnet), strict=False)
+
+    def _nhwc4(self, t, b, h, w, like, fill=0.0):
+        dst = ops.empty_nhwc(b, h, w, 4, like)
+        _hip.call("ff_nchw_to_nhwc4", _p(t.contiguous() if t is not None else None), t.shape[1] if t is not None else 0,
+                  fill, _p(dst), b, h, w, _stream())
+        return dst
+
+    def forward(self, tenOne, tenTwo, mask1, mask2, test_mode=False):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("FF_PWCNET on HIP is inference-only this round: call it under torch.no_grad()")
+        ops._require_gpu(tenOne)
+        b, _, h, w = tenOne.shape
+        if h % 64 or w % 64:
+            raise NotImplementedError("H and W must be multiples of 64 (the reference's pre-resize path is not built)")
+        assert mask1.shape[1] == 1
+        i1, i2 = self._nhwc4(tenOne, b, h, w, tenOne), self._nhwc4(tenTwo, b, h, w, tenOne)
+        m1 = self._nhwc4(mask1, b, h, w, tenOne)                      # 'point': repeat to 3 channels
+        m2 = self._nhwc4(None, b, h, w, tenOne, fill=255.0)           # ones_like(mask1) * 255
+        f1 = self.netExtractor.run(i1, m1)
+        f2 = self.netExtractor.run(i2, m2)
+        est = None
+        flows = []
+        for level, dec in ((6, self.netSix), (5, self.netFiv), (4, self.netFou), (3, self.netThr), (2, self.netTwo)):
+            est = dec.run(f1[level - 1], f2[level - 1], est)
+            if level == 2:
+                est["tenFlow"] = self.netRefiner.run(est["tenFeat"], est["tenFlow"])
+            flows.insert(0, est["tenFlow"])
+        if test_mode:
+            fl = est["tenFlow"][..., :2]
+            out = torch.empty((b, 2, h, w), dtype=torch.float32, device=tenOne.device)
+            _hip.call("ff_resize_bilinear", _p(fl), ops._ld(fl), 2, fl.shape[1], fl.shape[2], _p(out), b, h, w, 1.0, 1.0, _stream())
+            return out
+        return [ops.nhwc_to_nchw(f[..., :2]) for f in flows]

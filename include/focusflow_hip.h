@@ -34,6 +34,7 @@ extern "C" {
 #define FF_ACT_RELU 1
 #define FF_ACT_SIGMOID 2
 #define FF_ACT_TANH 3
+#define FF_ACT_LEAKY 4      /* LeakyReLU(0.1), FF-PWC (ff_pwcnet.py:129 ff.) */
 
 #define FF_MAX_SEG 3
 
@@ -81,6 +82,7 @@ typedef struct FFConvParams {
     int act;                           /* FF_ACT_*, before the residual add             */
     int act_res;                       /* FF_ACT_*, after the residual add              */
     int w_format;                      /* FF_W_*; for the split formats w_gstride counts 4-byte words */
+    int dil_h, dil_w;                  /* dilation (0 = 1): FF-PWC refiner, ff_pwcnet.py:350-364          */
 } FFConvParams;
 
 int ff_conv2d_fwd(const FFConvParams* p, void* stream);
@@ -226,8 +228,8 @@ int ff_pwc_costvolume_bwd(const float* g, int g_ld, const float* other, int othe
                           int grad_ld, int B, int H, int W, int C, void* stream);
 int ff_pwc_gout_transpose(const float* g, int g_ld, float* gt, int gt_ld, int B, int H, int W, void* stream);
 /* out = grid_sample(in, grid + flow, bilinear, zeros, align_corners=False) * (warped ones > 0.999) */
-int ff_pwc_backwarp(const float* in, int in_ld, const float* flow, int flow_ld, float* out, int out_ld,
-                    int B, int H, int W, int C, void* stream);
+int ff_pwc_backwarp(const float* in, int in_ld, const float* flow, int flow_ld, float flow_scale,
+                    float* out, int out_ld, int B, int H, int W, int C, void* stream);
 
 /* ========================================================================
  * Fused sequence loss (core/models/ff-raft/losses/losses.py:18-130: EPELoss, CPCL, MixLoss).
@@ -253,6 +255,13 @@ int ff_epe_metric(const float* pred, const float* flow_gt, const float* vmap, do
  * are caller-provided scratch. */
 int ff_mask_prepare(int mode, const float* mask, const float* image, const float* table, int ks, float* tmp,
                     unsigned int* gmax, float* dst_nhwc4, int B, int H, int W, void* stream);
+
+/* FF-PWC plumbing: raw (unscaled) NCHW -> NHWC4 (ff_pwcnet.py:405-410 consumes [0,255]); and
+ * F.interpolate(bilinear, align_corners=False) NHWC -> NCHW with channels 0/1 multiplied by mul0/mul1
+ * (test_mode output resize + flow rescale, ff_pwcnet.py:427-431). */
+int ff_nchw_to_nhwc4(const float* src_nchw, int src_c, float fill, float* dst_nhwc4, int B, int H, int W, void* stream);
+int ff_resize_bilinear(const float* src_nhwc, int ld, int C, int Hi, int Wi, float* dst_nchw, int B, int Ho, int Wo,
+                       float mul0, float mul1, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,3 +37,136 @@ def backwarp(ten_input: torch.Tensor, ten_flow: torch.Tensor) -> torch.Tensor:
     mask[mask > 0.999] = 1.0
     mask[mask < 1.0] = 0.0
     return out[:, :-1] * mask
+
+
+# ----------------------------------------------------------------------------
+# FF_PWCNET forward (ff_pwcnet.py:113-434), functional restatement over a state_dict with the
+# reference's key names.  PARITY UNPINNED: the reference module cannot be imported here (cv2, cupy
+# and a broken `correlation` import); this follows the source text line by line.
+# ----------------------------------------------------------------------------
+LEVEL_CH = [16, 32, 64, 96, 128, 196]
+EXTRACTOR = ["netOne", "netTwo", "netThr", "netFou", "netFiv", "netSix"]
+BACKWARP_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}      # fltBackwarp, ff_pwcnet.py:276
+DECODER = {6: "netSix", 5: "netFiv", 4: "netFou", 3: "netThr", 2: "netTwo"}
+
+
+def _c(sd, name, x, stride=1, padding=1, dilation=1):
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=stride, padding=padding, dilation=dilation)
+
+
+def _lrelu(x):
+    return F.leaky_relu(x, 0.1)
+
+
+def pwc_extractor(sd, p, x, mask, fusion_type="1x1conv"):
+    """ff_pwcnet.py:237-264."""
+    feats = []
+    for lvl, name in enumerate(EXTRACTOR):
+        for branch in ("", "mask_"):
+            t = x if branch == "" else mask
+            t = _lrelu(_c(sd, f"{p}.{branch}{name}.0", t, 2))
+            t = _lrelu(_c(sd, f"{p}.{branch}{name}.2", t))
+            t = _lrelu(_c(sd, f"{p}.{branch}{name}.4", t))
+            if branch == "":
+                x = t
+            else:
+                mask = t
+        fu = f"{p}.fusion{lvl + 1}"
+        x_new = x + F.conv2d(mask, sd[fu + ".mask2img.conv.weight"], sd[fu + ".mask2img.conv.bias"])
+        if lvl < 5:   # fusion6 is uni-directional
+            mask = mask + F.conv2d(x, sd[fu + ".img2mask.conv.weight"], sd[fu + ".img2mask.conv.bias"])
+        x = x_new
+        feats.append(x)
+    return feats
+
+
+def pwc_decoder(sd, p, level, one, two, prev):
+    """ff_pwcnet.py:307-343."""
+    if prev is None:
+        feat = _lrelu(cost_volume(one, two))
+        flow = None
+    else:
+        flow = F.conv_transpose2d(prev["tenFlow"], sd[p + ".netUpflow.weight"], sd[p + ".netUpflow.bias"], stride=2, padding=1)
+        upfeat = F.conv_transpose2d(prev["tenFeat"], sd[p + ".netUpfeat.weight"], sd[p + ".netUpfeat.bias"], stride=2, padding=1)
+        vol = _lrelu(cost_volume(one, backwarp(two, flow * BACKWARP_SCALE[level])))
+        feat = torch.cat([vol, one, flow, upfeat], 1)
+    for name in ("netOne", "netTwo", "netThr", "netFou", "netFiv"):
+        feat = torch.cat([_lrelu(_c(sd, f"{p}.{name}.0", feat)), feat], 1)
+    return {"tenFlow": _c(sd, p + ".netSix.0", feat), "tenFeat": feat}
+
+
+def pwc_refiner(sd, p, feat):
+    """ff_pwcnet.py:346-370."""
+    x = feat
+    for idx, dil in zip((0, 2, 4, 8, 10), (1, 2, 4, 16, 1)):
+        pass
+    dils = [1, 2, 4, 8, 16, 1, 1]
+    for i, d in enumerate(dils):
+        x = _c(sd, f"{p}.netMain.{2 * i}", x, 1, d, d)
+        if i < 6:
+            x = _lrelu(x)
+    return x
+
+
+def ffpwc_forward(sd, image1, image2, mask1, mask2=None, test_mode=False, mask_channel=3):
+    """ff_pwcnet.py:405-433 for inputs whose H, W are multiples of 64 (no resize) and 'point' masks.
+    Inputs stay in [0,255] (FF-PWC does not normalise)."""
+    b, _, h, w = image1.shape
+    assert h % 64 == 0 and w % 64 == 0
+    m1 = mask1.repeat(1, mask_channel, 1, 1)
+    m2 = torch.ones_like(m1) * 255
+    f1 = pwc_extractor(sd, "netExtractor", image1, m1)
+    f2 = pwc_extractor(sd, "netExtractor", image2, m2)
+    est = None
+    flows = []
+    for level in (6, 5, 4, 3, 2):
+        est = pwc_decoder(sd, DECODER[level], level, f1[level - 1], f2[level - 1], est)
+        if level == 2:
+            est["tenFlow"] = est["tenFlow"] + pwc_refiner(sd, "netRefiner", est["tenFeat"])
+        flows.insert(0, est["tenFlow"])
+    if test_mode:
+        out = F.interpolate(est["tenFlow"], size=(h, w), mode="bilinear", align_corners=False)
+        return out          # scale factors are 1 when no resize happened
+    return flows
+
+
+def pwc_state_spec():
+    """(key, shape) list of FF_PWCNET's state_dict (1x1conv fusion), derived from ff_pwcnet.py:123-370."""
+    spec = []
+
+    def conv(name, co, ci, k):
+        spec.append((name + ".weight", (co, ci, k, k)))
+        spec.append((name + ".bias", (co,)))
+
+    def extractor_stage(prefix, cin, c):
+        for i, (a, bb) in enumerate(((cin, c), (c, c), (c, c))):
+            conv(f"netExtractor.{prefix}.{2 * i}", bb, a, 3)
+
+    cin = 3
+    order = []
+    for lvl, name in enumerate(EXTRACTOR):
+        order.append((name, cin, LEVEL_CH[lvl]))
+        cin = LEVEL_CH[lvl]
+    # registration order in the reference: netOne, mask_netOne, fusion1, netTwo, ...
+    for lvl, (name, ci, c) in enumerate(order):
+        extractor_stage(name, ci, c)
+        extractor_stage("mask_" + name, ci, c)
+        conv(f"netExtractor.fusion{lvl + 1}.mask2img.conv", c, c, 1)
+        if lvl < 5:
+            conv(f"netExtractor.fusion{lvl + 1}.img2mask.conv", c, c, 1)
+    cur = {6: 81, 5: 81 + 128 + 4, 4: 81 + 96 + 4, 3: 81 + 64 + 4, 2: 81 + 32 + 4}
+    for level in (2, 3, 4, 5, 6):     # self.netTwo ... self.netSix
+        p = DECODER[level]
+        if level < 6:
+            spec.append((p + ".netUpflow.weight", (2, 2, 4, 4)))
+            spec.append((p + ".netUpflow.bias", (2,)))
+            spec.append((p + ".netUpfeat.weight", (cur[level + 1] + 448, 2, 4, 4)))
+            spec.append((p + ".netUpfeat.bias", (2,)))
+        c = cur[level]
+        for name, add, co in (("netOne", 0, 128), ("netTwo", 128, 128), ("netThr", 256, 96), ("netFou", 352, 64),
+                              ("netFiv", 416, 32), ("netSix", 448, 2)):
+            conv(f"{p}.{name}.0", co, c + add, 3)
+    chans = [(565, 128), (128, 128), (128, 128), (128, 96), (96, 64), (64, 32), (32, 2)]
+    for i, (ci, co) in enumerate(chans):
+        conv(f"netRefiner.netMain.{2 * i}", co, ci, 3)
+    return spec

@@ -73,3 +73,56 @@ def test_backwarp(b, c, h, w, scale):
     diff = (got - ref).abs().amax(1)
     bad = (diff > 1e-4).float().mean().item()
     assert bad < 2e-3, f"{bad * 100:.3f}% of pixels differ"
+
+
+def _pwc_weights():
+    """Deterministic weights, tamed for unnormalised [0,255] inputs: the two stem convs absorb 1/255 and the
+    flow heads are damped so warps stay inside the image."""
+    from oracle.weights import det_tensor
+    sd = {}
+    for k, s in pwc_ref.pwc_state_spec():
+        t = det_tensor("pwc." + k, s)
+        if k in ("netExtractor.netOne.0.weight", "netExtractor.mask_netOne.0.weight"):
+            t = t / 255.0
+        if ".netSix.0." in k or k.startswith("netRefiner.netMain.12") or "netUpf" in k:
+            t = t * 0.1
+        sd[k] = t
+    return sd
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_ffpwcnet_forward_matches_oracle(precision):
+    """FF_PWCNET (ff_pwcnet.py:405-433) end to end on HIP vs the CPU restatement (parity unpinned: the
+    reference module cannot run in this image)."""
+    from argparse import Namespace
+    from focusflow_official_amd import ops as _ops
+    from focusflow_official_amd.pwcnet import FF_PWCNET
+    cfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"), MODEL=Namespace(FUSION="parallel", FUSION_TYPE="1x1conv"))
+    sd = _pwc_weights()
+    m = FF_PWCNET(cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    g = torch.Generator().manual_seed(4)
+    base = torch.rand(2, 3, 36, 52, generator=g)
+    i1 = torch.nn.functional.interpolate(base, size=(128, 192), mode="bilinear", align_corners=False) * 255
+    i2 = torch.roll(i1, shifts=(2, -3), dims=(2, 3))
+    m1 = (torch.rand(2, 1, 128, 192, generator=g) < 0.02).float() * 255
+    with torch.no_grad():
+        ref = pwc_ref.ffpwc_forward(sd, i1, i2, m1)
+        ref_full = pwc_ref.ffpwc_forward(sd, i1, i2, m1, test_mode=True)
+    prev = _ops.conv_precision()
+    _ops.set_conv_precision(precision)
+    try:
+        with torch.no_grad():
+            got = m(i1.to(DEV), i2.to(DEV), m1.to(DEV), torch.zeros_like(m1).to(DEV))
+            got_full = m(i1.to(DEV), i2.to(DEV), m1.to(DEV), torch.zeros_like(m1).to(DEV), test_mode=True)
+    finally:
+        _ops.set_conv_precision(prev)
+    assert len(got) == 5
+    for lvl, (a, r) in enumerate(zip(got, ref)):
+        assert a.shape == r.shape
+        close(a.cpu(), r, tol=2e-4, what=f"flow level {lvl + 2}")
+    close(got_full.cpu(), ref_full, tol=2e-4, what="test_mode flow")
+    assert float(ref_full.abs().max()) > 0.05, "degenerate test: flow is ~0"
+    with pytest.raises(NotImplementedError):
+        m(i1[..., :100, :].to(DEV), i2[..., :100, :].to(DEV), m1[..., :100, :].to(DEV), m1[..., :100, :].to(DEV))
