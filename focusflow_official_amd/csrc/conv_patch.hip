@@ -1,0 +1,269 @@
+// Patch-stationary fp16x3 convolution for stride-1 "same" convolutions (3x3, 1x5, 5x1, 7x7, 1x1).
+//
+// conv_split.hip re-reads and re-splits every activation once per kernel tap (9x for 3x3) and pays a
+// global-load round trip per 32-k chunk.  Here a block owns an 8x16 tile of output pixels and, per
+// 32-channel chunk of the input, stages the tile PLUS ITS HALO ((8+KH-1) x (16+KW-1) pixels) in LDS once —
+// already converted to the split format [x0: 32 fp16 | x1: 32 fp16] — and then walks the KH*KW taps over
+// that stationary patch: a tap only changes which LDS rows a lane reads.  Per tap the only new bytes are
+// the 64x32 weight chunk (8 KB, L2-resident, double-buffered).  Activation traffic and conversion work
+// drop by KH*KW, address arithmetic is precomputed once per block (buffer loads, hardware zero padding).
+//
+// Block = 256 threads = 4 waves (2 x 2): wave (wm, wn) computes output rows 4wm..4wm+3 of the tile
+// (two 32-pixel MFMA tiles: rows 2t, 2t+1 x 16 columns) for 32 of the block's 64 output channels.
+#include <algorithm>
+#include <cstdlib>
+#include "ff_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 8, TW = 16, BN = 64, ROWB = 128;
+constexpr int MAXP = 6;     // patch float4 items per thread: ceil((TH+6)*(TW+6)*8 / 256) = 10 for 7x7 -> handled by loop bound
+
+struct PArgs {
+    FFConvParams p;
+    int Cin, nci;            // channels, 32-channel chunks
+    int tiles_x, tiles_y, n_tiles;
+    long long w_row_bytes;
+};
+
+__device__ __forceinline__ int swz(int row, int piece) { return piece ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 a = (_Float16)v[j];
+        h0[j] = a;
+        h1[j] = (_Float16)((v[j] - (float)a) * 2048.f);
+    }
+}
+
+template <int TERMS, int NITEM>   // NITEM = patch items (float4) per thread
+__global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FFConvParams& p = a.p;
+    const int KH = p.KH, KW = p.KW, PH = TH + KH - 1, PW = TW + KW - 1, NPIX = PH * PW;
+    char* sP = smem;                          // [NPIX][128 B] patch, split format
+    char* sW = smem + ((NPIX * ROWB + 255) & ~255);   // [2][BN][128 B] weights of one (tap, ci-chunk)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = p.H, W = p.W;
+    int bid = blockIdx.x;
+    const int nt = bid % a.n_tiles; bid /= a.n_tiles;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int bimg = bid / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+
+    // buffer resources
+    const long long pix_total = (long long)p.B * H * W;
+    __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[0]), 0, (int)(pix_total * p.x_ld[0] * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[1] ? p.x[1] : p.x[0]), 0, p.x[1] ? (int)(pix_total * p.x_ld[1] * 4) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[2] ? p.x[2] : p.x[0]), 0, p.x[2] ? (int)(pix_total * p.x_ld[2] * 4) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((long long)p.Cout * a.w_row_bytes), 0x00020000);
+    const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
+
+    // patch items of this thread: item = tid + 256*i -> (patch pixel, 16-byte channel group kq)
+    int ppix[NITEM];        // image pixel index of the patch pixel, or -1 (outside the image / no item)
+    int prow[NITEM];        // LDS row (patch pixel)
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+        const int item = tid + 256 * i;
+        const int px = item >> 3;
+        ppix[i] = -1;
+        prow[i] = px;
+        if (px < NPIX) {
+            const int yy = y0 - p.pad_h + px / PW, xx = x0 - p.pad_w + px % PW;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ppix[i] = (bimg * H + yy) * W + xx;
+        }
+    }
+    const int kq = tid & 7;
+    // weight pieces of this thread: BN rows x 8 pieces = 512 -> 2 per thread
+    int woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        woff[i] = n < p.Cout ? (int)(n * a.w_row_bytes) + kq * 16 : 0x7fffffff;
+    }
+
+    f32x4 rp[NITEM], rw[2];
+    auto load_patch = [&](int c) {          // 32-channel chunk c of the concatenated input (block-uniform)
+        int ci0 = c * 32;
+        __amdgpu_buffer_rsrc_t rs;
+        int ldb;
+        if (ci0 < c0) { rs = rs0; ldb = p.x_ld[0] * 4; }
+        else if (ci0 < c01) { rs = rs1; ldb = p.x_ld[1] * 4; ci0 -= c0; }
+        else { rs = rs2; ldb = p.x_ld[2] * 4; ci0 -= c01; }
+        const int cib = (ci0 + kq * 4) * 4;
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            const int off = ppix[i] >= 0 ? ppix[i] * ldb + cib : 0x7fffffff;     // out of range -> zeros
+            rp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        }
+    };
+    auto store_patch = [&]() {
+        const int pc = kq >> 1, half = (kq & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            const int row = prow[i];
+            if (row < NPIX) {
+                f16x4 h0, h1;
+                split4(rp[i], h0, h1);
+                *reinterpret_cast<f16x4*>(sP + row * ROWB + swz(row, pc) * 16 + half) = h0;
+                if (TERMS == 3) *reinterpret_cast<f16x4*>(sP + row * ROWB + swz(row, 4 + pc) * 16 + half) = h1;
+            }
+        }
+    };
+    auto load_w = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[i], kc * ROWB, 0));
+    };
+    auto store_w = [&](int buf) {
+        char* d = sW + buf * BN * ROWB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<f32x4*>(d + row * ROWB + swz(row, kq) * 16) = rw[i];
+        }
+    };
+
+    f32x16 acc[2], accx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
+
+    // lane -> output pixel of m-tile t: rows 2t (lanes 0-15) and 2t+1 (lanes 16-31), columns 0..15
+    const int li = lane & 31, lh = lane >> 5;
+    const int lrow = li >> 4, lcol = li & 15;
+    const int ntaps = KH * KW;
+    const int brow = wn * 32 + li;           // weight LDS row of this lane's output channel
+
+    load_patch(0);
+    load_w(0);
+    int wbuf = 0;
+    for (int c = 0; c < a.nci; ++c) {
+        __syncthreads();                     // previous chunk's taps are done with sP
+        store_patch();
+        store_w(wbuf);
+        __syncthreads();
+        if (c + 1 < a.nci) load_patch(c + 1);        // lands during this chunk's taps
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const bool last = tap + 1 == ntaps;
+            const int next_kc = last ? (c + 1) : (tap + 1) * a.nci + c;   // K order = (tap, ci): chunk index tap*nci + c
+            if (!(last && c + 1 == a.nci)) load_w(last ? c + 1 : next_kc);
+            const int dy = tap / KW, dx = tap - dy * KW;
+            const char* cW = sW + wbuf * BN * ROWB;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 a0[2], a1[2], b0, b1;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = ((wm * 2 + t) * 2 + lrow + dy) * PW + lcol + dx;
+                    a0[t] = *reinterpret_cast<const f16x8*>(sP + row * ROWB + swz(row, 2 * s + lh) * 16);
+                    if (TERMS == 3) a1[t] = *reinterpret_cast<const f16x8*>(sP + row * ROWB + swz(row, 4 + 2 * s + lh) * 16);
+                }
+                b0 = *reinterpret_cast<const f16x8*>(cW + brow * ROWB + swz(brow, 2 * s + lh) * 16);
+                if (TERMS == 3) b1 = *reinterpret_cast<const f16x8*>(cW + brow * ROWB + swz(brow, 4 + 2 * s + lh) * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b0, acc[t], 0, 0, 0);
+                    if (TERMS == 3) {
+                        accx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b1, accx[t], 0, 0, 0);
+                        accx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[t], b0, accx[t], 0, 0, 0);
+                    }
+                }
+            }
+            if (!last) {                      // next tap's weights go to the other buffer
+                store_w(wbuf ^ 1);
+                __syncthreads();
+                wbuf ^= 1;
+            }
+        }
+        wbuf ^= 1;                            // the chunk-boundary store_w(wbuf) above targets the free buffer
+    }
+
+    // epilogue: acc[t][r]: column n = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*lh = pixel index within the m-tile
+    const int n = n0 + wn * 32 + li;
+    if (n < p.Cout) {
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float cs = p.ch_scale ? p.ch_scale[n] : 1.f;
+        const float ct = p.ch_scale ? p.ch_shift[n] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;        // 0..31: row = pi>>4, col = pi&15
+                const int y = y0 + (wm * 2 + t) * 2 + (pi >> 4), x = x0 + (pi & 15);
+                if (y >= H || x >= W) continue;
+                const long long m = ((long long)bimg * H + y) * W + x;
+                float v = acc[t][r];
+                if (TERMS == 3) v += accx[t][r] * (1.f / 2048.f);
+                v += bias;
+                v *= p.out_scale;
+                if (p.ch_scale) v = v * cs + ct;
+                v = ff::apply_act(v, p.act);
+                if (p.res) v = ff::apply_act(v + p.res[m * p.res_ld + n], p.act_res);
+                p.y[m * p.y_ld + n] = v;
+            }
+        }
+    }
+}
+
+template <int TERMS, int NITEM>
+int launch(const PArgs& a, size_t lds, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<TERMS, NITEM>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        once = true;
+    }
+    const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    conv_patch_kernel<TERMS, NITEM><<<(unsigned)blocks, 256, lds, s>>>(a);
+    return ff::check_launch("ff_conv2d_fwd(patch)");
+}
+
+}  // namespace
+
+namespace ff {
+// returns FF_OK if launched, 1 if the shape is not eligible (caller falls back to conv_split)
+int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
+    static const bool enabled = !getenv("FF_NO_PATCH_CONV");
+    static const bool dbg = getenv("FF_DEBUG_DISPATCH") != nullptr;
+    if (dbg) fprintf(stderr, "[ff] patch? en=%d stride=%d dil=%d,%d groups=%d k=%dx%d pad=%d,%d cin=%d xc=%d,%d,%d fmt=%d\n", (int)enabled, p.stride,
+                     p.dil_h, p.dil_w, p.groups, p.KH, p.KW, p.pad_h, p.pad_w, cin, p.x_c[0], p.x_c[1], p.x_c[2], p.w_format);
+    if (!enabled) return 1;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
+    if (p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1) return 1;
+    if (p.KH % 2 == 0 || p.KW % 2 == 0 || p.pad_h != p.KH / 2 || p.pad_w != p.KW / 2 || p.KH > 7 || p.KW > 7) return 1;
+    if (p.KH * p.KW < 3) return 1;          // 1x1: nothing to reuse, the plain kernel is as good
+    if (cin % 32) return 1;
+    long long max_bytes = 0;
+    for (int i = 0; i < FF_MAX_SEG; ++i) {
+        if (p.x_c[i] % 32) return 1;
+        if (p.x_c[i]) max_bytes = std::max(max_bytes, (long long)p.B * p.H * p.W * p.x_ld[i] * 4);
+    }
+    PArgs a;
+    a.p = p;
+    a.Cin = cin;
+    a.nci = cin / 32;
+    a.tiles_x = (p.W + TW - 1) / TW;
+    a.tiles_y = (p.H + TH - 1) / TH;
+    a.n_tiles = (p.Cout + BN - 1) / BN;
+    a.w_row_bytes = (long long)((p.KH * p.KW * cin + 31) / 32) * ROWB;
+    max_bytes = std::max(max_bytes, (long long)p.Cout * a.w_row_bytes);
+    if (max_bytes >= (1ll << 31)) return 1;
+    const int npix = (TH + p.KH - 1) * (TW + p.KW - 1);
+    const size_t lds = ((npix * ROWB + 255) & ~255) + 2 * BN * ROWB;
+    const int nitem = (npix * 8 + 255) / 256;
+    const bool t3 = p.w_format == FF_W_F16X3;
+    if (nitem <= 6) return t3 ? launch<3, 6>(a, lds, s) : launch<1, 6>(a, lds, s);
+    if (nitem <= 10) return t3 ? launch<3, 10>(a, lds, s) : launch<1, 10>(a, lds, s);
+    return 1;
+}
+}  // namespace ff

@@ -373,6 +373,8 @@ __global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __res
 namespace ff {
 // called from ff_conv2d_fwd after argument validation
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s) {
+    const int rc = conv2d_fwd_patch(p, cin, s);      // stride-1 "same" convs: patch-stationary kernel
+    if (rc != 1) return rc;
     KernArgs a;
     a.p = p;
     a.M = M;
