@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TH = 8, TW = 16, BN = 64, ROWB = 128;
+constexpr int TW = 16, BN = 64, ROWB = 128;   // tile height TH = 4*TM (template): 8 rows, or 4 for small problems
 constexpr int MAXP = 6;     // patch float4 items per thread: ceil((TH+6)*(TW+6)*8 / 256) = 10 for 7x7 -> handled by loop bound
 
 struct PArgs {
@@ -42,8 +42,9 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
     }
 }
 
-template <int TERMS, int NITEM>   // NITEM = patch items (float4) per thread
+template <int TERMS, int NITEM, int TM>   // NITEM = patch items (float4) per thread; TM = 32-pixel MFMA tiles per wave
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
+    constexpr int TH = 4 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FFConvParams& p = a.p;
     const int KH = p.KH, KW = p.KW, PH = TH + KH - 1, PW = TW + KW - 1, NPIX = PH * PW;
@@ -133,9 +134,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
         }
     };
 
-    f32x16 acc[2], accx[2];
+    f32x16 acc[TM], accx[TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
 
@@ -162,17 +163,17 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
             const char* cW = sW + wbuf * BN * ROWB;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                f16x8 a0[2], a1[2], b0, b1;
+                f16x8 a0[TM], a1[TM], b0, b1;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int row = ((wm * 2 + t) * 2 + lrow + dy) * PW + lcol + dx;
+                for (int t = 0; t < TM; ++t) {
+                    const int row = ((wm * TM + t) * 2 + lrow + dy) * PW + lcol + dx;
                     a0[t] = *reinterpret_cast<const f16x8*>(sP + row * ROWB + swz(row, 2 * s + lh) * 16);
                     if (TERMS == 3) a1[t] = *reinterpret_cast<const f16x8*>(sP + row * ROWB + swz(row, 4 + 2 * s + lh) * 16);
                 }
                 b0 = *reinterpret_cast<const f16x8*>(cW + brow * ROWB + swz(brow, 2 * s + lh) * 16);
                 if (TERMS == 3) b1 = *reinterpret_cast<const f16x8*>(cW + brow * ROWB + swz(brow, 4 + 2 * s + lh) * 16);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < TM; ++t) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b0, acc[t], 0, 0, 0);
                     if (TERMS == 3) {
                         accx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b1, accx[t], 0, 0, 0);
@@ -196,11 +197,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
         const float cs = p.ch_scale ? p.ch_scale[n] : 1.f;
         const float ct = p.ch_scale ? p.ch_shift[n] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < TM; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;        // 0..31: row = pi>>4, col = pi&15
-                const int y = y0 + (wm * 2 + t) * 2 + (pi >> 4), x = x0 + (pi & 15);
+                const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + (pi & 15);
                 if (y >= H || x >= W) continue;
                 const long long m = ((long long)bimg * H + y) * W + x;
                 float v = acc[t][r];
@@ -216,15 +217,15 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
     }
 }
 
-template <int TERMS, int NITEM>
+template <int TERMS, int NITEM, int TM>
 int launch(const PArgs& a, size_t lds, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<TERMS, NITEM>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<TERMS, NITEM, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         once = true;
     }
     const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
-    conv_patch_kernel<TERMS, NITEM><<<(unsigned)blocks, 256, lds, s>>>(a);
+    conv_patch_kernel<TERMS, NITEM, TM><<<(unsigned)blocks, 256, lds, s>>>(a);
     return ff::check_launch("ff_conv2d_fwd(patch)");
 }
 
@@ -253,17 +254,26 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     a.Cin = cin;
     a.nci = cin / 32;
     a.tiles_x = (p.W + TW - 1) / TW;
-    a.tiles_y = (p.H + TH - 1) / TH;
     a.n_tiles = (p.Cout + BN - 1) / BN;
     a.w_row_bytes = (long long)((p.KH * p.KW * cin + 31) / 32) * ROWB;
     max_bytes = std::max(max_bytes, (long long)p.Cout * a.w_row_bytes);
     if (max_bytes >= (1ll << 31)) return 1;
-    const int npix = (TH + p.KH - 1) * (TW + p.KW - 1);
+    // 8x16 tiles unless that leaves the chip under-filled (update-block convs at 1/8 resolution): then 4x16
+    static const int force_th = getenv("FF_PATCH_TH") ? atoi(getenv("FF_PATCH_TH")) : 0;
+    const long long blocks8 = (long long)p.B * ((p.H + 7) / 8) * a.tiles_x * a.n_tiles;
+    const int th = force_th ? force_th : (blocks8 < 512 ? 4 : 8);
+    a.tiles_y = (p.H + th - 1) / th;
+    const int npix = (th + p.KH - 1) * (TW + p.KW - 1);
     const size_t lds = ((npix * ROWB + 255) & ~255) + 2 * BN * ROWB;
     const int nitem = (npix * 8 + 255) / 256;
     const bool t3 = p.w_format == FF_W_F16X3;
-    if (nitem <= 6) return t3 ? launch<3, 6>(a, lds, s) : launch<1, 6>(a, lds, s);
-    if (nitem <= 10) return t3 ? launch<3, 10>(a, lds, s) : launch<1, 10>(a, lds, s);
+    if (th == 8) {
+        if (nitem <= 6) return t3 ? launch<3, 6, 2>(a, lds, s) : launch<1, 6, 2>(a, lds, s);
+        if (nitem <= 10) return t3 ? launch<3, 10, 2>(a, lds, s) : launch<1, 10, 2>(a, lds, s);
+    } else {
+        if (nitem <= 4) return t3 ? launch<3, 4, 1>(a, lds, s) : launch<1, 4, 1>(a, lds, s);
+        if (nitem <= 8) return t3 ? launch<3, 8, 1>(a, lds, s) : launch<1, 8, 1>(a, lds, s);
+    }
     return 1;
 }
 }  // namespace ff
