@@ -42,7 +42,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
     }
 }
 
-template <int TERMS, int NITEM, int TM>   // NITEM = patch items (float4) per thread; TM = 32-pixel MFMA tiles per wave
+template <int TERMS, int NITEM, int TM, int ABL = 0>   // NITEM = patch items per thread; TM = MFMA tiles per wave; ABL = timing-only ablation
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
     constexpr int TH = 4 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
         for (int tap = 0; tap < ntaps; ++tap) {
             const bool last = tap + 1 == ntaps;
             const int next_kc = last ? (c + 1) : (tap + 1) * a.nci + c;   // K order = (tap, ci): chunk index tap*nci + c
-            if (!(last && c + 1 == a.nci)) load_w(last ? c + 1 : next_kc);
+            if (!(last && c + 1 == a.nci) && ABL != 1 && ABL != 2) load_w(last ? c + 1 : next_kc);
             const int dy = tap / KW, dx = tap - dy * KW;
             const char* cW = sW + wbuf * BN * ROWB;
 #pragma unroll
@@ -174,6 +174,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
                 if (TERMS == 3) b1 = *reinterpret_cast<const f16x8*>(cW + brow * ROWB + swz(brow, 4 + 2 * s + lh) * 16);
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
+                    if constexpr (ABL == 3) {      // no MFMA: keep operands alive
+                        asm volatile("" :: "v"(a0[t]), "v"(b0));
+                        if (TERMS == 3) asm volatile("" :: "v"(a1[t]), "v"(b1));
+                        continue;
+                    }
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b0, acc[t], 0, 0, 0);
                     if (TERMS == 3) {
                         accx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b1, accx[t], 0, 0, 0);
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
                     }
                 }
             }
-            if (!last) {                      // next tap's weights go to the other buffer
+            if (!last && ABL != 2) {          // next tap's weights go to the other buffer
                 store_w(wbuf ^ 1);
                 __syncthreads();
                 wbuf ^= 1;
@@ -217,15 +222,15 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
     }
 }
 
-template <int TERMS, int NITEM, int TM>
+template <int TERMS, int NITEM, int TM, int ABL = 0>
 int launch(const PArgs& a, size_t lds, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<TERMS, NITEM, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<TERMS, NITEM, TM, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         once = true;
     }
     const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
-    conv_patch_kernel<TERMS, NITEM, TM><<<(unsigned)blocks, 256, lds, s>>>(a);
+    conv_patch_kernel<TERMS, NITEM, TM, ABL><<<(unsigned)blocks, 256, lds, s>>>(a);
     return ff::check_launch("ff_conv2d_fwd(patch)");
 }
 
@@ -267,6 +272,12 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     const size_t lds = ((npix * ROWB + 255) & ~255) + 2 * BN * ROWB;
     const int nitem = (npix * 8 + 255) / 256;
     const bool t3 = p.w_format == FF_W_F16X3;
+    static const int abl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;   // timing experiments (wrong results!)
+    if (abl && th == 8 && nitem <= 6 && t3) {
+        if (abl == 1) return launch<3, 6, 2, 1>(a, lds, s);
+        if (abl == 2) return launch<3, 6, 2, 2>(a, lds, s);
+        return launch<3, 6, 2, 3>(a, lds, s);
+    }
     if (th == 8) {
         if (nitem <= 6) return t3 ? launch<3, 6, 2>(a, lds, s) : launch<1, 6, 2>(a, lds, s);
         if (nitem <= 10) return t3 ? launch<3, 10, 2>(a, lds, s) : launch<1, 10, 2>(a, lds, s);
