@@ -6,7 +6,7 @@ but the modules below only HOLD parameters: ``nn.Conv2d`` / ``nn.BatchNorm2d``
 instances are never called.  The forward is a sequence of libfocusflow_hip
 launches on NHWC fp32 tensors.
 """
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn

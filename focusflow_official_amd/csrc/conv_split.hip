@@ -373,7 +373,9 @@ __global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __res
 namespace ff {
 // called from ff_conv2d_fwd after argument validation
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s) {
-    const int rc = conv2d_fwd_patch(p, cin, s);      // stride-1 "same" convs: patch-stationary kernel
+    int rc = conv2d_fwd_ws(p, cin, s);               // stride-1 "same" convs: wave-specialised patch kernel
+    if (rc != 1) return rc;
+    rc = conv2d_fwd_patch(p, cin, s);                // same shapes, single-role waves (small grids / FF_WS_CONV=0)
     if (rc != 1) return rc;
     KernArgs a;
     a.p = p;

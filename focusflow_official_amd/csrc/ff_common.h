@@ -30,6 +30,7 @@ inline int check_launch(const char* what) {
 
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s);  // conv_split.hip
 int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s);         // conv_patch.hip; 1 = not eligible
+int conv2d_fwd_ws(const FFConvParams& p, int cin, hipStream_t s);            // conv_ws.hip (wave-specialised); 1 = not eligible
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -113,6 +113,20 @@ def test_conv2d(ops, case, fmt):
     close(nchw(out), ref, rtol=2e-5 if fmt != "f16" else 4e-3, what=f"conv2d[{fmt}]")
 
 
+def test_conv2d_wave_specialised_kernel_opt_in():
+    """conv_ws.hip (persistent, wave-specialised) is opt-in via FF_WS_CONV=1, read once per process: run the
+    half-precision conv cases through it in ONE child process and require the same tolerances."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FF_WS_CONV="1", FF_DEBUG_DISPATCH="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.abspath(__file__), "-k", "test_conv2d and not fp32 and not wave_specialised"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_conv_epilogue_scale_shift_and_outscale(ops):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, 64, 16, 24, generator=g)
