@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import fn, ops
-from .ops import ACT_NONE, ACT_RELU
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 EPS = 1e-5
 
@@ -43,15 +43,17 @@ class PackedConv:
 
     def get(self):
         key = (ops.conv_precision(),) + tuple(
-            (c.weight._version, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()) for c in self.convs)
+            (c.weight._version, c.weight.data_ptr()) + ((c.bias._version, c.bias.data_ptr()) if c.bias is not None else ())
+            for c in self.convs)
         if key != self._key:
             dev = self.convs[0].weight.device
             self.w = torch.empty((self.cout, self.kh * self.kw * self.cin_pad), dtype=torch.float32, device=dev)
-            self.b = torch.empty(self.cout, dtype=torch.float32, device=dev)
+            self.b = torch.zeros(self.cout, dtype=torch.float32, device=dev)   # bias=False convs (SA) keep zeros
             off = 0
             for c in self.convs:
                 ops.pack_conv_weight(c.weight.detach(), self.w, self.cin_pad, off)
-                self.b[off:off + c.out_channels].copy_(c.bias.detach())  # device memcpy
+                if c.bias is not None:
+                    self.b[off:off + c.out_channels].copy_(c.bias.detach())  # device memcpy
                 off += c.out_channels
             self.fmt = ops.w_format()
             if self.fmt != 0:
@@ -118,8 +120,52 @@ class _FusionConv(nn.Module):
         self._p = PackedConv([self.conv])
 
 
+class _SA(nn.Module):
+    """Spatial-attention fusion (parallel_fusion.py:49-73): out = sigmoid(conv3x3([mean_c q1, max_c q1])) * conv_v(v) + q,
+    q1 = conv_q(cat[q, v]); every conv is 3x3 without bias.  Parameter names as in the reference."""
+
+    def __init__(self, c, bias=False):
+        super().__init__()
+        self.conv_q = nn.Conv2d(2 * c, c, 3, padding=1, bias=bias)
+        self.conv_v = nn.Sequential(nn.Conv2d(c, c, 3, 1, 1, bias=bias))
+        self.s_map = nn.Sequential(nn.Conv2d(2, 1, 3, 1, 1, bias=bias), nn.Sigmoid())
+        self._pq, self._pv, self._ps = PackedConv([self.conv_q]), PackedConv([self.conv_v[0]]), PackedConv([self.s_map[0]])
+
+    def run(self, q, v):
+        q1 = fn.conv(self._pq, [q, v])
+        v1 = fn.conv(self._pv, v)
+        s = fn.conv(self._ps, fn.chan_stats(q1), act=ACT_SIGMOID)          # (B,H,W,1)
+        return fn.scale_add(v1, s, q, 0)
+
+
+class _CA(nn.Module):
+    """Channel-attention fusion (parallel_fusion.py:14-46): out = (mlp(avg_hw q1) + mlp(max_hw q1)) * conv_v(v) + q,
+    mlp = conv1x1(C -> C/16) -> ReLU -> conv1x1(-> C) -> Sigmoid.  The two pooled vectors run through the MLP as
+    one batch of 2B one-pixel images."""
+
+    def __init__(self, c, reduction=16, bias=True):
+        super().__init__()
+        self.conv_q = nn.Conv2d(2 * c, c, 3, padding=1, bias=bias)
+        self.conv_v = nn.Sequential(nn.Conv2d(c, c, 3, 1, 1, bias=bias))
+        self.avgpool, self.maxpool = nn.AdaptiveAvgPool2d(1), nn.AdaptiveMaxPool2d(1)   # no state; kept for module parity
+        self.c_map = nn.Sequential(nn.Conv2d(c, c // reduction, 1, padding=0, bias=bias), nn.ReLU(inplace=True),
+                                   nn.Conv2d(c // reduction, c, 1, padding=0, bias=bias), nn.Sigmoid())
+        self._pq, self._pv = PackedConv([self.conv_q]), PackedConv([self.conv_v[0]])
+        self._p1, self._p2 = PackedConv([self.c_map[0]]), PackedConv([self.c_map[2]])
+
+    def run(self, q, v):
+        q1 = fn.conv(self._pq, [q, v])
+        v1 = fn.conv(self._pv, v)
+        pooled = fn.spatial_stats(q1)                                       # (2B,1,1,C): avg rows, then max rows
+        ch = self._p1.cout                                                  # C/16 channels, padded to a multiple of 4
+        hid = fn.conv(self._p1, pooled, act=ACT_RELU, pad_out=True,
+                      fill_tail=(lambda full: full[..., ch:].zero_()) if ch % 4 else None)
+        cm = fn.conv(self._p2, hid, act=ACT_SIGMOID)                        # (2B,1,1,C)
+        return fn.scale_add(v1, cm, q, 1)
+
+
 class FusionUnit(nn.Module):
-    """parallel_fusion.py:98-150 for the '1x1conv', '1x1conv-unidirection' and 'concat' types."""
+    """parallel_fusion.py:98-150: '1x1conv', '1x1conv-unidirection', 'concat', 'SA', 'CA'."""
 
     def __init__(self, c, fusion_type, bi_direction=True):
         super().__init__()
@@ -131,12 +177,17 @@ class FusionUnit(nn.Module):
             self.mask2img = _FusionConv(2 * c, c)
             self.img2mask = _FusionConv(2 * c, c) if bi_direction else None
         elif fusion_type in ("SA", "CA"):
-            raise NotImplementedError(f"fusion type {fusion_type} is not built on the HIP path yet (SURVEY §8f-3)")
+            unit = _SA if fusion_type == "SA" else _CA
+            self.mask2img = unit(c)
+            self.img2mask = unit(c) if bi_direction else None
         else:
             raise ValueError(f"Fusion type {fusion_type} not supported.")
 
     def run(self, mask, img):
-        if self.fusion_type == "concat":
+        if self.fusion_type in ("SA", "CA"):
+            img_out = self.mask2img.run(img, mask)
+            mask_out = self.img2mask.run(mask, img) if self.img2mask is not None else mask
+        elif self.fusion_type == "concat":
             img_out = fn.conv(self.mask2img._p, [img, mask])
             mask_out = fn.conv(self.img2mask._p, [mask, img]) if self.img2mask is not None else mask
         else:  # out = q + conv1x1(v): the residual add rides in the conv epilogue

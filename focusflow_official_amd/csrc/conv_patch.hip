@@ -22,7 +22,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TW = 16, BN = 64, ROWB = 128;   // tile height TH = 4*TM (template): 8 rows, or 4 for small problems
-constexpr int MAXP = 6;     // patch float4 items per thread: ceil((TH+6)*(TW+6)*8 / 256) = 10 for 7x7 -> handled by loop bound
+
 
 struct PArgs {
     FFConvParams p;

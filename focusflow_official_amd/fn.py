@@ -5,7 +5,7 @@ and gradient accumulation into `.grad`, nothing else.
 The dispatchers at the bottom (`conv`, `norm`, ...) pick the fused inference
 launch when no gradient is being recorded and the autograd node otherwise.
 """
-from typing import List, Optional, Sequence
+from typing import List, Optional
 
 import torch
 
@@ -229,6 +229,58 @@ class LookupFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------
+# SA / CA fusion units (parallel_fusion.py:14-73)
+# ----------------------------------------------------------------------------
+class ChanStatsFn(torch.autograd.Function):
+    """(B,H,W,C) -> (B,H,W,4) = [mean over channels, max over channels, 0, 0]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        st, am = ops.chan_stats(x)
+        ctx.save_for_backward(am)
+        ctx.c = x.shape[3]
+        return st
+
+    @staticmethod
+    def backward(ctx, g):
+        (am,) = ctx.saved_tensors
+        return ops.chan_stats_bwd(_dense(g), am, ctx.c)
+
+
+class SpatialStatsFn(torch.autograd.Function):
+    """(B,H,W,C) -> (2B,1,1,C): per-sample mean over pixels stacked on the per-sample max."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out, am = ops.spatial_stats(x)
+        ctx.save_for_backward(am)
+        ctx.hw = x.shape[1:3]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (am,) = ctx.saved_tensors
+        return ops.spatial_stats_bwd(_dense(g), am, *ctx.hw)
+
+
+class ScaleAddFn(torch.autograd.Function):
+    """out = s * v + q; s per pixel (mode 0) or per (sample, channel), avg-branch + max-branch (mode 1)."""
+
+    @staticmethod
+    def forward(ctx, v, s, q, mode):
+        ctx.save_for_backward(v, s)
+        ctx.mode = mode
+        return ops.scale_add(v, s, q, mode)
+
+    @staticmethod
+    def backward(ctx, gout):
+        v, s = ctx.saved_tensors
+        gout = _dense(gout)
+        gv, gs = ops.scale_add_bwd(gout, v, s, ctx.mode)
+        return gv, gs, gout, None
+
+
+# ----------------------------------------------------------------------------
 # dispatchers
 # ----------------------------------------------------------------------------
 def recording(*tensors) -> bool:
@@ -253,3 +305,15 @@ def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail
             fill_tail(full)
         return full
     return pc(xs, act=act, res=res, out_scale=out_scale)
+
+
+def chan_stats(x):
+    return ChanStatsFn.apply(x) if recording(x) else ops.chan_stats(x)[0]
+
+
+def spatial_stats(x):
+    return SpatialStatsFn.apply(x) if recording(x) else ops.spatial_stats(x)[0]
+
+
+def scale_add(v, s, q, mode):
+    return ScaleAddFn.apply(v, s, q, mode) if recording(v, s, q) else ops.scale_add(v, s, q, mode)

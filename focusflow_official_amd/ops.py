@@ -278,6 +278,84 @@ def mask_prepare(mode: int, mask_nchw: Tensor, image_nchw: Tensor, table: Tensor
     return dst
 
 
+# ----------------------------------------------------------------------------
+# SA / CA fusion units (parallel_fusion.py:14-73)
+# ----------------------------------------------------------------------------
+SPATIAL_SLABS = 64   # FF_SPATIAL_SLABS
+
+
+def chan_stats(x: Tensor):
+    """(B,H,W,C) -> ((B,H,W,4) = [mean_c, max_c, 0, 0], argmax (B,H,W) int32)."""
+    _require_gpu(x)
+    b, h, w, c = x.shape
+    st = empty_nhwc(b, h, w, 4, x)
+    am = torch.empty((b, h, w), dtype=torch.int32, device=x.device)
+    _hip.call("ff_chan_stats_fwd", _p(x), _ld(x), c, b * h * w, _p(st), 4, _p(am), _stream())
+    return st, am
+
+
+def chan_stats_bwd(g: Tensor, argmax: Tensor, c: int) -> Tensor:
+    b, h, w, _ = g.shape
+    gx = empty_nhwc(b, h, w, c, g)
+    _hip.call("ff_chan_stats_bwd", _p(g), _ld(g), _p(argmax), c, b * h * w, _p(gx), _ld(gx), _stream())
+    return gx
+
+
+def _spatial_scratch(b, c, like):
+    return torch.empty(SPATIAL_SLABS * b * c * 3, dtype=torch.float32, device=like.device)
+
+
+def spatial_stats(x: Tensor):
+    """(B,H,W,C) -> ((2B,1,1,C): rows [0,B) = mean over pixels, rows [B,2B) = max; argmax (B,C) int32)."""
+    _require_gpu(x)
+    b, h, w, c = x.shape
+    out = torch.empty((2 * b, 1, 1, c), dtype=torch.float32, device=x.device)
+    am = torch.empty((b, c), dtype=torch.int32, device=x.device)
+    _hip.call("ff_spatial_stats_fwd", _p(x), _ld(x), c, b, h * w, _p(out), _p(out[b:]), _p(am), _p(_spatial_scratch(b, c, x)),
+              _stream())
+    return out, am
+
+
+def spatial_stats_bwd(g: Tensor, argmax: Tensor, h: int, w: int) -> Tensor:
+    b2, _, _, c = g.shape
+    b = b2 // 2
+    g = g.contiguous()
+    gx = empty_nhwc(b, h, w, c, g)
+    _hip.call("ff_spatial_stats_bwd", _p(g), _p(g[b:]), _p(argmax), c, b, h * w, _p(gx), _ld(gx), _stream())
+    return gx
+
+
+def scale_add(v: Tensor, s: Tensor, q: Optional[Tensor], mode: int) -> Tensor:
+    """out = s * v + q.  mode 0: s (B,H,W,1) per pixel; mode 1: s (2B,1,1,C), scale = s[:B] + s[B:]."""
+    _require_gpu(v)
+    b, h, w, c = v.shape
+    out = empty_nhwc(b, h, w, c, v)
+    if mode == 0:
+        assert s.shape[:3] == (b, h, w)
+        _hip.call("ff_scale_add_fwd", _p(v), _ld(v), _p(s), _ld(s), None, _p(q), _ld(q) if q is not None else 0, _p(out),
+                  _ld(out), c, b, h * w, 0, _stream())
+    else:
+        assert s.shape == (2 * b, 1, 1, c) and s.is_contiguous()
+        _hip.call("ff_scale_add_fwd", _p(v), _ld(v), _p(s), 0, _p(s[b:]), _p(q), _ld(q) if q is not None else 0, _p(out),
+                  _ld(out), c, b, h * w, 1, _stream())
+    return out
+
+
+def scale_add_bwd(gout: Tensor, v: Tensor, s: Tensor, mode: int):
+    """-> (gv, gs) with gs shaped like s."""
+    b, h, w, c = v.shape
+    gv = empty_nhwc(b, h, w, c, v)
+    if mode == 0:
+        gs = torch.empty((b, h, w, 1), dtype=torch.float32, device=v.device)
+        _hip.call("ff_scale_add_bwd", _p(gout), _ld(gout), _p(v), _ld(v), _p(s), _ld(s), None, _p(gv), _ld(gv), _p(gs), None,
+                  c, b, h * w, 0, _stream())
+    else:
+        gs = torch.empty((2 * b, 1, 1, c), dtype=torch.float32, device=v.device)
+        _hip.call("ff_scale_add_bwd", _p(gout), _ld(gout), _p(v), _ld(v), _p(s), 0, _p(s[b:]), _p(gv), _ld(gv), _p(gs),
+                  _p(_spatial_scratch(b, c, v)), c, b, h * w, 1, _stream())
+    return gv, gs
+
+
 def act_copy(src: Tensor, dst: Tensor, act: int):
     b, h, w, c = src.shape
     assert dst.shape == src.shape
@@ -365,7 +443,8 @@ def unpack_conv_wgrad(packed: Tensor, cout, cin, kh, kw, cin_pad, cout_offset) -
 
 def pack_conv_weight_dgrad(w_oihw: Tensor, dst: Tensor, cout_pad: int, cout_offset: int):
     co, ci, kh, kw = w_oihw.shape
-    assert dst.is_contiguous() and dst.shape == (ci, kh * kw * cout_pad)
+    # rows beyond Cin (channel padding of the forward input) stay zero: their input gradient is zero
+    assert dst.is_contiguous() and dst.shape[0] >= ci and dst.shape[1] == kh * kw * cout_pad
     _hip.call("ff_pack_conv_weight_dgrad", _p(w_oihw.contiguous()), co, ci, kh, kw, _p(dst), cout_pad, cout_offset, _stream())
 
 

@@ -263,6 +263,34 @@ int ff_nchw_to_nhwc4(const float* src_nchw, int src_c, float fill, float* dst_nh
 int ff_resize_bilinear(const float* src_nhwc, int ld, int C, int Hi, int Wi, float* dst_nchw, int B, int Ho, int Wo,
                        float mul0, float mul1, void* stream);
 
+/* ========================================================================
+ * SA / CA fusion units (parallel_fusion.py:14-73) — the parts that are not convolutions.  NHWC fp32,
+ * deterministic reductions.
+ *   ff_chan_stats_fwd      st[p][0] = mean_c x[p][c], st[p][1] = max_c, st[p][2..st_ld) = 0 (the padded
+ *                          input of SA.s_map's 2->1 conv, :66-69); argmax[p] = first maximal channel
+ *   ff_chan_stats_bwd      gx[p][c] = g[p][0] / C + (c == argmax[p]) * g[p][1]
+ *   ff_spatial_stats_fwd   avg[b][c], mx[b][c] = AdaptiveAvg/MaxPool2d(1) (CA, :42-43); argmax = pixel index;
+ *                          scratch: FF_SPATIAL_SLABS * B * C * 3 floats
+ *   ff_spatial_stats_bwd   gx[b][p][c] = gavg[b][c] / HW + (p == argmax[b][c]) * gmax[b][c]
+ *   ff_scale_add_fwd       out = sv * v + q (q nullable); mode 0: sv = s[pixel * s_ld] (SA, :70-71);
+ *                          mode 1: sv = s[b*C + c] + s2[b*C + c] (s2 nullable) (CA, :44-46)
+ *   ff_scale_add_bwd       gv = sv * gout; gs = sum over channels (mode 0: one float per pixel) or over
+ *                          pixels (mode 1: gs[b*C + c], duplicated at gs[B*C + ...] when s2 is given;
+ *                          scratch as above) of v * gout
+ * ======================================================================== */
+#define FF_SPATIAL_SLABS 64
+int ff_chan_stats_fwd(const float* x, int x_ld, int C, long long npix, float* st, int st_ld, int* argmax, void* stream);
+int ff_chan_stats_bwd(const float* g, int g_ld, const int* argmax, int C, long long npix, float* gx, int gx_ld,
+                      void* stream);
+int ff_spatial_stats_fwd(const float* x, int x_ld, int C, int B, int HW, float* avg, float* mx, int* argmax,
+                         float* scratch, void* stream);
+int ff_spatial_stats_bwd(const float* gavg, const float* gmax, const int* argmax, int C, int B, int HW, float* gx,
+                         int gx_ld, void* stream);
+int ff_scale_add_fwd(const float* v, int v_ld, const float* s, int s_ld, const float* s2, const float* q, int q_ld,
+                     float* out, int out_ld, int C, int B, int HW, int mode, void* stream);
+int ff_scale_add_bwd(const float* gout, int g_ld, const float* v, int v_ld, const float* s, int s_ld, const float* s2,
+                     float* gv, int gv_ld, float* gs, float* scratch, int C, int B, int HW, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

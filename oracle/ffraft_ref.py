@@ -33,7 +33,7 @@ BN_MOMENTUM = 0.1
 # layer helpers
 # ----------------------------------------------------------------------------
 def _conv(sd, name, x, stride=1, padding=0):
-    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=stride, padding=padding)
+    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=stride, padding=padding)   # SA convs: no bias
 
 
 def _norm(sd, name, x, kind, training):
@@ -76,9 +76,33 @@ def _fuse(sd, p, mask, img, fusion_type, bidirectional):
     elif fusion_type == "concat":
         img_out = _conv(sd, p + ".mask2img.conv", torch.cat([img, mask], 1))
         mask_out = _conv(sd, p + ".img2mask.conv", torch.cat([mask, img], 1)) if bidirectional else mask
+    elif fusion_type in ("SA", "CA"):
+        unit = _sa_unit if fusion_type == "SA" else _ca_unit
+        img_out = unit(sd, p + ".mask2img", img, mask)
+        mask_out = unit(sd, p + ".img2mask", mask, img) if bidirectional else mask
     else:
         raise ValueError(f"Fusion type {fusion_type} not supported.")
     return mask_out, img_out
+
+
+def _sa_unit(sd, p, q, v):
+    """SA.forward (parallel_fusion.py:63-73): spatial map from the channel mean / max of conv_q(cat[q, v])."""
+    q1 = _conv(sd, p + ".conv_q", torch.cat([q, v], 1), padding=1)
+    v = _conv(sd, p + ".conv_v.0", v, padding=1)
+    st = torch.cat([q1.mean(dim=1, keepdim=True), q1.max(dim=1, keepdim=True)[0]], 1)
+    return torch.sigmoid(_conv(sd, p + ".s_map.0", st, padding=1)) * v + q
+
+
+def _ca_unit(sd, p, q, v):
+    """CA.forward (parallel_fusion.py:39-46): channel map = mlp(avg-pooled) + mlp(max-pooled) of conv_q(cat[q, v])."""
+    q1 = _conv(sd, p + ".conv_q", torch.cat([q, v], 1), padding=1)
+    v = _conv(sd, p + ".conv_v.0", v, padding=1)
+
+    def mlp(t):
+        return torch.sigmoid(_conv(sd, p + ".c_map.2", torch.relu(_conv(sd, p + ".c_map.0", t))))
+
+    c_map = mlp(q1.mean(dim=(2, 3), keepdim=True)) + mlp(q1.amax(dim=(2, 3), keepdim=True))
+    return c_map * v + q
 
 
 def cce_encoder(sd, p, x, mask, kind, training=False, fusion_type="1x1conv"):

@@ -44,3 +44,15 @@ def det_sd():
 def det_sd_concat():
     from oracle.weights import det_tensor
     return {k: det_tensor(k, s) for k, s, _ in golden_spec("state_dict_spec_concat")}
+
+
+@pytest.fixture(scope="session")
+def det_sd_sa():
+    from oracle.weights import det_tensor
+    return {k: det_tensor(k, s) for k, s, _ in golden_spec("state_dict_spec_sa")}
+
+
+@pytest.fixture(scope="session")
+def det_sd_ca():
+    from oracle.weights import det_tensor
+    return {k: det_tensor(k, s) for k, s, _ in golden_spec("state_dict_spec_ca")}

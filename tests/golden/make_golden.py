@@ -246,6 +246,31 @@ def main():
     np.savez_compressed(os.path.join(HERE, "fwd_concat_128x160_b1_it4.npz"), flow_low=np32(fl), flow_up=np32(fu),
                         in_crc=np.array([crc(image1), crc(image2), crc(mask1)], dtype=np.int64))
 
+    # SA / CA fusion variants (one reference config each): the fusion units alone on random (q, v), and the
+    # final flow of the whole network at 128x160
+    from FF_RAFT_Core.parallel_fusion import CA, SA  # noqa: E402  (reference)
+    for ft, cls in (("SA", SA), ("CA", CA)):
+        unit = cls(64)
+        unit.load_state_dict({k: det_tensor(f"unit_{ft}." + k, v.shape) for k, v in unit.state_dict().items()})
+        g = torch.Generator().manual_seed(21)
+        q, v = torch.randn(2, 64, 12, 20, generator=g), torch.randn(2, 64, 12, 20, generator=g)
+        with torch.no_grad():
+            out = unit.eval()(q, v)
+        net_v = RAFT(in_channels=256, inside_fusion="parallel", fuse_cnet=True, cfg=cfg(ft))
+        sdv = net_v.state_dict()
+        net_v.load_state_dict({k: det_tensor("flow_net." + k, v_.shape) for k, v_ in sdv.items()})
+        with open(os.path.join(HERE, f"state_dict_spec_{ft.lower()}.json"), "w") as f:
+            json.dump([["flow_net." + k, list(v_.shape), str(v_.dtype)] for k, v_ in sdv.items()], f)
+        net_v.eval()
+        image1, image2, mask1, mask2 = orc.shifted_pair(1, 128, 160, seed=8)
+        i1, i2, m1, m2 = orc.prepare_inputs(image1, image2, mask1, mask2, 3)
+        with torch.no_grad():
+            fl, fu = net_v(i1, i2, m1, m2, iters=4, test_mode=True)
+        np.savez_compressed(os.path.join(HERE, f"fwd_{ft.lower()}_128x160_b1_it4.npz"), flow_low=np32(fl), flow_up=np32(fu),
+                            unit_out=np32(out), unit_keys=np.array(list(unit.state_dict().keys())),
+                            in_crc=np.array([crc(image1), crc(image2), crc(mask1)], dtype=np.int64))
+        print(ft, "unit |out|", out.abs().max().item(), "flow", fu.abs().max().item())
+
 
 if __name__ == "__main__":
     main()

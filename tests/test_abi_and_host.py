@@ -96,8 +96,9 @@ def test_unsupported_configurations_fail_loudly(lib_path):
     from focusflow_official_amd import FF_RAFT_FUSION
     with pytest.raises(NotImplementedError):
         FF_RAFT_FUSION(use_fusion="attention", cfg=_cfg())
-    with pytest.raises(NotImplementedError):
-        FF_RAFT_FUSION(use_fusion="parallel", fuse_cnet=True, cfg=_cfg("SA"))
+    for ft in ("SA", "CA"):  # attention fusion units are built: state_dict must carry the reference's key names
+        keys = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg(ft)).state_dict().keys()
+        assert [k for k, _, _ in golden_spec(f"state_dict_spec_{ft.lower()}")] == list(keys)
     with pytest.raises(ValueError):
         FF_RAFT_FUSION(use_fusion="parallel", fuse_cnet=True, cfg=_cfg("bogus"))
 

@@ -193,6 +193,32 @@ def test_gru_and_upsample_backward(mods):
     close(nchw(md.grad), mask.grad, rtol=1e-4, atol_rel=1e-4, what="dmask")
 
 
+@pytest.mark.parametrize("ft", ["SA", "CA"])
+def test_attention_fusion_unit_backward(mods, ft):
+    """Gradients of an SA / CA unit (inputs and every parameter) against autograd through the oracle's restatement
+    of the same unit (pinned by the reference's output in fwd_{sa,ca}_128x160_b1_it4.npz)."""
+    from oracle import ffraft_ref as orc
+    from oracle.weights import det_tensor
+    unit = (mods.cce._SA if ft == "SA" else mods.cce._CA)(96)          # C/16 = 6: exercises the padded hidden layer
+    unit.load_state_dict({k: det_tensor(f"bwd_{ft}." + k, v.shape) for k, v in unit.state_dict().items()})
+    sd = {"u." + k: v.detach().clone().double().requires_grad_(True) for k, v in unit.state_dict().items()}
+    unit = unit.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    q, v = torch.randn(2, 96, 20, 28, generator=g), torch.randn(2, 96, 20, 28, generator=g)
+    gout = torch.randn(2, 96, 20, 28, generator=g)
+    qr, vr = q.double().requires_grad_(True), v.double().requires_grad_(True)
+    ref = (orc._sa_unit if ft == "SA" else orc._ca_unit)(sd, "u", qr, vr)
+    ref.backward(gout.double())
+    qd, vd = nhwc(q).requires_grad_(True), nhwc(v).requires_grad_(True)
+    out = unit.run(qd, vd)
+    close(nchw(out), ref.detach(), what=f"{ft} forward")
+    out.backward(nhwc(gout))
+    close(nchw(qd.grad), qr.grad, what=f"{ft} dq")
+    close(nchw(vd.grad), vr.grad, what=f"{ft} dv")
+    for k, p in unit.named_parameters():
+        close(p.grad.cpu(), sd["u." + k].grad, rtol=1e-4, atol_rel=1e-4, what=f"{ft} d{k}")
+
+
 def _cfg():
     return Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"),
                      MODEL=Namespace(FUSION_TYPE="1x1conv", LOAD_MODULE_TO_BRANCH=False))

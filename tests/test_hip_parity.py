@@ -346,6 +346,29 @@ def test_concat_fusion_variant(det_sd_concat):
     close(fu.cpu(), g["flow_up"], rtol=0, atol=1e-3, what="concat flow_up")
 
 
+@pytest.mark.parametrize("ft", ["SA", "CA"])
+def test_attention_fusion_units_and_variants(ft, det_sd_sa, det_sd_ca):
+    """SA / CA fusion (parallel_fusion.py:14-73): the unit alone against the reference's output on random (q, v),
+    then the whole network against the reference's final flow."""
+    from focusflow_official_amd import cce
+    from oracle.weights import det_tensor
+    g = load_golden(f"fwd_{ft.lower()}_128x160_b1_it4")
+    unit = (cce._SA if ft == "SA" else cce._CA)(64)
+    assert sorted(unit.state_dict()) == sorted(str(k) for k in g["unit_keys"])
+    unit.load_state_dict({k: det_tensor(f"unit_{ft}." + k, v.shape) for k, v in unit.state_dict().items()})
+    unit = unit.to(DEV)
+    gen = torch.Generator().manual_seed(21)
+    q, v = torch.randn(2, 64, 12, 20, generator=gen), torch.randn(2, 64, 12, 20, generator=gen)
+    with torch.no_grad():
+        out = unit.run(nhwc(q), nhwc(v))
+    close(nchw(out), g["unit_out"], rtol=2e-5, what=f"{ft} unit")
+    inp = [t.to(DEV) for t in orc.shifted_pair(1, 128, 160, seed=8)]
+    m = _model(det_sd_sa if ft == "SA" else det_sd_ca, ft)
+    with torch.no_grad():
+        fl, fu = m(*inp, raft_iters=4, test_mode=True)
+    close(fu.cpu(), g["flow_up"], rtol=0, atol=1e-3, what=f"{ft} flow_up")
+
+
 def test_config1_384x512_and_batch_consistency(det_sd):
     """BASELINE config 1 (B=1 384x512 it12) against the reference's vector, then
     config 2's size (B=8): eight copies of the pair must give eight identical flows

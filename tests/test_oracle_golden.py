@@ -94,6 +94,27 @@ def test_concat_fusion(det_sd_concat):
     np.testing.assert_allclose(fu.numpy(), g["flow_up"], rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("ft", ["SA", "CA"])
+def test_attention_fusion_units_and_variants(ft, det_sd_sa, det_sd_ca):
+    """SA / CA (parallel_fusion.py:14-73): the unit alone on the reference's random (q, v), then the whole net."""
+    from oracle.weights import det_tensor
+    g = load_golden(f"fwd_{ft.lower()}_128x160_b1_it4")
+    shapes = {"SA": {"conv_q.weight": (64, 128, 3, 3), "conv_v.0.weight": (64, 64, 3, 3), "s_map.0.weight": (1, 2, 3, 3)},
+              "CA": {"conv_q.weight": (64, 128, 3, 3), "conv_q.bias": (64,), "conv_v.0.weight": (64, 64, 3, 3),
+                     "conv_v.0.bias": (64,), "c_map.0.weight": (4, 64, 1, 1), "c_map.0.bias": (4,),
+                     "c_map.2.weight": (64, 4, 1, 1), "c_map.2.bias": (64,)}}[ft]
+    assert sorted(shapes) == sorted(str(k) for k in g["unit_keys"])
+    sd = {"u." + k: det_tensor(f"unit_{ft}." + k, s) for k, s in shapes.items()}
+    gen = torch.Generator().manual_seed(21)
+    q, v = torch.randn(2, 64, 12, 20, generator=gen), torch.randn(2, 64, 12, 20, generator=gen)
+    out = (orc._sa_unit if ft == "SA" else orc._ca_unit)(sd, "u", q, v)
+    np.testing.assert_allclose(out.numpy(), g["unit_out"], rtol=0, atol=2e-5)
+    inp = orc.shifted_pair(1, 128, 160, seed=8)
+    with torch.no_grad():
+        fl, fu = orc.ffraft_forward(det_sd_sa if ft == "SA" else det_sd_ca, *inp, raft_iters=4, test_mode=True, fusion_type=ft)
+    np.testing.assert_allclose(fu.numpy(), g["flow_up"], rtol=0, atol=1e-4)
+
+
 def test_train_step_matches_reference(det_sd):
     """Train-mode forward (BN batch statistics) + sequence L1 + autograd."""
     g = load_golden("train_shift_128x128_b2_it3")
