@@ -209,6 +209,35 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ src, int ld, in
     }
 }
 
+// F.interpolate(bilinear, align_corners=False) of a 1- or 3-channel NCHW image into NHWC4 (1 channel is repeated
+// to 3, channel 3 = 0): FF_PWCNET.preprocess (ff_pwcnet.py:391-403) fused with the layout change
+__global__ void resize_to_nhwc4_kernel(const float* __restrict__ src, int src_c, int Hi, int Wi, float* __restrict__ dst, int B,
+                                       int Ho, int Wo) {
+    const long long total = (long long)B * Ho * Wo;
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % Wo);
+        const long long t = i / Wo;
+        const int y = (int)(t % Ho);
+        const long long b = t / Ho;
+        float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        float o[3];
+        for (int c = 0; c < src_c; ++c) {
+            const float* pl = src + (b * src_c + c) * (long long)Hi * Wi;
+            const float v00 = pl[(long long)y0 * Wi + x0], v01 = pl[(long long)y0 * Wi + x1];
+            const float v10 = pl[(long long)y1 * Wi + x0], v11 = pl[(long long)y1 * Wi + x1];
+            o[c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        }
+        if (src_c == 1) o[1] = o[2] = o[0];
+        *reinterpret_cast<f32x4*>(dst + i * 4) = (f32x4){o[0], o[1], o[2], 0.f};
+    }
+}
+
 inline int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -290,4 +319,12 @@ extern "C" int ff_resize_bilinear(const float* src_nhwc, int ld, int C, int Hi, 
     FF_REQUIRE(src_nhwc && dst_nchw && B > 0 && C > 0 && ld >= C && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "ff_resize_bilinear: bad argument");
     resize_bilinear_kernel<<<grid_for((long long)B * C * Ho * Wo), 256, 0, static_cast<hipStream_t>(stream)>>>(src_nhwc, ld, C, Hi, Wi, dst_nchw, B, Ho, Wo, mul0, mul1);
     return ff::check_launch("ff_resize_bilinear");
+}
+
+extern "C" int ff_resize_to_nhwc4(const float* src_nchw, int src_c, int Hi, int Wi, float* dst_nhwc4, int B, int Ho, int Wo,
+                                  void* stream) {
+    FF_REQUIRE(src_nchw && dst_nhwc4 && B > 0 && (src_c == 1 || src_c == 3) && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && ff::aligned16(dst_nhwc4),
+               "ff_resize_to_nhwc4: bad argument");
+    resize_to_nhwc4_kernel<<<grid_for((long long)B * Ho * Wo), 256, 0, static_cast<hipStream_t>(stream)>>>(src_nchw, src_c, Hi, Wi, dst_nhwc4, B, Ho, Wo);
+    return ff::check_launch("ff_resize_to_nhwc4");
 }

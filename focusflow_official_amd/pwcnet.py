@@ -12,9 +12,9 @@ owns ONE wide buffer laid out in the reference's final channel order, every piec
 upfeat 2+2]); a conv reads the suffix starting at its own offset and writes its output slot in front of
 it.  Packed weights get zero columns at the pad channels.
 
-Built: 'point' masks, fusion type 1x1conv / concat, inputs whose H and W are multiples of 64 (the
-reference bilinearly resizes other sizes first; BASELINE config 4 is 448x1024).  Training (backward of
-transposed conv / backwarp) is a later row.
+Built: 'point' masks, every fusion type, any input size (sizes that are not multiples of 64 are bilinearly
+resized first and the flow is resized / rescaled back, as the reference does; BASELINE config 4, 448x1024,
+needs no resize).  Training (backward of transposed conv / backwarp) is a later row.
 """
 import torch
 import torch.nn as nn
@@ -208,16 +208,25 @@ class FF_PWCNET(nn.Module):
                   fill, _p(dst), b, h, w, _stream())
         return dst
 
+    def _resized4(self, t, b, h, w):
+        dst = ops.empty_nhwc(b, h, w, 4, t)
+        _hip.call("ff_resize_to_nhwc4", _p(t.contiguous()), t.shape[1], t.shape[2], t.shape[3], _p(dst), b, h, w, _stream())
+        return dst
+
     def forward(self, tenOne, tenTwo, mask1, mask2, test_mode=False):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("FF_PWCNET on HIP is inference-only this round: call it under torch.no_grad()")
         ops._require_gpu(tenOne)
-        b, _, h, w = tenOne.shape
-        if h % 64 or w % 64:
-            raise NotImplementedError("H and W must be multiples of 64 (the reference's pre-resize path is not built)")
+        b, _, h0, w0 = tenOne.shape
         assert mask1.shape[1] == 1
-        i1, i2 = self._nhwc4(tenOne, b, h, w, tenOne), self._nhwc4(tenTwo, b, h, w, tenOne)
-        m1 = self._nhwc4(mask1, b, h, w, tenOne)                      # 'point': repeat to 3 channels
+        # preprocess (ff_pwcnet.py:391-403): bilinear resize to the next multiples of 64, a no-op when they already are
+        h, w = (h0 + 63) // 64 * 64, (w0 + 63) // 64 * 64
+        self.origin_H, self.origin_W, self.new_H, self.new_W = h0, w0, h, w
+        if (h, w) == (h0, w0):
+            i1, i2 = self._nhwc4(tenOne, b, h, w, tenOne), self._nhwc4(tenTwo, b, h, w, tenOne)
+            m1 = self._nhwc4(mask1, b, h, w, tenOne)                  # 'point': repeat to 3 channels
+        else:
+            i1, i2, m1 = self._resized4(tenOne, b, h, w), self._resized4(tenTwo, b, h, w), self._resized4(mask1, b, h, w)
         m2 = self._nhwc4(None, b, h, w, tenOne, fill=255.0)           # ones_like(mask1) * 255
         f1 = self.netExtractor.run(i1, m1)
         f2 = self.netExtractor.run(i2, m2)
@@ -230,7 +239,8 @@ class FF_PWCNET(nn.Module):
             flows.insert(0, est["tenFlow"])
         if test_mode:
             fl = est["tenFlow"][..., :2]
-            out = torch.empty((b, 2, h, w), dtype=torch.float32, device=tenOne.device)
-            _hip.call("ff_resize_bilinear", _p(fl), ops._ld(fl), 2, fl.shape[1], fl.shape[2], _p(out), b, h, w, 1.0, 1.0, _stream())
+            out = torch.empty((b, 2, h0, w0), dtype=torch.float32, device=tenOne.device)     # back to the caller's size,
+            _hip.call("ff_resize_bilinear", _p(fl), ops._ld(fl), 2, fl.shape[1], fl.shape[2], _p(out), b, h0, w0,
+                      float(w0) / w, float(h0) / h, _stream())                                   # flow rescaled (:427-431)
             return out
         return [ops.nhwc_to_nchw(f[..., :2]) for f in flows]

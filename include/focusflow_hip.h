@@ -262,6 +262,10 @@ int ff_mask_prepare(int mode, const float* mask, const float* image, const float
 int ff_nchw_to_nhwc4(const float* src_nchw, int src_c, float fill, float* dst_nhwc4, int B, int H, int W, void* stream);
 int ff_resize_bilinear(const float* src_nhwc, int ld, int C, int Hi, int Wi, float* dst_nchw, int B, int Ho, int Wo,
                        float mul0, float mul1, void* stream);
+/* FF_PWCNET.preprocess (ff_pwcnet.py:391-403): the same bilinear resize of a 1- or 3-channel NCHW input to
+ * (Ho, Wo), written as NHWC4 (one channel is repeated to three; channel 3 = 0). */
+int ff_resize_to_nhwc4(const float* src_nchw, int src_c, int Hi, int Wi, float* dst_nhwc4, int B, int Ho, int Wo,
+                       void* stream);
 
 /* ========================================================================
  * SA / CA fusion units (parallel_fusion.py:14-73) — the parts that are not convolutions.  NHWC fp32,

@@ -109,10 +109,11 @@ def pwc_refiner(sd, p, feat):
 
 
 def ffpwc_forward(sd, image1, image2, mask1, mask2=None, test_mode=False, mask_channel=3):
-    """ff_pwcnet.py:405-433 for inputs whose H, W are multiples of 64 (no resize) and 'point' masks.
-    Inputs stay in [0,255] (FF-PWC does not normalise)."""
-    b, _, h, w = image1.shape
-    assert h % 64 == 0 and w % 64 == 0
+    """ff_pwcnet.py:405-433 with 'point' masks, including preprocess (:391-403): sizes that are not multiples of 64
+    are bilinearly resized first.  Inputs stay in [0,255] (FF-PWC does not normalise)."""
+    b, _, h0, w0 = image1.shape
+    h, w = -(-h0 // 64) * 64, -(-w0 // 64) * 64
+    image1, image2, mask1 = (F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False) for t in (image1, image2, mask1))
     m1 = mask1.repeat(1, mask_channel, 1, 1)
     m2 = torch.ones_like(m1) * 255
     f1 = pwc_extractor(sd, "netExtractor", image1, m1)
@@ -125,8 +126,10 @@ def ffpwc_forward(sd, image1, image2, mask1, mask2=None, test_mode=False, mask_c
             est["tenFlow"] = est["tenFlow"] + pwc_refiner(sd, "netRefiner", est["tenFeat"])
         flows.insert(0, est["tenFlow"])
     if test_mode:
-        out = F.interpolate(est["tenFlow"], size=(h, w), mode="bilinear", align_corners=False)
-        return out          # scale factors are 1 when no resize happened
+        out = F.interpolate(est["tenFlow"], size=(h0, w0), mode="bilinear", align_corners=False)
+        out[:, 0] = out[:, 0] * w0 / w
+        out[:, 1] = out[:, 1] * h0 / h
+        return out
     return flows
 
 

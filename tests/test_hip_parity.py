@@ -387,6 +387,25 @@ def test_config1_384x512_and_batch_consistency(det_sd):
         close(fu8[i].cpu(), flow_up[0].cpu(), rtol=0, atol=2e-4, what=f"batch sample {i}")
 
 
+def test_config5_shape_540x960_padded(det_sd):
+    """BASELINE config 5's frame size: 540x960 replicate-padded to 544x960 (68x120 at 1/8: level 3 is 8x15, odd
+    widths at two pyramid levels), against the CPU oracle.  Few iterations on purpose: with synthetic weights the
+    recurrence is not contractive at this size — the reference's own arithmetic run in fp32 and in fp64 differs by
+    3e-3 px after 12 iterations and 0.45 px after 32 (tools/check_c5.py) — so parity is asserted where
+    rounding noise has not been amplified yet."""
+    from focusflow_official_amd.utils import InputPadder
+    inp = orc.shifted_pair(1, 540, 960, seed=3)
+    pad = InputPadder(inp[0].shape)
+    pin = pad.pad(*inp)
+    assert pin[0].shape[-2:] == (544, 960)
+    m = _model(det_sd)
+    with torch.no_grad():
+        fl, fu = m(*[t.to(DEV) for t in pin], raft_iters=3, test_mode=True)
+        rl, ru = orc.ffraft_forward(det_sd, *pin, raft_iters=3, test_mode=True)
+    close(fl.cpu(), rl, rtol=0, atol=1e-3, what="C5 flow_low")
+    close(pad.unpad(fu.cpu()), pad.unpad(ru), rtol=0, atol=1e-3, what="C5 flow_up")
+
+
 def test_full_size_lookup_properties(ops):
     """Size-independent properties at B=8, 48x64 (BASELINE config 2 shapes)."""
     g = torch.Generator().manual_seed(0)

@@ -124,5 +124,12 @@ def test_ffpwcnet_forward_matches_oracle(precision):
         close(a.cpu(), r, tol=2e-4, what=f"flow level {lvl + 2}")
     close(got_full.cpu(), ref_full, tol=2e-4, what="test_mode flow")
     assert float(ref_full.abs().max()) > 0.05, "degenerate test: flow is ~0"
-    with pytest.raises(NotImplementedError):
-        m(i1[..., :100, :].to(DEV), i2[..., :100, :].to(DEV), m1[..., :100, :].to(DEV), m1[..., :100, :].to(DEV))
+    # preprocess path (ff_pwcnet.py:391-403): 100x180 is resized to 128x192, the flow is resized / rescaled back
+    c1, c2, cm = i1[..., :100, :180].contiguous(), i2[..., :100, :180].contiguous(), m1[..., :100, :180].contiguous()
+    with torch.no_grad():
+        ref_small = pwc_ref.ffpwc_forward(sd, c1, c2, cm, test_mode=True)
+        got_small = m(c1.to(DEV), c2.to(DEV), cm.to(DEV), cm.to(DEV), test_mode=True)
+        got_list = m(c1.to(DEV), c2.to(DEV), cm.to(DEV), cm.to(DEV))
+    assert got_small.shape == (2, 2, 100, 180) and got_list[0].shape == (2, 2, 32, 48)
+    assert (m.origin_H, m.origin_W, m.new_H, m.new_W) == (100, 180, 128, 192)
+    close(got_small.cpu(), ref_small, tol=2e-4, what="test_mode flow after pre-resize")

@@ -1,0 +1,31 @@
+"""One-off check of BASELINE config 5 (B=1, 540x960 padded to 544x960, iters=32): HIP path vs the CPU oracle."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from argparse import Namespace
+import torch
+from focusflow_official_amd import FF_RAFT_FUSION
+from focusflow_official_amd.utils import InputPadder
+from oracle import ffraft_ref as orc
+from oracle.weights import det_tensor
+
+iters = int(os.environ.get("ITERS", 32))
+cfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"), MODEL=Namespace(FUSION_TYPE="1x1conv", LOAD_MODULE_TO_BRANCH=False))
+m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg)
+sd = {k: det_tensor(k, v.shape) for k, v in m.state_dict().items()}
+m.load_state_dict(sd)
+m = m.cuda().eval()
+inp = orc.shifted_pair(1, 540, 960, seed=3)
+pad = InputPadder(inp[0].shape)
+pin = pad.pad(*inp)
+with torch.no_grad():
+    for _ in range(2):
+        t0 = time.time()
+        fl, fu = m(*[t.cuda() for t in pin], raft_iters=iters, test_mode=True)
+        torch.cuda.synchronize()
+        print(f"hip: {1e3 * (time.time() - t0):.1f} ms, |flow|max {fu.abs().max().item():.3f}", flush=True)
+    torch.set_num_threads(int(os.environ.get("THREADS", 16)))
+    t0 = time.time()
+    rl, ru = orc.ffraft_forward(sd, *pin, raft_iters=iters, test_mode=True)
+    print(f"oracle: {time.time() - t0:.1f} s", flush=True)
+d = (pad.unpad(fu.cpu()) - pad.unpad(ru)).abs().max().item()
+print(f"C5 540x960 it{iters}: max |flow_up - oracle| = {d:.3e} px ({'OK' if d < 1e-3 else 'FAIL'} at 1e-3)")
