@@ -192,7 +192,7 @@ def train_mode(args, world, rank, local_rank, device):
             "metric": "training frame-pairs/sec FF-RAFT 368x496 iters=12 (fwd+MixLoss+bwd+AdamW)",
             "value": round(pairs / elapsed, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (forward convs: " + ops_precision() + "; backward fp32 MFMA)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (forward convs: " + ops_precision() + "; backward convs: f16x3 with power-of-two gradient scaling; corr-volume backward fp32 MFMA)",
             "data": "synthetic",
             "config": {"workload": f"FF-RAFT training step, {args.batch} pairs/GPU {h}x{w}, iters={args.iters}, MixLoss "
                                    f"(k=1, sigma=0.01, lamda=1), AdamW + OneCycleLR, clip 1.0 (BASELINE configs[2] shape)",

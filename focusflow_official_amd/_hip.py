@@ -26,7 +26,7 @@ class FFConvParams(C.Structure):
         ("y_gstride", _ll), ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
         ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
         ("act", C.c_int), ("act_res", C.c_int), ("w_format", C.c_int),
-        ("dil_h", C.c_int), ("dil_w", C.c_int),
+        ("dil_h", C.c_int), ("dil_w", C.c_int), ("x_amax", _fp),
     ]
 
 
@@ -51,10 +51,10 @@ _SIGS = {
     "ff_upsample_flow": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_nhwc_to_nchw": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     # backward
-    "ff_conv2d_wgrad": [C.POINTER(FFConvParams), _fp, _ll, _fp],
+    "ff_conv2d_wgrad": [C.POINTER(FFConvParams), _fp, _ll, _fp, _fp],
     "ff_unpack_conv_wgrad": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "ff_pack_conv_weight_dgrad": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp],
-    "ff_act_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, C.c_int, C.c_float, _fp],
+    "ff_act_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp],
     "ff_dilate2": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_norm_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp, _fp,
                     C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],

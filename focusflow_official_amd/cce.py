@@ -62,8 +62,10 @@ class PackedConv:
         return self.w, self.b
 
     def get_dgrad(self):
-        """Weights of the input-gradient convolution: [cin_pad][KH][KW][cout_pad], flipped + transposed."""
-        key = tuple((c.weight._version, c.weight.data_ptr()) for c in self.convs)
+        """Weights of the input-gradient convolution: [cin_pad][KH][KW][cout_pad], flipped + transposed, in the
+        active conv format (fp32 rows, or fp16-split rows: the dgrad then runs on the f16 matrix pipe with the
+        gradient scaled by a power of two, see FFConvParams.x_amax).  Returns (rows, format)."""
+        key = (ops.conv_precision(),) + tuple((c.weight._version, c.weight.data_ptr()) for c in self.convs)
         if key != self._dkey:
             cout_pad = (self.cout + 3) // 4 * 4
             self.wd = torch.zeros((self.cin_pad, self.kh * self.kw * cout_pad), dtype=torch.float32,
@@ -72,8 +74,11 @@ class PackedConv:
             for c in self.convs:
                 ops.pack_conv_weight_dgrad(c.weight.detach(), self.wd, cout_pad, off)
                 off += c.out_channels
+            self.dfmt = ops.w_format()
+            if self.dfmt != 0:
+                self.wd = ops.pack_split(self.wd)
             self._dkey = key
-        return self.wd
+        return self.wd, self.dfmt
 
     def __call__(self, xs, act=ACT_NONE, **kw):
         w, b = self.get()

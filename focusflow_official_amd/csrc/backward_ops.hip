@@ -20,9 +20,12 @@ __device__ __forceinline__ float act_grad_from_output(float y, int act) {
 }
 
 // g[c] = dy[c] * act'(y[c]) * scale for c < C, 0 for C <= c < Cpad
+// amax (nullable, caller zeroes): bits of max|g| - the power-of-two scale of the f16 dgrad (FFConvParams.x_amax)
 __global__ void act_bwd_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ y, int y_ld,
-                               float* __restrict__ g, int g_ld, long long npix, int C, int Cpad, int act, float scale) {
+                               float* __restrict__ g, int g_ld, long long npix, int C, int Cpad, int act, float scale,
+                               unsigned int* __restrict__ amax) {
     const long long total = npix * Cpad;
+    float mx = 0.f;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long p = i / Cpad;
         const int c = (int)(i - p * Cpad);
@@ -32,6 +35,21 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, int dy_ld, const fl
             if (act != FF_ACT_NONE) v *= act_grad_from_output(y[p * y_ld + c], act);
         }
         g[p * g_ld + c] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    if (amax) {     // non-negative floats order like their bit patterns; max is order-independent (deterministic).
+        __shared__ float wmax[4];   // ONE atomic per block: same-address atomics serialise at the memory side
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            // the running maximum only grows: a (possibly stale) plain read skips almost every atomic - same-address
+            // atomics serialise at ~10 ns each, 4096 of them would cost more than the kernel itself
+            if (mx > 0.f && mx < INFINITY && __float_as_uint(mx) > *reinterpret_cast<volatile unsigned int*>(amax))
+                atomicMax(amax, __float_as_uint(mx));
+        }
     }
 }
 
@@ -396,10 +414,10 @@ inline int grid_for(long long total) {
 }  // namespace
 
 extern "C" int ff_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* g, int g_ld, long long npix,
-                          int C, int Cpad, int act, float scale, void* stream) {
+                          int C, int Cpad, int act, float scale, unsigned int* amax, void* stream) {
     FF_REQUIRE(dy && g && npix > 0 && C > 0 && Cpad >= C && g_ld >= Cpad && dy_ld >= C, "ff_act_bwd: bad argument");
     FF_REQUIRE(act == FF_ACT_NONE || (y && y_ld >= C), "ff_act_bwd: activation needs the forward output");
-    act_bwd_kernel<<<grid_for(npix * Cpad), 256, 0, static_cast<hipStream_t>(stream)>>>(dy, dy_ld, y, y_ld, g, g_ld, npix, C, Cpad, act, scale);
+    act_bwd_kernel<<<grid_for(npix * Cpad), 256, 0, static_cast<hipStream_t>(stream)>>>(dy, dy_ld, y, y_ld, g, g_ld, npix, C, Cpad, act, scale, amax);
     return ff::check_launch("ff_act_bwd");
 }
 

@@ -47,6 +47,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
     constexpr int TH = 4 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FFConvParams& p = a.p;
+    float xs, xinv;
+    ff::input_scale(p.x_amax, xs, xinv);       // 1, 1 unless the caller passed max|x| (gradients: dgrad on the f16 pipe)
     const int KH = p.KH, KW = p.KW, PH = TH + KH - 1, PW = TW + KW - 1, NPIX = PH * PW;
     char* sP = smem;                          // [NPIX][128 B] patch, split format
     char* sW = smem + ((NPIX * ROWB + 255) & ~255);   // [2][BN][128 B] weights of one (tap, ci-chunk)
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
             const int row = prow[i];
             if (row < NPIX) {
                 f16x4 h0, h1;
-                split4(rp[i], h0, h1);
+                split4(rp[i] * xs, h0, h1);
                 *reinterpret_cast<f16x4*>(sP + row * ROWB + swz(row, pc) * 16 + half) = h0;
                 if (TERMS == 3) *reinterpret_cast<f16x4*>(sP + row * ROWB + swz(row, 4 + pc) * 16 + half) = h1;
             }
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
                 const long long m = ((long long)bimg * H + y) * W + x;
                 float v = acc[t][r];
                 if (TERMS == 3) v += accx[t][r] * (1.f / 2048.f);
-                v += bias;
+                v = v * xinv + bias;
                 v *= p.out_scale;
                 if (p.ch_scale) v = v * cs + ct;
                 v = ff::apply_act(v, p.act);

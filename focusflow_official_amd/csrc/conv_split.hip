@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
     char* sB = smem + 2 * BM * ROWB;        // [2][BN][128 B]
 
     const FFConvParams& p = a.p;
+    float xs, xinv;
+    ff::input_scale(p.x_amax, xs, xinv);       // 1, 1 unless the caller passed max|x| (gradients: dgrad on the f16 pipe)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int nblk = gridDim.x;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
         for (int i = 0; i < LA; ++i) {
             const int row = rbase + 32 * i;
             f16x4 h0, h1;
-            split4(ra[i], h0, h1);
+            split4(ra[i] * xs, h0, h1);
             *reinterpret_cast<f16x4*>(dA + row * ROWB + swz(row, pc) * 16 + half) = h0;
             if (TERMS == 3) *reinterpret_cast<f16x4*>(dA + row * ROWB + swz(row, 4 + pc) * 16 + half) = h1;
         }
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
                 if (m >= a.M) continue;
                 float v = acc[i][j][r];
                 if (TERMS == 3) v += accx[i][j][r] * (1.f / 2048.f);
-                v += bias;
+                v = v * xinv + bias;
                 v *= p.out_scale;
                 if (p.ch_scale) v = v * cs + ct;
                 v = ff::apply_act(v, p.act);

@@ -197,7 +197,7 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ src, float* __restri
 
 }  // namespace
 
-extern "C" int ff_conv2d_wgrad(const FFConvParams* pp, float* dw, long long dw_gstride, void* stream) {
+extern "C" int ff_conv2d_wgrad(const FFConvParams* pp, float* dw, long long dw_gstride, float* db, void* stream) {
     FF_REQUIRE(pp && dw, "ff_conv2d_wgrad: null pointer");
     const FFConvParams& p = *pp;
     FF_REQUIRE(p.x[0] && p.y, "ff_conv2d_wgrad: null x/dy");
@@ -217,6 +217,9 @@ extern "C" int ff_conv2d_wgrad(const FFConvParams* pp, float* dw, long long dw_g
     FF_REQUIRE(Ho == p.Ho && Wo == p.Wo, "ff_conv2d_wgrad: output size mismatch");
     const long long M = (long long)p.B * Ho * Wo;
     FF_REQUIRE(M < (1ll << 30), "ff_conv2d_wgrad: too many pixels");
+    const bool split = p.w_format != FF_W_F32 && p.groups == 1;
+    FF_REQUIRE(!db || split, "ff_conv2d_wgrad: the bias gradient is produced by the split-format kernel only (groups == 1)");
+    if (split) return ff::conv2d_wgrad_split(p, dw, db, (int)M, cin, static_cast<hipStream_t>(stream));
     WgArgs a;
     a.p = p;
     a.dw = dw;

@@ -29,6 +29,20 @@ inline int check_launch(const char* what) {
 }
 
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s);  // conv_split.hip
+// power-of-two input scale of the split formats (FFConvParams.x_amax): xs puts max|x| at 2^10, xinv undoes it
+__device__ __forceinline__ void input_scale(const unsigned int* x_amax, float& xs, float& xinv) {
+    xs = 1.f; xinv = 1.f;
+    if (x_amax) {
+        const int e = (int)((*x_amax >> 23) & 0xffu);          // biased exponent of max|x|
+        if (e > 0 && e < 255) {
+            int k = 137 - e;                                       // 2^(127+10-e)
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            xs = __uint_as_float((unsigned)(127 + k) << 23);
+            xinv = __uint_as_float((unsigned)(127 - k) << 23);
+        }
+    }
+}
+int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int cin, hipStream_t s);   // conv_wgrad_split.hip
 int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s);         // conv_patch.hip; 1 = not eligible
 int conv2d_fwd_ws(const FFConvParams& p, int cin, hipStream_t s);            // conv_ws.hip (wave-specialised); 1 = not eligible
 

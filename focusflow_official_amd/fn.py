@@ -55,13 +55,13 @@ class ConvFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         xs, y = list(saved[:nseg]), saved[nseg]
         dy = _dense(dy)
-        g = ops.act_bwd(dy, y, act, ctx.out_scale, pc.cout)            # (B,Ho,Wo,Cpad), zero padded
+        g, amax = ops.act_bwd(dy, y, act, ctx.out_scale, pc.cout, want_amax=True)   # (B,Ho,Wo,Cpad), zero padded
         grads: List[Optional[Tensor]] = [None] * 7
         # input gradient: forward conv over g with flipped/transposed weights
         need_dx = any(ctx.needs_input_grad[7 + i] for i in range(nseg))
         dxs = [None] * nseg
         if need_dx:
-            wd = pc.get_dgrad()
+            wd, dfmt = pc.get_dgrad()
             cin_tot = sum(x.shape[3] for x in xs)
             b, h, w, _ = xs[0].shape
             gi = g
@@ -69,7 +69,8 @@ class ConvFn(torch.autograd.Function):
                 gi = ops.dilate2(g, h + 2 * pc.pad[0] - pc.kh + 1, w + 2 * pc.pad[1] - pc.kw + 1)
             elif pc.stride != 1:
                 raise NotImplementedError("stride > 2")
-            dx = ops.conv2d([gi], wd, None, cin_tot, pc.kh, pc.kw, 1, (pc.kh - 1 - pc.pad[0], pc.kw - 1 - pc.pad[1]))
+            dx = ops.conv2d([gi], wd, None, cin_tot, pc.kh, pc.kw, 1, (pc.kh - 1 - pc.pad[0], pc.kw - 1 - pc.pad[1]),
+                            w_fmt=dfmt, x_amax=amax if dfmt else None)
             off = 0
             for i, x in enumerate(xs):
                 if ctx.needs_input_grad[7 + i]:
@@ -81,8 +82,9 @@ class ConvFn(torch.autograd.Function):
         # parameter gradients
         base = 7 + nseg + (1 if ctx.has_res else 0)
         need_w = any(ctx.needs_input_grad[base:])
-        dwp = ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad) if need_w else None
-        db = ops.channel_sum(g, pc.cout) if need_w else None
+        dwp = db = None
+        if need_w:   # weight + bias gradient in one launch (f16 matrix pipe unless the conv precision is fp32)
+            dwp, db = ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True)
         off = 0
         for j, cv in enumerate(pc.convs):
             co = cv.out_channels

@@ -128,9 +128,11 @@ def pack_conv_weight(w_oihw: Tensor, dst: Tensor, cin_pad: int, cout_offset: int
 def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: int, kh: int, kw: int,
            stride: int = 1, pad=(0, 0), act: int = ACT_NONE, out: Optional[Tensor] = None,
            res: Optional[Tensor] = None, act_res: int = ACT_NONE, ch_scale: Optional[Tensor] = None,
-           ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0, dilation: int = 1) -> Tensor:
+           ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0, dilation: int = 1,
+           x_amax: Optional[Tensor] = None) -> Tensor:
     """Convolution over the channel-concatenation of `xs` (see FFConvParams).  `wpack` is fp32
-    [Cout][K] (w_fmt 0) or the split rows of pack_split (w_fmt 1/2)."""
+    [Cout][K] (w_fmt 0) or the split rows of pack_split (w_fmt 1/2).  x_amax: device word holding the bits of
+    max|x| (act_bwd): the split formats then scale the input by a power of two so that gradients fit fp16."""
     if isinstance(pad, int):
         pad = (pad, pad)
     x0 = xs[0]
@@ -164,6 +166,7 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     p.KH, p.KW, p.stride, p.pad_h, p.pad_w = kh, kw, stride, pad[0], pad[1]
     p.act, p.act_res, p.w_format = act, act_res, w_fmt
     p.dil_h = p.dil_w = dilation
+    p.x_amax = x_amax.data_ptr() if x_amax is not None else None
     assert out.shape[:3] == (b, ho, wo) and out.shape[3] >= cout
     _hip.call("ff_conv2d_fwd", C.byref(p), _stream())
     return out
@@ -423,15 +426,25 @@ def _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo):
     return p
 
 
-def conv2d_wgrad(xs: Sequence[Tensor], g: Tensor, cout: int, kh: int, kw: int, stride: int, pad) -> Tensor:
-    """packed dW [cout][kh*kw*cin] from inputs `xs` and output gradient g (B,Ho,Wo,>=cout, ld % 4 == 0)."""
+def conv2d_wgrad(xs: Sequence[Tensor], g: Tensor, cout: int, kh: int, kw: int, stride: int, pad,
+                 g_amax: Optional[Tensor] = None, want_db: bool = False):
+    """packed dW [cout][kh*kw*cin] from inputs `xs` and output gradient g (B,Ho,Wo,>=cout, ld % 4 == 0).
+    With g_amax (bits of max|g|, act_bwd) and a split conv format the kernel runs on the f16 matrix pipe and can
+    also return the bias gradient: -> dW, or (dW, db) when want_db."""
     b, h, w, _ = xs[0].shape
     _, ho, wo, _ = g.shape
     cin = sum(x.shape[3] for x in xs)
     dw = torch.zeros((cout, kh * kw * cin), dtype=torch.float32, device=g.device)
     p = _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo)
     p.y, p.y_ld = g.data_ptr(), _ld(g)
-    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(dw), 0, _stream())
+    fmt = w_format() if g_amax is not None else 0
+    db = None
+    if fmt:
+        p.w_format, p.x_amax = fmt, g_amax.data_ptr()
+        db = torch.zeros(cout, dtype=torch.float32, device=g.device) if want_db else None
+    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(dw), 0, _p(db), _stream())
+    if want_db:
+        return dw, (db if db is not None else channel_sum(g, cout))
     return dw
 
 
@@ -448,14 +461,16 @@ def pack_conv_weight_dgrad(w_oihw: Tensor, dst: Tensor, cout_pad: int, cout_offs
     _hip.call("ff_pack_conv_weight_dgrad", _p(w_oihw.contiguous()), co, ci, kh, kw, _p(dst), cout_pad, cout_offset, _stream())
 
 
-def act_bwd(dy: Tensor, y: Optional[Tensor], act: int, scale: float, c: int) -> Tensor:
-    """g = dy*act'(y)*scale over the first c channels, zero-padded to a multiple of 4."""
+def act_bwd(dy: Tensor, y: Optional[Tensor], act: int, scale: float, c: int, want_amax: bool = False):
+    """g = dy*act'(y)*scale over the first c channels, zero-padded to a multiple of 4.
+    want_amax: also return a device word with the bits of max|g| (-> conv2d(x_amax=...))."""
     b, h, w, _ = dy.shape
     cpad = (c + 3) // 4 * 4
     g = empty_nhwc(b, h, w, cpad, dy)
+    amax = torch.zeros(1, dtype=torch.int32, device=dy.device) if want_amax else None
     _hip.call("ff_act_bwd", _p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(g), cpad, b * h * w, c, cpad,
-              act, scale, _stream())
-    return g
+              act, scale, _p(amax), _stream())
+    return (g, amax) if want_amax else g
 
 
 def dilate2(g: Tensor, hd: int, wd: int) -> Tensor:
@@ -535,7 +550,7 @@ def corr_volume_bwd(dvol: Tensor, f1: Tensor, f2: Tensor):
     p.KH = p.KW = p.stride = 1
     p.out_scale = s
     p.y, p.y_ld, p.y_gstride = dvol.data_ptr(), q, q * q
-    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(df2), q * c, _stream())
+    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(df2), q * c, None, _stream())
     return df1, df2.view(b, h, w, c)
 
 

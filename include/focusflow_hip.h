@@ -83,6 +83,9 @@ typedef struct FFConvParams {
     int act_res;                       /* FF_ACT_*, after the residual add              */
     int w_format;                      /* FF_W_*; for the split formats w_gstride counts 4-byte words */
     int dil_h, dil_w;                  /* dilation (0 = 1): FF-PWC refiner, ff_pwcnet.py:350-364          */
+    const unsigned int* x_amax;        /* NULL, or device word = bits of max|x| over the input (ff_act_bwd): the split
+                                        * formats then read x * 2^k (k puts the maximum at 2^10) and undo it in the
+                                        * epilogue - gradients lie far below fp16's range (dgrad on the f16 pipe)   */
 } FFConvParams;
 
 int ff_conv2d_fwd(const FFConvParams* p, void* stream);
@@ -178,7 +181,10 @@ int ff_nhwc_to_nchw(const float* src, int ld, float* dst, int B, int H, int W, i
  * `p` describes the forward conv (x segments, geometry); p->y / p->y_ld carry dY
  * (channels rounded up to a multiple of 4).  groups = B with a 1x1 kernel gives
  * d(corr volume)/d(fmap2) (BmmBackward of corr.py:58). */
-int ff_conv2d_wgrad(const FFConvParams* p, float* dw, long long dw_gstride, void* stream);
+/* p->w_format = FF_W_F16X3 / FF_W_F16 (groups == 1) runs it on the f16 matrix pipe with split operands; dY is
+ * then scaled by the power of two derived from p->x_amax (= bits of max|dY|, from ff_act_bwd), and `db`
+ * (nullable, CALLER ZEROES) receives the bias gradient sum_pixels dY[pix][co].  db must be NULL for FF_W_F32. */
+int ff_conv2d_wgrad(const FFConvParams* p, float* dw, long long dw_gstride, float* db, void* stream);
 /* packed dW rows [cout_offset, cout_offset+Cout) -> OIHW gradient of one nn.Conv2d */
 int ff_unpack_conv_wgrad(const float* packed, int Cout, int Cin, int KH, int KW, int cin_pad,
                          int cout_offset, float* dw_oihw, void* stream);
@@ -188,7 +194,7 @@ int ff_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int KH, in
                               int cout_pad, int cout_offset, void* stream);
 /* g = dy * act'(y) * scale (activation derivative from the forward OUTPUT), zero-padded to Cpad */
 int ff_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* g, int g_ld,
-               long long npix, int C, int Cpad, int act, float scale, void* stream);
+               long long npix, int C, int Cpad, int act, float scale, unsigned int* amax, void* stream);
 /* zero-dilation by 2: dst[b][2y][2x][:] = src[b][y][x][:] (input gradient of stride-2 convs) */
 int ff_dilate2(const float* src, int src_ld, float* dst, int B, int Ho, int Wo, int Hd, int Wd, int C,
                void* stream);
