@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--skip-unused-upsample", action="store_true",
+                    help="NOT the default / not the headline number: compute the mask head + convex up-sampling only for "
+                         "the last iteration (the reference discards the other 11 in test_mode); outputs are bit-identical")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = BASELINE configs[1] (the headline metric); train = configs[2]-shaped step "
                          "(forward + MixLoss + backward + clip + AdamW, DDP over RCCL when --gpus > 1)")
@@ -245,6 +248,7 @@ def main():
         return train_mode(args, world, rank, local_rank, device)
     torch.manual_seed(1234)
     model = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
+    model.flow_net.skip_unused_upsample = bool(args.skip_unused_upsample)
     # weak scaling: every rank owns args.batch independent pairs of the global batch
     lo, hi = shard_units(args.batch * world, world, rank)
     batch = synthetic_batch(hi - lo, args.height, args.width, 1234 + rank, device)
@@ -288,7 +292,7 @@ def main():
             "vs_baseline": None, "dtype": DTYPES[ops.conv_precision()], "data": "synthetic",
             "config": {"workload": f"FF-RAFT forward (test_mode), {args.batch} pairs/GPU {args.height}x{args.width}, "
                                    f"iters={args.iters}, random-init weights, ORB-like masks (BASELINE configs[1])",
-                       "pairs_per_gpu": args.batch, "conv_precision": ops.conv_precision(), "hipgraph": bool(args.graph),
+                       "pairs_per_gpu": args.batch, "conv_precision": ops.conv_precision(), "hipgraph": bool(args.graph), "skip_unused_upsample": bool(args.skip_unused_upsample),
                        "parallelism": f"dp{world} (independent shards, no collective)"},
             "roofline": {"kernel": "lookup_wave_kernel (ff_corr_lookup_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -15,6 +15,7 @@
 // Block tile 128 co x 64 k, 32-pixel chunks double-buffered in LDS, pixel range split over blockIdx.y; the
 // 128 x 64 result goes through LDS so that every atomic wave-instruction adds 256 contiguous bytes of dW.
 #include <algorithm>
+#include <cstdlib>
 #include "ff_common.h"
 
 namespace {
@@ -222,7 +223,8 @@ int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int c
     a.n2_tiles = (a.K + BN2 - 1) / BN2;
     const int nchunks = (M + RK - 1) / RK;
     const long long tiles = (long long)a.n1_tiles * a.n2_tiles;
-    int splits = (int)((1536 + tiles - 1) / tiles);       // ~3 blocks per CU x 2 rounds
+    static const int target = getenv("FF_WGRAD_BLOCKS") ? atoi(getenv("FF_WGRAD_BLOCKS")) : 1536;   // tuning knob
+    int splits = (int)((target + tiles - 1) / tiles);
     if (splits > nchunks) splits = nchunks;
     if (splits < 1) splits = 1;
     a.chunks_per_split = (nchunks + splits - 1) / splits;

@@ -79,16 +79,23 @@ class RAFT(nn.Module):
         flow_predictions = []
         flow_up = None
         flow4 = None
-        for _ in range(iters):
+        # The reference up-samples every iteration and, in test_mode, throws 11 of the 12 results away
+        # (raft.py:226-236).  Default: do the same work.  skip_unused_upsample (opt-in, inference only) computes
+        # the mask head + convex up-sampling for the last iteration only; flow_low / flow_up are bit-identical.
+        lazy = bool(getattr(self, "skip_unused_upsample", False)) and test_mode and not taped
+        for it in range(iters):
             # coords1 is advanced in place by ff_coords_step (raw pointer: autograd cannot see it), so a
             # recorded lookup keeps its own snapshot for the backward scatter
             corr = corr_fn(coords1.clone() if taped else coords1)
             flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
             ops.coords_step(coords1, None, flow4, None)                   # flow = coords1 - coords0
             fill = lambda motion, c=coords1: ops.coords_step(c, None, None, motion[..., 126:])  # noqa: E731
-            net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill)
+            need_mask = not lazy or it == iters - 1
+            net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask)
             flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
             ops.coords_step(coords1, delta.detach(), flow4, None)         # coords1 += delta
+            if not need_mask:
+                continue
             if fn.recording(delta, up_mask):
                 flow_up = fn.UpsampleFn.apply(flow4, delta, up_mask)
             else:

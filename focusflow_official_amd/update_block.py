@@ -78,13 +78,17 @@ class BasicUpdateBlock(nn.Module):
         self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True),
                                   nn.Conv2d(256, 64 * 9, 1, padding=0))
         self._heads = PackedConv([self.flow_head.conv1, self.mask[0]])
+        self._head1 = PackedConv([self.flow_head.conv1])      # flow head alone (RAFT.skip_unused_upsample)
         self._flow2 = PackedConv([self.flow_head.conv2])
         self._mask2 = PackedConv([self.mask[2]])
 
-    def run(self, net, inp, corr, flow4, fill_flow):
-        """-> (net, up_mask, delta_flow), all NHWC.  update.py:126-135."""
+    def run(self, net, inp, corr, flow4, fill_flow, need_mask=True):
+        """-> (net, up_mask, delta_flow), all NHWC.  update.py:126-135.  need_mask=False (inference only, opt-in)
+        leaves out the up-sampling mask head when the caller is going to discard it."""
         motion = self.encoder.run(flow4, corr, fill_flow)
         net = self.gru.run(net, [inp, motion])
+        if not need_mask:
+            return net, None, fn.conv(self._flow2, fn.conv(self._head1, net, act=ACT_RELU))
         hid = fn.conv(self._heads, net, act=ACT_RELU)                      # [flow-head 256 | mask-head 256]
         delta = fn.conv(self._flow2, hid[..., :256])
         up_mask = fn.conv(self._mask2, hid[..., 256:], out_scale=0.25)     # ".25 * self.mask(net)"

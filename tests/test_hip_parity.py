@@ -387,6 +387,19 @@ def test_config1_384x512_and_batch_consistency(det_sd):
         close(fu8[i].cpu(), flow_up[0].cpu(), rtol=0, atol=2e-4, what=f"batch sample {i}")
 
 
+def test_skip_unused_upsample_is_bit_identical(det_sd):
+    """Opt-in inference shortcut: mask head + convex up-sampling for the last iteration only (the reference throws
+    the other results away in test_mode, raft.py:226-236) must not change a single bit of either output."""
+    m = _model(det_sd)
+    inp = [t.to(DEV) for t in orc.shifted_pair(2, 128, 192, seed=1)]
+    with torch.no_grad():
+        fl0, fu0 = m(*inp, raft_iters=5, test_mode=True)
+        m.flow_net.skip_unused_upsample = True
+        fl1, fu1 = m(*inp, raft_iters=5, test_mode=True)
+        m.flow_net.skip_unused_upsample = False
+    assert torch.equal(fl0, fl1) and torch.equal(fu0, fu1)
+
+
 def test_config5_shape_540x960_padded(det_sd):
     """BASELINE config 5's frame size: 540x960 replicate-padded to 544x960 (68x120 at 1/8: level 3 is 8x15, odd
     widths at two pyramid levels), against the CPU oracle.  Few iterations on purpose: with synthetic weights the
