@@ -205,20 +205,36 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
         const float ct = p.ch_scale ? p.ch_shift[n] : 0.f;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
+            // Three passes per tile: values first (this frees the accx registers), then ALL residual loads of the
+            // tile together (res may alias y as far as the compiler knows: inside the store loop they become 16
+            // serial load -> store round trips per lane), then add + store.
+            float vv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;        // 0..31: row = pi>>4, col = pi&15
-                const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + (pi & 15);
-                if (y >= H || x >= W) continue;
-                const long long m = ((long long)bimg * H + y) * W + x;
                 float v = acc[t][r];
                 if (TERMS == 3) v += accx[t][r] * (1.f / 2048.f);
                 v = v * xinv + bias;
                 v *= p.out_scale;
                 if (p.ch_scale) v = v * cs + ct;
-                v = ff::apply_act(v, p.act);
-                if (p.res) v = ff::apply_act(v + p.res[m * p.res_ld + n], p.act_res);
-                p.y[m * p.y_ld + n] = v;
+                vv[r] = ff::apply_act(v, p.act);
+            }
+            if (p.res) {
+                float rr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + (pi & 15);
+                    rr[r] = (y < H && x < W) ? p.res[(((long long)bimg * H + y) * W + x) * p.res_ld + n] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[r] = ff::apply_act(vv[r] + rr[r], p.act_res);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;        // 0..31: row = pi>>4, col = pi&15
+                const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + (pi & 15);
+                if (y >= H || x >= W) continue;
+                p.y[(((long long)bimg * H + y) * W + x) * p.y_ld + n] = vv[r];
             }
         }
     }

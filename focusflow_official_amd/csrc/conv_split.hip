@@ -273,19 +273,33 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
         const float ct = p.ch_scale ? p.ch_shift[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // Three passes per tile: values first (frees the accx registers), then ALL residual loads of the tile
+            // together (the compiler must assume res aliases y: inside the store loop they become 16 serial
+            // load -> store round trips per lane), then add + store.
+            float vv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int m = m0 + (wm * TM + i) * 32 + row;
-                if (m >= a.M) continue;
                 float v = acc[i][j][r];
                 if (TERMS == 3) v += accx[i][j][r] * (1.f / 2048.f);
                 v = v * xinv + bias;
                 v *= p.out_scale;
                 if (p.ch_scale) v = v * cs + ct;
-                v = ff::apply_act(v, p.act);
-                if (p.res) v = ff::apply_act(v + p.res[(long long)m * p.res_ld + n], p.act_res);
-                yb[(long long)m * p.y_ld + n] = v;
+                vv[r] = ff::apply_act(v, p.act);
+            }
+            if (p.res) {
+                float rr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    rr[r] = m < a.M ? p.res[(long long)m * p.res_ld + n] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[r] = ff::apply_act(vv[r] + rr[r], p.act_res);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < a.M) yb[(long long)m * p.y_ld + n] = vv[r];
             }
         }
     }

@@ -1,0 +1,58 @@
+"""Per-layer table of the forward convolutions: record every ops.conv2d call of one FF-RAFT step (B=8, 384x512, 12
+iterations), replay each distinct shape in isolation and print time, useful TFLOP/s and minimum-traffic GB/s, sorted by
+their share of the step."""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from argparse import Namespace
+import torch
+from focusflow_official_amd import FF_RAFT_FUSION, ops
+
+calls = collections.OrderedDict()
+orig = ops.conv2d
+
+
+def rec(xs, wpack, bias, cout, kh, kw, stride=1, pad=(0, 0), **kw_):
+    out = orig(xs, wpack, bias, cout, kh, kw, stride, pad, **kw_)
+    key = (tuple(tuple(x.shape) for x in xs), cout, kh, kw, stride, pad if isinstance(pad, tuple) else (pad, pad),
+           kw_.get("w_fmt", 0), kw_.get("res") is not None)
+    if key not in calls:
+        calls[key] = dict(n=0, args=(xs, wpack, bias, cout, kh, kw, stride, pad, dict(kw_)))
+    calls[key]["n"] += 1
+    return out
+
+
+cfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"), MODEL=Namespace(FUSION_TYPE="1x1conv", LOAD_MODULE_TO_BRANCH=False))
+m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg).cuda().eval()
+b = int(os.environ.get("B", 8))
+g = torch.Generator().manual_seed(0)
+im = [torch.randint(0, 256, (b, 3, 384, 512), generator=g).float().cuda() for _ in range(2)]
+mk = [((torch.rand(b, 1, 384, 512, generator=g) < 0.0025).float() * 255).cuda() for _ in range(2)]
+import focusflow_official_amd.cce as cce, focusflow_official_amd.fn as fn, focusflow_official_amd.update_block as ub
+ops.conv2d = rec
+with torch.no_grad():
+    m(im[0], im[1], mk[0], mk[1], raft_iters=12, test_mode=True)
+ops.conv2d = orig
+rows = []
+for key, c in calls.items():
+    xs, wpack, bias, cout, kh, kw, stride, pad, kw_ = c["args"]
+    kw_ = {k: v for k, v in kw_.items() if k != "out"}
+    for _ in range(2):
+        out = orig(xs, wpack, bias, cout, kh, kw, stride, pad, **kw_)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        out = orig(xs, wpack, bias, cout, kh, kw, stride, pad, **kw_)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    cin = sum(x.shape[3] for x in xs)
+    npx = out.shape[0] * out.shape[1] * out.shape[2]
+    fl = 2.0 * npx * cout * cin * kh * kw
+    by = (sum(x.numel() for x in xs) + out.numel() * (2 if key[-1] else 1)) * 4
+    rows.append((us * c["n"], us, c["n"], key, fl / us / 1e6, by / us / 1e3))
+tot = sum(r[0] for r in rows)
+print(f"total conv time (isolated replay) {tot / 1e3:.2f} ms per step")
+for t, us, n, key, tf, gb in sorted(rows, reverse=True)[:40]:
+    shp = "+".join(str(s[3]) for s in key[0])
+    print(f"{t / 1e3:6.2f} ms {100 * t / tot:5.1f}%  n={n:3d} {us:7.1f} us  {tf:6.1f} TF/s {gb:6.0f} GB/s  {key[0][0][1]}x{key[0][0][2]} cin {shp:>11} -> {key[1]:3d} k{key[2]}x{key[3]} s{key[4]} res={int(key[7])}")
