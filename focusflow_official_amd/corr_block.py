@@ -29,8 +29,19 @@ class CorrBlock:
             self._token = fn.PyramidFn.apply(vol, self, h, w)      # sets self.corr_pyramid
         else:
             self.corr_pyramid: List[torch.Tensor] = ops.corr_pyramid(ops.corr_volume(fmap1, fmap2), h, w)
+        # Inference: the lookup writes into a buffer whose channel count is padded to a multiple of 32 (324 -> 352,
+        # pad channels zero once), so that convc1 takes the block-uniform loader (32-channel chunks) of the conv
+        # kernel instead of the generic im2col one.  The buffer is reused by every iteration of this pair.
+        self._nk = num_levels * (2 * radius + 1) ** 2
+        self._padded = None
 
     def __call__(self, coords: torch.Tensor, want_taps: bool = False):
         if self._token is not None and not want_taps:
             return fn.LookupFn.apply(self._token, self, coords)
-        return ops.corr_lookup(self.corr_pyramid, coords, self.radius, want_taps)
+        if want_taps or torch.is_grad_enabled():
+            return ops.corr_lookup(self.corr_pyramid, coords, self.radius, want_taps)
+        if self._padded is None:
+            b, h, w, _ = coords.shape
+            self._padded = torch.zeros((b, h, w, (self._nk + 31) // 32 * 32), dtype=torch.float32, device=coords.device)
+        ops.corr_lookup(self.corr_pyramid, coords, self.radius, out=self._padded[..., :self._nk])
+        return self._padded

@@ -209,18 +209,22 @@ def corr_pyramid(vol: Tensor, h: int, w: int) -> List[Tensor]:
     return lv
 
 
-def corr_lookup(levels: List[Tensor], coords: Tensor, radius: int = 4, want_taps: bool = False):
-    """coords: (B, H, W, 2) [x, y].  Returns (B, H, W, L*(2r+1)^2) (+ int32 taps)."""
+def corr_lookup(levels: List[Tensor], coords: Tensor, radius: int = 4, want_taps: bool = False,
+                out: Optional[Tensor] = None):
+    """coords: (B, H, W, 2) [x, y].  Returns (B, H, W, L*(2r+1)^2) (+ int32 taps).  `out`: a (B,H,W,nk) view of a
+    wider buffer (the caller owns the channels beyond nk)."""
     _require_gpu(coords)
     b, h, w, _ = coords.shape
     assert coords.is_contiguous()
     nl = len(levels)
     nk = nl * (2 * radius + 1) ** 2
-    out = empty_nhwc(b, h, w, nk, coords)
+    if out is None:
+        out = empty_nhwc(b, h, w, nk, coords)
+    assert out.shape == (b, h, w, nk)
     taps = torch.empty((b * h * w, nl, 2, 2 * radius + 1), dtype=torch.int32, device=coords.device) if want_taps else None
     arr = (C.c_void_p * 4)(*[lv.data_ptr() for lv in levels] + [0] * (4 - nl))
     h0, w0 = levels[0].shape[-2:]
-    _timed_call("lookup", "ff_corr_lookup_fwd", arr, nl, radius, _p(coords), b * h * w, h0, w0, _p(out), nk, _p(taps), _stream())
+    _timed_call("lookup", "ff_corr_lookup_fwd", arr, nl, radius, _p(coords), b * h * w, h0, w0, _p(out), _ld(out), _p(taps), _stream())
     return (out, taps) if want_taps else out
 
 

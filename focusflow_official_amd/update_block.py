@@ -58,13 +58,15 @@ class BasicMotionEncoder(nn.Module):
         self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
         self._c1, self._c2 = PackedConv([self.convc1]), PackedConv([self.convc2])
+        self._c1p = PackedConv([self.convc1], (cor_planes + 31) // 32 * 32)     # lookup output padded to 352 channels
         self._f1, self._f2 = PackedConv([self.convf1], 4), PackedConv([self.convf2])
         self._cv = PackedConv([self.conv])
 
     def run(self, flow4, corr, fill_flow):
         """flow4: (B,H,W,4) zero-padded flow.  Returns motion (B,H,W,128): 126 conv channels, and
         `fill_flow(motion)` writes the flow into channels 126:128 (torch.cat([out, flow]), update.py:97)."""
-        cor = fn.conv(self._c2, fn.conv(self._c1, corr, act=ACT_RELU), act=ACT_RELU)
+        c1 = self._c1p if corr.shape[3] == self._c1p.cin_pad else self._c1
+        cor = fn.conv(self._c2, fn.conv(c1, corr, act=ACT_RELU), act=ACT_RELU)
         flo = fn.conv(self._f2, fn.conv(self._f1, flow4, act=ACT_RELU), act=ACT_RELU)
         return fn.conv(self._cv, [cor, flo], act=ACT_RELU, pad_out=True, fill_tail=fill_flow)
 
