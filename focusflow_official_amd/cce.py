@@ -55,7 +55,10 @@ class PackedConv:
                 if c.bias is not None:
                     self.b[off:off + c.out_channels].copy_(c.bias.detach())  # device memcpy
                 off += c.out_channels
-            self.fmt = ops.w_format()
+            # 1- and 2-channel 3x3 heads stay in fp32 rows: ff_conv2d_fwd runs them as dot products on the vector ALU
+            # (conv_small.hip) instead of wasting a 64-wide matrix tile on them
+            small = self.cout <= 2 and (self.kh, self.kw, self.stride) == (3, 3, 1) and self.pad == (1, 1)
+            self.fmt = 0 if small else ops.w_format()
             if self.fmt != 0:
                 self.w = ops.pack_split(self.w)
             self._key = key

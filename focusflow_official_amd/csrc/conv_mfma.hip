@@ -281,6 +281,7 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     FF_REQUIRE(p.w_format >= FF_W_F32 && p.w_format <= FF_W_F16, "ff_conv2d_fwd: bad w_format %d", p.w_format);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (p.w_format != FF_W_F32) return ff::conv2d_fwd_split(p, (int)M, cin, s);
+    if (const int rc = ff::conv2d_fwd_small(p, cin, s); rc != 1) return rc;    // 1- and 2-channel 3x3 heads: vector ALU
     KernArgs a;
     a.p = p;
     a.M = (int)M;

@@ -1,0 +1,121 @@
+// Direct 3x3 convolution for 1 or 2 output channels (flow head conv2 256 -> 2, update.py:13-14; SA's 2 -> 1
+// spatial map; FF-PWC's flow estimators): on a 64-wide MFMA tile such a conv wastes 97 % of the matrix work
+// (41 us for 0.23 GFLOP at 48x64x8).  Here it is a dot product on the vector ALU, exact fp32:
+//
+//   one wave = a run of RUN output pixels of one image row; lane = one group of 4 input channels (Cin <= 256 per
+//   pass, more passes for wider inputs); the 3x3 weights of the lane's channels stay in registers for the run;
+//   the input window slides along x, so each new pixel costs 3 coalesced float4 loads (1 KB per wave) instead
+//   of 9; per pixel and output channel the 64 partial sums are folded with xor-shuffles.
+#include "ff_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int RUN = 8;
+
+struct SArgs {
+    FFConvParams p;
+    int Cin, runs_x;
+};
+
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b, float acc) {
+    acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc); return fmaf(a[3], b[3], acc);
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_small_kernel(const SArgs a) {
+    const FFConvParams& p = a.p;
+    const int lane = threadIdx.x & 63;
+    const long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);       // (b, y, run)
+    const long long ntask = (long long)p.B * p.H * a.runs_x;
+    if (task >= ntask) return;
+    const int run = (int)(task % a.runs_x);
+    const int y = (int)((task / a.runs_x) % p.H);
+    const int b = (int)(task / ((long long)a.runs_x * p.H));
+    const int x0 = run * RUN;
+    const int H = p.H, W = p.W, K = 9 * a.Cin;
+
+    float mine[COUT];                        // lane i (< RUN) collects pixel x0 + i
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) mine[c] = 0.f;
+
+    // channel passes: lane's 4 channels at cpos = pass*256 + lane*4 of the concatenated input
+    for (int cbase = 0; cbase < a.Cin; cbase += 256) {
+        const int cpos = cbase + lane * 4;
+        const bool cok = cpos < a.Cin;
+        // which segment holds cpos (segments are multiples of 4 channels, so a float4 never straddles two)
+        const float* xp = nullptr;
+        int ld = 0, cs = cpos;
+        if (cok) {
+            const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
+            if (cs < c0) { xp = p.x[0]; ld = p.x_ld[0]; }
+            else if (cs < c01) { xp = p.x[1]; ld = p.x_ld[1]; cs -= c0; }
+            else { xp = p.x[2]; ld = p.x_ld[2]; cs -= c01; }
+        }
+        f32x4 w[COUT][9];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                w[c][t] = cok ? *reinterpret_cast<const f32x4*>(p.w + (long long)c * K + t * a.Cin + cpos) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto load = [&](int yy, int xx) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                v = *reinterpret_cast<const f32x4*>(xp + ((long long)(b * H + yy) * W + xx) * ld + cs);
+            return v;
+        };
+        f32x4 col[3][3];                     // col[slot][dy]: window columns x-1, x, x+1 rotate through 3 slots
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) { col[0][dy] = load(y - 1 + dy, x0 - 1); col[1][dy] = load(y - 1 + dy, x0); }
+#pragma unroll
+        for (int i = 0; i < RUN; ++i) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) col[(i + 2) % 3][dy] = load(y - 1 + dy, x0 + i + 1);
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+                float s = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) s = dot4(col[(i + dx) % 3][dy], w[c][dy * 3 + dx], s);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);      // fold the 64 lanes right away
+                if (lane == i) mine[c] += s;
+            }
+        }
+    }
+    const int x = x0 + lane;
+    if (lane < RUN && x < W) {
+        const long long m = ((long long)b * H + y) * W + x;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+            float v = mine[c] + (p.bias ? p.bias[c] : 0.f);
+            v *= p.out_scale;
+            if (p.ch_scale) v = v * p.ch_scale[c] + p.ch_shift[c];
+            v = ff::apply_act(v, p.act);
+            if (p.res) v = ff::apply_act(v + p.res[m * p.res_ld + c], p.act_res);
+            p.y[m * p.y_ld + c] = v;
+        }
+    }
+}
+
+}  // namespace
+
+namespace ff {
+// FF_OK if launched, 1 if the shape is not this kernel's (fp32 rows, 3x3, stride 1, pad 1, Cout <= 2, groups 1)
+int conv2d_fwd_small(const FFConvParams& p, int cin, hipStream_t s) {
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
+    if (p.w_format != FF_W_F32 || p.Cout > 2 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1 ||
+        dlh != 1 || dlw != 1 || p.groups != 1)
+        return 1;
+    SArgs a;
+    a.p = p;
+    a.Cin = cin;
+    a.runs_x = (p.W + RUN - 1) / RUN;
+    const long long tasks = (long long)p.B * p.H * a.runs_x;
+    const unsigned blocks = (unsigned)((tasks + 3) / 4);
+    if (p.Cout == 1) conv_small_kernel<1><<<blocks, 256, 0, s>>>(a);
+    else conv_small_kernel<2><<<blocks, 256, 0, s>>>(a);
+    return check_launch("ff_conv2d_fwd(small)");
+}
+}  // namespace ff

@@ -56,7 +56,7 @@ class _Packed:
                 src, dst = src + real, dst + padded
             packed = torch.empty((co, kh * kw * cpad), dtype=torch.float32, device=w.device)
             ops.pack_conv_weight(wp, packed, cpad, 0)
-            self.fmt = ops.w_format()
+            self.fmt = 0 if (co <= 2 and kh == 3 and not self.transposed) else ops.w_format()   # small heads: conv_small.hip (fp32)
             self.w = ops.pack_split(packed) if self.fmt else packed
             self.b = cv.bias.detach()
             self.cout, self.k = co, kh
