@@ -12,7 +12,7 @@
 // dY is far below fp16's range: it is scaled by the power of two that puts max|dY| (FFConvParams.x_amax, from
 // ff_act_bwd) at 2^10, undone in the epilogue.  Xcol holds activations (|x| < 65504 as in the forward).
 // The bias gradient (column sums of dY) rides along in the blocks of the first k-tile.
-// Block tile 128 co x 64 k, 32-pixel chunks double-buffered in LDS, pixel range split over blockIdx.y; the
+// Block tile 128 co x 64 k (64 x 128 when Cout <= 64), 32-pixel chunks double-buffered in LDS, pixel range split over blockIdx.y; the
 // 128 x 64 result goes through LDS so that every atomic wave-instruction adds 256 contiguous bytes of dW.
 #include <algorithm>
 #include <cstdlib>
@@ -27,9 +27,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int RK = 32;            // pixels per chunk
-constexpr int BN1 = 128, BN2 = 64;
 constexpr int PITCH = 144;        // bytes per LDS row: 32 x0 + 32 x1 halfs = 128 B, + 16 B pad
-constexpr int A_BYTES = BN1 * PITCH, B_BYTES = BN2 * PITCH;
 
 struct WsArgs {
     FFConvParams p;   // forward geometry; p.y = dY, p.x_amax = bits of max|dY| (nullable)
@@ -39,24 +37,36 @@ struct WsArgs {
     int n1_tiles, n2_tiles, chunks_per_split;
 };
 
-template <int TERMS>
+// One operand tile of N channels x 32 pixels: N/4 channel quads x (1024/N) pixel groups over the 256 threads, each
+// thread moving PX = N/32 consecutive pixels of its quad (4 for a 128-wide tile: ds_write_b64 runs; 2 for a 64-wide
+// one: ds_write_b32 runs).  Channel 4g + j lives in LDS row j * (N/4) + g.
+template <int N>
+struct Stage {
+    static constexpr int Q = N / 4, PX = N / 32;
+};
+
+template <int TERMS, int BN1, int BN2>   // block tile: BN1 output channels x BN2 im2col columns, (128,64) or (64,128)
 __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
+    constexpr int A_BYTES = BN1 * PITCH, B_BYTES = BN2 * PITCH;
+    constexpr int QA = Stage<BN1>::Q, PA = Stage<BN1>::PX, QB = Stage<BN2>::Q, PB = Stage<BN2>::PX;
+    constexpr int TA = BN1 / 64, TB = BN2 / 64;               // 32-row MFMA tiles per wave (2 x 2 waves)
+    static_assert(TA * TB == 2, "tile must be 128x64 or 64x128");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A_BYTES + B_BYTES]; reused by the epilogue
     const FFConvParams& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                  // 2 x 2 waves: 64 co x 32 k each
+    const int wm = wave >> 1, wn = wave & 1;
     const int t1 = blockIdx.x / a.n2_tiles, t2 = blockIdx.x - t1 * a.n2_tiles;
     const int co0 = t1 * BN1, k0 = t2 * BN2;
     const int H = p.H, W = p.W, Wo = p.Wo, HoWo = p.Ho * p.Wo;
     float xs, xinv;
     ff::input_scale(p.x_amax, xs, xinv);
 
-    // dY staging: channel quad ga, pixels 4*ra .. 4*ra+3 of the chunk
-    const int ga = tid & 31, ra = tid >> 5;
+    // dY staging: channel quad ga, pixels PA*ra .. of the chunk
+    const int ga = tid % QA, ra = tid / QA;
     const int coa = co0 + ga * 4;
     const bool aok = coa < p.Cout;                            // dY buffer is channel-padded to a multiple of 4
-    // Xcol staging: k quad gb, pixels 2*rb, 2*rb+1
-    const int gb = tid & 15, rb = tid >> 4;
+    // Xcol staging: k quad gb, pixels PB*rb ..
+    const int gb = tid % QB, rb = tid / QB;
     const int kk = k0 + gb * 4;
     const bool kok = kk < a.K;
     int dyk = 0, dxk = 0, cik = 0, ldk = 0;
@@ -72,19 +82,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
         else { xpk = p.x[2]; ldk = p.x_ld[2]; cik -= c01; }
     }
 
-    f32x4 rav[4], rbv[2];
+    f32x4 rav[PA], rbv[PB];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     auto stage_load = [&](int mbase) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = mbase + ra * 4 + i;
+        for (int i = 0; i < PA; ++i) {
+            const int m = mbase + ra * PA + i;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (aok && m < a.M) v = *reinterpret_cast<const f32x4*>(p.y + (long long)m * p.y_ld + coa);
             rav[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = mbase + rb * 2 + i;
+        for (int i = 0; i < PB; ++i) {
+            const int m = mbase + rb * PB + i;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (kok && m < a.M) {
                 const int b = m / HoWo, rem = m - b * HoWo;
@@ -96,46 +106,49 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
             rbv[i] = v;
         }
     };
+    // split PX consecutive pixels of one channel and write the run: x0 at `row`, x1 64 bytes further
+    auto put = [&](char* row, const float (&v)[4], int npx, float scale) {
+        _Float16 h0[4], h1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sv = v[i] * scale;
+            h0[i] = (_Float16)sv;
+            h1[i] = (_Float16)((sv - (float)h0[i]) * 2048.f);
+        }
+        if (npx == 4) {
+            *reinterpret_cast<f16x4*>(row) = (f16x4){h0[0], h0[1], h0[2], h0[3]};
+            if (TERMS == 3) *reinterpret_cast<f16x4*>(row + 64) = (f16x4){h1[0], h1[1], h1[2], h1[3]};
+        } else {
+            *reinterpret_cast<f16x2*>(row) = (f16x2){h0[0], h0[1]};
+            if (TERMS == 3) *reinterpret_cast<f16x2*>(row + 64) = (f16x2){h1[0], h1[1]};
+        }
+    };
     auto stage_store = [&](int buf) {
         char* dA = smem + buf * (A_BYTES + B_BYTES);
         char* dB = dA + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                          // channel 4*ga + j -> LDS row j*32 + ga
-            f16x4 h0, h1;
+        for (int j = 0; j < 4; ++j) {                          // channel 4*ga + j -> LDS row j*QA + ga
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = rav[i][j];
-                bsum[j] += v;
-                const float sv = v * xs;
-                const _Float16 x0 = (_Float16)sv;
-                h0[i] = x0;
-                h1[i] = (_Float16)((sv - (float)x0) * 2048.f);
-            }
-            char* row = dA + (j * 32 + ga) * PITCH + ra * 8;   // pixels 4*ra.. -> byte 8*ra of the x0 run
-            *reinterpret_cast<f16x4*>(row) = h0;
-            if (TERMS == 3) *reinterpret_cast<f16x4*>(row + 64) = h1;
+            for (int i = 0; i < PA; ++i) { v[i] = rav[i][j]; bsum[j] += v[i]; }
+            put(dA + (j * QA + ga) * PITCH + ra * PA * 2, v, PA, xs);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                          // k 4*gb + j -> LDS row j*16 + gb
-            f16x2 h0, h1;
+        for (int j = 0; j < 4; ++j) {                          // k 4*gb + j -> LDS row j*QB + gb
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float v = rbv[i][j];
-                const _Float16 x0 = (_Float16)v;
-                h0[i] = x0;
-                h1[i] = (_Float16)((v - (float)x0) * 2048.f);
-            }
-            char* row = dB + (j * 16 + gb) * PITCH + rb * 4;
-            *reinterpret_cast<f16x2*>(row) = h0;
-            if (TERMS == 3) *reinterpret_cast<f16x2*>(row + 64) = h1;
+            for (int i = 0; i < PB; ++i) v[i] = rbv[i][j];
+            put(dB + (j * QB + gb) * PITCH + rb * PB * 2, v, PB, 1.f);
         }
     };
 
-    f32x16 acc[2], accx[2];
+    f32x16 acc[TA][TB], accx[TA][TB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TA; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
     const int chunk0 = blockIdx.y * a.chunks_per_split;
     const int nchunks_total = (a.M + RK - 1) / RK;
@@ -148,63 +161,92 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
     int cur = 0;
     for (int c = 0; c < nch; ++c) {
         if (c + 1 < nch) stage_load((chunk0 + c + 1) * RK);
-        const char* cA = smem + cur * (A_BYTES + B_BYTES) + (wm * 64 + li) * PITCH + lh * 16;
-        const char* cB = smem + cur * (A_BYTES + B_BYTES) + A_BYTES + (wn * 32 + li) * PITCH + lh * 16;
+        const char* cA = smem + cur * (A_BYTES + B_BYTES) + (wm * TA * 32 + li) * PITCH + lh * 16;
+        const char* cB = smem + cur * (A_BYTES + B_BYTES) + A_BYTES + (wn * TB * 32 + li) * PITCH + lh * 16;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                          // 16 pixels per MFMA step
-            f16x8 y0[2], y1[2], x0, x1;
+            f16x8 y0[TA], y1[TA], x0[TB], x1[TB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TA; ++i) {
                 y0[i] = *reinterpret_cast<const f16x8*>(cA + i * 32 * PITCH + s * 32);
                 if (TERMS == 3) y1[i] = *reinterpret_cast<const f16x8*>(cA + i * 32 * PITCH + s * 32 + 64);
             }
-            x0 = *reinterpret_cast<const f16x8*>(cB + s * 32);
-            if (TERMS == 3) x1 = *reinterpret_cast<const f16x8*>(cB + s * 32 + 64);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y0[i], x0, acc[i], 0, 0, 0);
-                if (TERMS == 3) {
-                    accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y0[i], x1, accx[i], 0, 0, 0);
-                    accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y1[i], x0, accx[i], 0, 0, 0);
-                }
+            for (int j = 0; j < TB; ++j) {
+                x0[j] = *reinterpret_cast<const f16x8*>(cB + j * 32 * PITCH + s * 32);
+                if (TERMS == 3) x1[j] = *reinterpret_cast<const f16x8*>(cB + j * 32 * PITCH + s * 32 + 64);
             }
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y0[i], x0[j], acc[i][j], 0, 0, 0);
+                    if (TERMS == 3) {
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y0[i], x1[j], accx[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y1[i], x0[j], accx[i][j], 0, 0, 0);
+                    }
+                }
         }
         if (c + 1 < nch) stage_store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
-    // ---- epilogue: un-permute through LDS ([co 128][k 64] fp32, pitch 65), then coalesced atomics
+    // ---- epilogue: un-permute through LDS ([co BN1][k BN2] fp32, pitch BN2+1), then coalesced atomics
+    constexpr int SP = BN2 + 1;
     float* so = reinterpret_cast<float*>(smem);
     const float osc = p.out_scale * xinv;
-    const int kcol = wn * 32 + li, kreal = (kcol & 15) * 4 + (kcol >> 4);      // LDS row j*16+gb holds k 4*gb+j
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TA; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int arow = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // LDS row j*32+ga holds co 4*ga+j
-            const int coreal = (arow & 31) * 4 + (arow >> 5);
-            float v = acc[i][r];
-            if (TERMS == 3) v += accx[i][r] * (1.f / 2048.f);
-            so[coreal * 65 + kreal] = v * osc;
+        for (int j = 0; j < TB; ++j) {
+            const int brow = (wn * TB + j) * 32 + li;          // LDS row jj*QB + g holds k 4*g + jj
+            const int kreal = (brow % QB) * 4 + brow / QB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int arow = (wm * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // row jj*QA + g holds co 4*g + jj
+                const int coreal = (arow % QA) * 4 + arow / QA;
+                float v = acc[i][j][r];
+                if (TERMS == 3) v += accx[i][j][r] * (1.f / 2048.f);
+                so[coreal * SP + kreal] = v * osc;
+            }
         }
-    }
-    float* sb = so + 128 * 65;                                  // [8][128] bias partials
+    float* sb = so + BN1 * SP;                                  // [256/QA][BN1] bias partials
     if (a.db && t2 == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sb[ra * 128 + ga * 4 + j] = bsum[j];
+        for (int j = 0; j < 4; ++j) sb[ra * BN1 + ga * 4 + j] = bsum[j];
     }
     __syncthreads();
     for (int e = tid; e < BN1 * BN2; e += 256) {
-        const int co = e >> 6, k = e & 63;
-        if (co0 + co < p.Cout && k0 + k < a.K) atomicAdd(a.dw + (long long)(co0 + co) * a.K + k0 + k, so[co * 65 + k]);
+        const int co = e / BN2, k = e - co * BN2;
+        if (co0 + co < p.Cout && k0 + k < a.K) atomicAdd(a.dw + (long long)(co0 + co) * a.K + k0 + k, so[co * SP + k]);
     }
-    if (a.db && t2 == 0 && tid < 128 && co0 + tid < p.Cout) {
+    if (a.db && t2 == 0 && tid < BN1 && co0 + tid < p.Cout) {
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) s += sb[r * 128 + tid];
+        for (int r = 0; r < 256 / QA; ++r) s += sb[r * BN1 + tid];
         atomicAdd(a.db + co0 + tid, s * p.out_scale);
     }
+}
+
+template <int BN1, int BN2>
+int launch(WsArgs& a, int M, hipStream_t s) {
+    const FFConvParams& p = a.p;
+    a.n1_tiles = (p.Cout + BN1 - 1) / BN1;
+    a.n2_tiles = (a.K + BN2 - 1) / BN2;
+    const int nchunks = (M + RK - 1) / RK;
+    const long long tiles = (long long)a.n1_tiles * a.n2_tiles;
+    static const int target = getenv("FF_WGRAD_BLOCKS") ? atoi(getenv("FF_WGRAD_BLOCKS")) : 1536;   // tuning knob
+    int splits = (int)((target + tiles - 1) / tiles);
+    if (splits > nchunks) splits = nchunks;
+    if (splits < 1) splits = 1;
+    a.chunks_per_split = (nchunks + splits - 1) / splits;
+    splits = (nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    dim3 grid(a.n1_tiles * a.n2_tiles, splits, 1);
+    const size_t lds = std::max<size_t>(2 * (BN1 + BN2) * PITCH, (BN1 * (BN2 + 1) + (256 / (BN1 / 4)) * BN1) * sizeof(float));
+    if (p.w_format == FF_W_F16) conv_wgrad_split_kernel<1, BN1, BN2><<<grid, 256, lds, s>>>(a);
+    else conv_wgrad_split_kernel<3, BN1, BN2><<<grid, 256, lds, s>>>(a);
+    return ff::check_launch("ff_conv2d_wgrad(split)");
 }
 
 }  // namespace
@@ -219,20 +261,8 @@ int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int c
     a.M = M;
     a.Cin = cin;
     a.K = p.KH * p.KW * cin;
-    a.n1_tiles = (p.Cout + BN1 - 1) / BN1;
-    a.n2_tiles = (a.K + BN2 - 1) / BN2;
-    const int nchunks = (M + RK - 1) / RK;
-    const long long tiles = (long long)a.n1_tiles * a.n2_tiles;
-    static const int target = getenv("FF_WGRAD_BLOCKS") ? atoi(getenv("FF_WGRAD_BLOCKS")) : 1536;   // tuning knob
-    int splits = (int)((target + tiles - 1) / tiles);
-    if (splits > nchunks) splits = nchunks;
-    if (splits < 1) splits = 1;
-    a.chunks_per_split = (nchunks + splits - 1) / splits;
-    splits = (nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
-    dim3 grid(a.n1_tiles * a.n2_tiles, splits, 1);
-    const size_t lds = std::max<size_t>(2 * (A_BYTES + B_BYTES), (128 * 65 + 8 * 128) * sizeof(float));
-    if (p.w_format == FF_W_F16) conv_wgrad_split_kernel<1><<<grid, 256, lds, s>>>(a);
-    else conv_wgrad_split_kernel<3><<<grid, 256, lds, s>>>(a);
-    return check_launch("ff_conv2d_wgrad(split)");
+    // a 128-row tile of output channels would be half empty for Cout <= 64 (and 3/4 full for 96): go wide in k instead
+    if (p.Cout <= 64) return launch<64, 128>(a, M, s);
+    return launch<128, 64>(a, M, s);
 }
 }  // namespace ff
