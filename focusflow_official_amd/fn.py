@@ -23,6 +23,64 @@ def _dense(t: Tensor) -> Tensor:
 
 
 # ----------------------------------------------------------------------------
+class GraphScope:
+    """Weight-gradient bookkeeping of ONE recorded forward pass.
+
+    A conv that is applied many times in one graph (the update block: 12 iterations; fnet: both frames) would hand
+    autograd one weight-gradient tensor per application - per application a zero-fill, an un-pack launch and an
+    accumulation add (about 1800 small launches per training step).  Inside a scope the wgrad kernel instead adds
+    into one buffer per conv (it accumulates with atomics anyway) and only the LAST application to run its backward
+    returns the total to autograd, so hooks (DDP) still see exactly one gradient per parameter.  If a backward pass
+    ends with applications that never ran (a loss that does not reach some of them), `flush` adds what was
+    accumulated straight into `.grad`."""
+
+    def __init__(self):
+        self.live, self.acc, self._cb_queued = {}, {}, False
+        self._amax_pool, self._amax_used = None, 0
+
+    def amax_word(self, device):
+        if self._amax_pool is None or self._amax_used >= self._amax_pool.numel():
+            self._amax_pool, self._amax_used = torch.zeros(2048, dtype=torch.int32, device=device), 0
+        self._amax_used += 1
+        return self._amax_pool[self._amax_used - 1:self._amax_used]
+
+    def queue_flush(self):
+        if not self._cb_queued:
+            self._cb_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        self._cb_queued = False
+        for pc, (dwp, db) in list(self.acc.items()):
+            off = 0
+            for cv in pc.convs:
+                co = cv.out_channels
+                if cv.weight.requires_grad:
+                    gw = ops.unpack_conv_wgrad(dwp, co, pc.cin, pc.kh, pc.kw, pc.cin_pad, off)
+                    cv.weight.grad = gw if cv.weight.grad is None else cv.weight.grad + gw
+                if cv.bias is not None and cv.bias.requires_grad:
+                    gb = db[off:off + co].clone()
+                    cv.bias.grad = gb if cv.bias.grad is None else cv.bias.grad + gb
+                off += co
+        self.acc.clear()
+        self.live.clear()
+
+
+_scope: Optional[GraphScope] = None
+
+
+def begin_graph() -> GraphScope:
+    """Open a weight-gradient scope for the forward pass that follows (RAFT.forward when recording)."""
+    global _scope
+    _scope = GraphScope()
+    return _scope
+
+
+def end_graph():
+    global _scope
+    _scope = None
+
+
 class ConvFn(torch.autograd.Function):
     """y = act(conv(cat(xs)) + bias) * ... (+ res).  tensors = xs..., [res], (w_i, b_i)..."""
 
@@ -47,6 +105,10 @@ class ConvFn(torch.autograd.Function):
             y = full
         ctx.pc, ctx.act, ctx.out_scale, ctx.nseg, ctx.has_res = pc, act, out_scale, nseg, has_res
         ctx.save_for_backward(*xs, y if act != ACT_NONE else None)
+        ctx.scope = None
+        if _scope is not None and ops.w_format() and any(ctx.needs_input_grad[7 + nseg + (1 if has_res else 0):]):
+            ctx.scope = _scope
+            _scope.live[pc] = _scope.live.get(pc, 0) + 1
         return y
 
     @staticmethod
@@ -55,7 +117,9 @@ class ConvFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         xs, y = list(saved[:nseg]), saved[nseg]
         dy = _dense(dy)
-        g, amax = ops.act_bwd(dy, y, act, ctx.out_scale, pc.cout, want_amax=True)   # (B,Ho,Wo,Cpad), zero padded
+        scope = ctx.scope
+        g, amax = ops.act_bwd(dy, y, act, ctx.out_scale, pc.cout, want_amax=True,    # (B,Ho,Wo,Cpad), zero padded
+                              amax=scope.amax_word(dy.device) if scope is not None else None)
         grads: List[Optional[Tensor]] = [None] * 7
         # input gradient: forward conv over g with flipped/transposed weights
         need_dx = any(ctx.needs_input_grad[7 + i] for i in range(nseg))
@@ -83,7 +147,19 @@ class ConvFn(torch.autograd.Function):
         base = 7 + nseg + (1 if ctx.has_res else 0)
         need_w = any(ctx.needs_input_grad[base:])
         dwp = db = None
-        if need_w:   # weight + bias gradient in one launch (f16 matrix pipe unless the conv precision is fp32)
+        if need_w and scope is not None:   # shared weights: add into the conv's buffer, deliver with the last application
+            acc = scope.acc.get(pc)
+            if acc is None:
+                kdim = pc.kh * pc.kw * sum(x.shape[3] for x in xs)
+                z = torch.zeros(pc.cout * kdim + pc.cout, dtype=torch.float32, device=g.device)
+                acc = scope.acc[pc] = (z[:pc.cout * kdim].view(pc.cout, kdim), z[pc.cout * kdim:])
+            ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True, dw=acc[0], db=acc[1])
+            scope.live[pc] -= 1
+            if scope.live[pc] > 0:
+                scope.queue_flush()
+                return tuple(grads + [None] * (2 * len(pc.convs)))
+            dwp, db = scope.acc.pop(pc)
+        elif need_w:   # weight + bias gradient in one launch (f16 matrix pipe unless the conv precision is fp32)
             dwp, db = ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True)
         off = 0
         for j, cv in enumerate(pc.convs):

@@ -431,22 +431,28 @@ def _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo):
 
 
 def conv2d_wgrad(xs: Sequence[Tensor], g: Tensor, cout: int, kh: int, kw: int, stride: int, pad,
-                 g_amax: Optional[Tensor] = None, want_db: bool = False):
+                 g_amax: Optional[Tensor] = None, want_db: bool = False, dw: Optional[Tensor] = None,
+                 db: Optional[Tensor] = None):
     """packed dW [cout][kh*kw*cin] from inputs `xs` and output gradient g (B,Ho,Wo,>=cout, ld % 4 == 0).
     With g_amax (bits of max|g|, act_bwd) and a split conv format the kernel runs on the f16 matrix pipe and can
-    also return the bias gradient: -> dW, or (dW, db) when want_db."""
+    also return the bias gradient: -> dW, or (dW, db) when want_db.  `dw` / `db`: existing buffers to ADD into
+    (the kernel accumulates with atomics; fresh zeroed ones are allocated when omitted)."""
     b, h, w, _ = xs[0].shape
     _, ho, wo, _ = g.shape
     cin = sum(x.shape[3] for x in xs)
-    dw = torch.zeros((cout, kh * kw * cin), dtype=torch.float32, device=g.device)
+    if dw is None:
+        dw = torch.zeros((cout, kh * kw * cin), dtype=torch.float32, device=g.device)
+    assert dw.shape == (cout, kh * kw * cin) and dw.is_contiguous()
     p = _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo)
     p.y, p.y_ld = g.data_ptr(), _ld(g)
     fmt = w_format() if g_amax is not None else 0
-    db = None
     if fmt:
         p.w_format, p.x_amax = fmt, g_amax.data_ptr()
-        db = torch.zeros(cout, dtype=torch.float32, device=g.device) if want_db else None
-    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(dw), 0, _p(db), _stream())
+        if want_db and db is None:
+            db = torch.zeros(cout, dtype=torch.float32, device=g.device)
+    else:
+        assert db is None, "accumulating bias-gradient buffers need a split conv format"
+    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(dw), 0, _p(db) if fmt else None, _stream())
     if want_db:
         return dw, (db if db is not None else channel_sum(g, cout))
     return dw
@@ -465,13 +471,16 @@ def pack_conv_weight_dgrad(w_oihw: Tensor, dst: Tensor, cout_pad: int, cout_offs
     _hip.call("ff_pack_conv_weight_dgrad", _p(w_oihw.contiguous()), co, ci, kh, kw, _p(dst), cout_pad, cout_offset, _stream())
 
 
-def act_bwd(dy: Tensor, y: Optional[Tensor], act: int, scale: float, c: int, want_amax: bool = False):
+def act_bwd(dy: Tensor, y: Optional[Tensor], act: int, scale: float, c: int, want_amax: bool = False,
+            amax: Optional[Tensor] = None):
     """g = dy*act'(y)*scale over the first c channels, zero-padded to a multiple of 4.
-    want_amax: also return a device word with the bits of max|g| (-> conv2d(x_amax=...))."""
+    want_amax: also return a device word with the bits of max|g| (-> conv2d(x_amax=...)); `amax`: a zeroed int32
+    word to use for it instead of allocating one."""
     b, h, w, _ = dy.shape
     cpad = (c + 3) // 4 * 4
     g = empty_nhwc(b, h, w, cpad, dy)
-    amax = torch.zeros(1, dtype=torch.int32, device=dy.device) if want_amax else None
+    if want_amax and amax is None:
+        amax = torch.zeros(1, dtype=torch.int32, device=dy.device)
     _hip.call("ff_act_bwd", _p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(g), cpad, b * h * w, c, cpad,
               act, scale, _p(amax), _stream())
     return (g, amax) if want_amax else g

@@ -61,6 +61,14 @@ class RAFT(nn.Module):
         or (flow_low, flow_up) in test_mode.  raft.py:173-236."""
         b, hh, ww, _ = image1.shape
         h8, w8 = hh // 8, ww // 8
+        if torch.is_grad_enabled():
+            fn.begin_graph()          # one weight-gradient buffer per conv for this recorded pass (fn.GraphScope)
+        try:
+            return self._forward(image1, image2, mask1, mask2, iters, flow_init, test_mode, b, hh, ww, h8, w8)
+        finally:
+            fn.end_graph()
+
+    def _forward(self, image1, image2, mask1, mask2, iters, flow_init, test_mode, b, hh, ww, h8, w8):
         fmap1 = self.fnet(image1, mask1)
         fmap2 = self.fnet(image2, mask2)
         self.fmap = fmap1

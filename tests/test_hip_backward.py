@@ -294,3 +294,31 @@ def test_frozen_bn_training_step_gives_gradients(det_sd):
                  "flow_net.update_block.gru.convq1.weight", "flow_net.fnet.fusion3.img2mask.conv.weight"]:
         ref_g = sd[name].grad
         close(params[name].grad.cpu(), ref_g, rtol=3e-3, atol_rel=3e-3, what=name)
+
+
+@pytest.mark.parametrize("partial", [False, True])
+def test_shared_weight_gradient_scope_matches_immediate_mode(det_sd, partial, monkeypatch):
+    """fn.GraphScope (one weight-gradient buffer per conv and per recorded pass, delivered by the last application
+    to run its backward) must give the gradients of the plain one-tensor-per-application path - also when the loss
+    reaches only some applications (final prediction only: the first iterations' mask head never runs backward and
+    its accumulated share is flushed into .grad at the end of the pass)."""
+    from focusflow_official_amd import FF_RAFT_FUSION, fn
+    inp = [t.to(DEV) for t in orc.shifted_pair(1, 128, 128, seed=11)]
+    results = []
+    for use_scope in (True, False):
+        if not use_scope:
+            monkeypatch.setattr(fn, "begin_graph", lambda: None)
+        m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg())
+        m.load_state_dict(det_sd, strict=True)
+        m = m.to(DEV).train()
+        preds = m(*inp, raft_iters=3)
+        loss = preds[-1].abs().mean() if partial else sum(p.abs().mean() for p in preds)
+        loss.backward()
+        results.append({n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None})
+    scoped, plain = results
+    assert sorted(scoped) == sorted(plain) and len(scoped) > 200
+    for n in plain:
+        if float(plain[n].abs().max()) < 1e-5:      # biases in front of an InstanceNorm: the true gradient is 0, both are noise
+            assert float(scoped[n].abs().max()) < 1e-5, n
+            continue
+        close(scoped[n], plain[n], rtol=1e-4, atol_rel=1e-4, what=n)
