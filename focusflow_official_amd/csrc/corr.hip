@@ -24,8 +24,14 @@ __global__ __launch_bounds__(256) void pyramid_kernel(const float* __restrict__ 
     for (int i = threadIdx.x; i < h1 * w1; i += 256) {
         const int y = i / w1, x = i - y * w1;
         const float* p = src + (2 * y) * w0 + 2 * x;
-        const float2 a = *reinterpret_cast<const float2*>(p);
-        const float2 b = *reinterpret_cast<const float2*>(p + w0);
+        float2 a, b;
+        if (w0 & 1) {   // odd plane width (W/8 odd): rows are not 8-byte aligned, the last column is dropped (floor)
+            a = make_float2(p[0], p[1]);
+            b = make_float2(p[w0], p[w0 + 1]);
+        } else {
+            a = *reinterpret_cast<const float2*>(p);
+            b = *reinterpret_cast<const float2*>(p + w0);
+        }
         const float v = (((a.x + a.y) + b.x) + b.y) * 0.25f;
         s1[i] = v;
         l1[plane * h1 * w1 + i] = v;
@@ -247,7 +253,7 @@ extern "C" int ff_corr_pyramid(const float* l0, float* l1, float* l2, float* l3,
                                void* stream) {
     FF_REQUIRE(l0 && l1 && l2 && l3, "ff_corr_pyramid: null pointer");
     FF_REQUIRE(planes > 0 && planes < (1ll << 31) && h0 >= 8 && w0 >= 8, "ff_corr_pyramid: plane %dx%d too small (need >= 8x8)", h0, w0);
-    FF_REQUIRE(w0 % 2 == 0 && ((uintptr_t)l0 & 7) == 0, "ff_corr_pyramid: w0 must be even and level 0 8-byte aligned");
+    FF_REQUIRE(((uintptr_t)l0 & 7) == 0, "ff_corr_pyramid: level 0 must be 8-byte aligned");
     const int h1 = h0 / 2, w1 = w0 / 2, h2 = h1 / 2, w2 = w1 / 2;
     const size_t lds = (size_t)(h1 * w1 + h2 * w2) * sizeof(float);
     FF_REQUIRE(lds <= 64 * 1024, "ff_corr_pyramid: plane too large for LDS staging");

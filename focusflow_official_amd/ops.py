@@ -551,9 +551,12 @@ def corr_volume_bwd(dvol: Tensor, f1: Tensor, f2: Tensor):
     q = h * w
     s = 1.0 / math.sqrt(c)
     dvol = dvol.contiguous().view(b, q, q)
-    f2t = torch.zeros((b, c, q), dtype=torch.float32, device=f1.device)       # [c][j] = f2[j][c]
+    qp = (q + 3) // 4 * 4
+    if qp != q:      # odd plane sizes: the kernels read the contraction index in 16-byte groups -> zero-pad its rows
+        dvol = torch.nn.functional.pad(dvol, (0, qp - q))
+    f2t = torch.zeros((b, c, qp), dtype=torch.float32, device=f1.device)      # [c][j] = f2[j][c]
     for i in range(b):
-        _hip.call("ff_pack_conv_weight_dgrad", _p(f2[i]), q, c, 1, 1, _p(f2t[i]), q, 0, _stream())
+        _hip.call("ff_pack_conv_weight_dgrad", _p(f2[i]), q, c, 1, 1, _p(f2t[i]), qp, 0, _stream())
     df1 = grouped_1x1(dvol, f2t, s).view(b, h, w, c)
     df2 = torch.zeros((b, q, c), dtype=torch.float32, device=f1.device)
     p = FFConvParams()
@@ -562,7 +565,7 @@ def corr_volume_bwd(dvol: Tensor, f1: Tensor, f2: Tensor):
     p.Ho, p.Wo, p.Cout = 1, q, q
     p.KH = p.KW = p.stride = 1
     p.out_scale = s
-    p.y, p.y_ld, p.y_gstride = dvol.data_ptr(), q, q * q
+    p.y, p.y_ld, p.y_gstride = dvol.data_ptr(), qp, q * qp
     _hip.call("ff_conv2d_wgrad", C.byref(p), _p(df2), q * c, None, _stream())
     return df1, df2.view(b, h, w, c)
 

@@ -322,3 +322,28 @@ def test_shared_weight_gradient_scope_matches_immediate_mode(det_sd, partial, mo
             assert float(scoped[n].abs().max()) < 1e-5, n
             continue
         close(scoped[n], plain[n], rtol=1e-4, atol_rel=1e-4, what=n)
+
+
+def test_odd_plane_sizes_forward_and_backward(det_sd):
+    """136x152 frames: the 1/8-resolution planes are 17x19 (odd in both directions: pooling floors, the pyramid
+    rows are not 8-byte aligned, conv tiles are ragged).  Forward and a few gradients against the CPU oracle."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg())
+    m.load_state_dict(det_sd, strict=True)
+    m = m.to(DEV).train()
+    m.flow_net.freeze_bn()
+    inp = orc.shifted_pair(1, 136, 152, seed=13)
+    preds = m(*[t.to(DEV) for t in inp], raft_iters=2)
+    sum(p.abs().mean() for p in preds).backward()
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+          for k, v in det_sd.items()}
+    ref = orc.ffraft_forward(sd, *inp, raft_iters=2, training=False)
+    sum(p.abs().mean() for p in ref).backward()
+    close(preds[-1].detach().cpu(), ref[-1].detach(), rtol=0, atol_rel=2e-4, what="pred")
+    params = dict(m.named_parameters(remove_duplicate=False))
+    for name in ["flow_net.fnet.layer3.1.conv2.weight", "flow_net.cnet.conv1.weight", "flow_net.update_block.gru.convz2.weight",
+                 "flow_net.update_block.encoder.convc1.weight", "flow_net.update_block.mask.2.weight",
+                 "flow_net.fnet.fusion2.mask2img.conv.weight"]:
+        # 1e-2 of the tensor's max, as in the train-step fixture test: the reference's own fp32-vs-fp64 spread on
+        # gradients that travel the whole network (encoder stems) is a few 1e-3
+        close(params[name].grad.cpu(), sd[name].grad, rtol=1e-2, atol_rel=1e-2, what=name)
