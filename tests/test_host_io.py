@@ -266,3 +266,19 @@ def test_evaluate_metrics_dense_and_sparse():
     epe, f1, mepe = evaluate.evaluate_loader(model, [(torch.zeros(1, 3, h, w), torch.zeros(1, 3, h, w), gt, m, m, valid)],
                                              iters=32, pad_mode="kitti", sparse=True).sparse()
     assert abs(epe - 5.0) < 1e-5 and abs(f1 - 50.0) < 1e-4 and abs(mepe - 4.0) < 1e-5
+
+
+def test_forward_interpolate_warm_start():
+    """utils.py:26-54: a constant flow lands every vector on another grid point carrying the same vector; a flow
+    that pushes everything out of the frame leaves nothing to interpolate from in that region."""
+    from focusflow_official_amd.utils import forward_interpolate
+    f = torch.zeros(2, 10, 14)
+    f[0] += 3.0
+    f[1] -= 1.0
+    out = forward_interpolate(f)
+    assert out.shape == (2, 10, 14) and out.dtype == torch.float32
+    assert torch.all(out[0] == 3.0) and torch.all(out[1] == -1.0)
+    g = torch.Generator().manual_seed(0)
+    r = torch.randn(2, 10, 14, generator=g)
+    out = forward_interpolate(r)
+    assert torch.isfinite(out).all() and set(out[0].flatten().tolist()) <= set(r[0].flatten().tolist())
