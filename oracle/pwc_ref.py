@@ -1,6 +1,6 @@
 """CPU oracle for FF-PWC's native component — TEST INFRASTRUCTURE.
 
-Cost volume: PARITY UNPINNED.  The reference's own implementation (CuPy-compiled CUDA strings,
+Cost volume: PARITY UNPINNED (the rest of FF-PWC is pinned, see below).  The reference's own implementation (CuPy-compiled CUDA strings,
 core/models/ff-pwcnet/PWCNet_Core/correlation.py:7-232) cannot run in this image (no cupy, no
 CUDA device; its CPU path raises NotImplementedError, :320-321) and the reference holds no test
 or golden vector for it.  `cost_volume` below restates the arithmetic those kernels spell out
@@ -41,8 +41,10 @@ def backwarp(ten_input: torch.Tensor, ten_flow: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------
 # FF_PWCNET forward (ff_pwcnet.py:113-434), functional restatement over a state_dict with the
-# reference's key names.  PARITY UNPINNED: the reference module cannot be imported here (cv2, cupy
-# and a broken `correlation` import); this follows the source text line by line.
+# reference's key names.  PINNED, except for the cost-volume arithmetic: tests/golden/make_golden_pwc.py runs the
+# reference's own FF_PWCNET (Extractor / Decoder / Refiner / backwarp / preprocess / test_mode resize) with two
+# stand-in modules for what this image lacks - an empty cv2 and a `correlation` whose FunctionCorrelation is
+# `cost_volume` above - and tests/test_oracle_golden.py holds this restatement to those vectors.
 # ----------------------------------------------------------------------------
 LEVEL_CH = [16, 32, 64, 96, 128, 196]
 EXTRACTOR = ["netOne", "netTwo", "netThr", "netFou", "netFiv", "netSix"]
@@ -72,9 +74,18 @@ def pwc_extractor(sd, p, x, mask, fusion_type="1x1conv"):
             else:
                 mask = t
         fu = f"{p}.fusion{lvl + 1}"
-        x_new = x + F.conv2d(mask, sd[fu + ".mask2img.conv.weight"], sd[fu + ".mask2img.conv.bias"])
-        if lvl < 5:   # fusion6 is uni-directional
-            mask = mask + F.conv2d(x, sd[fu + ".img2mask.conv.weight"], sd[fu + ".img2mask.conv.bias"])
+
+        def fc(name, t):
+            return F.conv2d(t, sd[f"{fu}.{name}.conv.weight"], sd[f"{fu}.{name}.conv.bias"])
+
+        if fusion_type == "concat":   # parallel_fusion.py:76-84: conv1x1(cat[q, v])
+            x_new = fc("mask2img", torch.cat([x, mask], 1))
+            if lvl < 5:
+                mask = fc("img2mask", torch.cat([mask, x], 1))
+        else:                         # '1x1conv' (:87-95): q + conv1x1(v)
+            x_new = x + fc("mask2img", mask)
+            if lvl < 5:   # fusion6 is uni-directional
+                mask = mask + fc("img2mask", x)
         x = x_new
         feats.append(x)
     return feats
@@ -98,8 +109,6 @@ def pwc_decoder(sd, p, level, one, two, prev):
 def pwc_refiner(sd, p, feat):
     """ff_pwcnet.py:346-370."""
     x = feat
-    for idx, dil in zip((0, 2, 4, 8, 10), (1, 2, 4, 16, 1)):
-        pass
     dils = [1, 2, 4, 8, 16, 1, 1]
     for i, d in enumerate(dils):
         x = _c(sd, f"{p}.netMain.{2 * i}", x, 1, d, d)
@@ -108,7 +117,7 @@ def pwc_refiner(sd, p, feat):
     return x
 
 
-def ffpwc_forward(sd, image1, image2, mask1, mask2=None, test_mode=False, mask_channel=3):
+def ffpwc_forward(sd, image1, image2, mask1, mask2=None, test_mode=False, mask_channel=3, fusion_type="1x1conv"):
     """ff_pwcnet.py:405-433 with 'point' masks, including preprocess (:391-403): sizes that are not multiples of 64
     are bilinearly resized first.  Inputs stay in [0,255] (FF-PWC does not normalise)."""
     b, _, h0, w0 = image1.shape
@@ -116,8 +125,8 @@ def ffpwc_forward(sd, image1, image2, mask1, mask2=None, test_mode=False, mask_c
     image1, image2, mask1 = (F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False) for t in (image1, image2, mask1))
     m1 = mask1.repeat(1, mask_channel, 1, 1)
     m2 = torch.ones_like(m1) * 255
-    f1 = pwc_extractor(sd, "netExtractor", image1, m1)
-    f2 = pwc_extractor(sd, "netExtractor", image2, m2)
+    f1 = pwc_extractor(sd, "netExtractor", image1, m1, fusion_type)
+    f2 = pwc_extractor(sd, "netExtractor", image2, m2, fusion_type)
     est = None
     flows = []
     for level in (6, 5, 4, 3, 2):

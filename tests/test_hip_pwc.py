@@ -133,3 +133,41 @@ def test_ffpwcnet_forward_matches_oracle(precision):
     assert got_small.shape == (2, 2, 100, 180) and got_list[0].shape == (2, 2, 32, 48)
     assert (m.origin_H, m.origin_W, m.new_H, m.new_W) == (100, 180, 128, 192)
     close(got_small.cpu(), ref_small, tol=2e-4, what="test_mode flow after pre-resize")
+
+
+@pytest.mark.parametrize("ft", ["1x1conv", "concat"])
+def test_ffpwcnet_matches_reference_layer_vectors(ft):
+    """FF_PWCNET on HIP against vectors produced by the reference's own module (cost volume substituted by the
+    oracle's definition, tests/golden/make_golden_pwc.py): five flows and the test_mode output, with and without the
+    pre-resize, and the state_dict keys/shapes."""
+    from argparse import Namespace
+    from conftest import golden_spec, load_golden
+    from focusflow_official_amd.pwcnet import FF_PWCNET
+    from oracle.weights import det_tensor
+    cfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"), MODEL=Namespace(FUSION="parallel", FUSION_TYPE=ft))
+    m = FF_PWCNET(cfg)
+    spec = golden_spec(f"pwc_state_dict_spec_{ft}")
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(s)) for k, s, _ in spec]
+    sd = {}
+    for k, shp, _ in spec:
+        t = det_tensor("pwc." + k, shp)
+        if k in ("netExtractor.netOne.0.weight", "netExtractor.mask_netOne.0.weight"):
+            t = t / 255.0
+        if ".netSix.0." in k or k.startswith("netRefiner.netMain.12") or "netUpf" in k:
+            t = t * 0.1
+        sd[k] = t
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    g = load_golden(f"pwc_fwd_{ft}")
+    for tag, (b, h, w), seed in (("128x192", (2, 128, 192), 4), ("100x180", (1, 100, 180), 5)):
+        gen = torch.Generator().manual_seed(seed)
+        base = torch.rand(b, 3, h // 4 + 4, w // 4 + 4, generator=gen)
+        i1 = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear", align_corners=False) * 255
+        i2 = torch.roll(i1, shifts=(2, -3), dims=(2, 3))
+        m1 = (torch.rand(b, 1, h, w, generator=gen) < 0.02).float() * 255
+        with torch.no_grad():
+            flows = m(i1.to(DEV), i2.to(DEV), m1.to(DEV), torch.zeros_like(m1).to(DEV))
+            full = m(i1.to(DEV), i2.to(DEV), m1.to(DEV), torch.zeros_like(m1).to(DEV), test_mode=True)
+        for lvl, fl in enumerate(flows):
+            close(fl.cpu(), torch.from_numpy(g[f"flow{lvl + 2}_{tag}"]), tol=2e-4, what=f"{ft} {tag} flow level {lvl + 2}")
+        close(full.cpu(), torch.from_numpy(g[f"full_{tag}"]), tol=2e-4, what=f"{ft} {tag} test_mode flow")

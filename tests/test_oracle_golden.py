@@ -224,3 +224,40 @@ def test_loss_oracle_matches_reference(kind):
     assert abs(metrics["epe"] - g[kind + ":epe"][0]) < 1e-5
     for i, p in enumerate(preds):
         np.testing.assert_allclose(p.grad[:, :, ::3, ::3].numpy(), g[f"{kind}:g{i}"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("ft", ["1x1conv", "concat"])
+def test_ffpwc_restatement_matches_reference_layers(ft):
+    """FF_PWCNET (ff_pwcnet.py:113-434) restated in oracle/pwc_ref.py vs vectors from the reference's own module run
+    with the cost volume substituted (tests/golden/make_golden_pwc.py): state_dict keys/shapes, the five flows, the
+    test_mode output, with and without the pre-resize."""
+    import zlib
+    from conftest import golden_spec
+    from oracle import pwc_ref
+    from oracle.weights import det_tensor
+    spec = golden_spec(f"pwc_state_dict_spec_{ft}")
+    if ft == "1x1conv":
+        assert [(k, tuple(s)) for k, s, _ in spec] == [(k, tuple(s)) for k, s in pwc_ref.pwc_state_spec()]
+    sd = {}
+    for k, shp, _ in spec:
+        t = det_tensor("pwc." + k, shp)
+        if k in ("netExtractor.netOne.0.weight", "netExtractor.mask_netOne.0.weight"):
+            t = t / 255.0
+        if ".netSix.0." in k or k.startswith("netRefiner.netMain.12") or "netUpf" in k:
+            t = t * 0.1
+        sd[k] = t
+    g = load_golden(f"pwc_fwd_{ft}")
+    for tag, (b, h, w), seed in (("128x192", (2, 128, 192), 4), ("100x180", (1, 100, 180), 5)):
+        gen = torch.Generator().manual_seed(seed)
+        base = torch.rand(b, 3, h // 4 + 4, w // 4 + 4, generator=gen)
+        i1 = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear", align_corners=False) * 255
+        i2 = torch.roll(i1, shifts=(2, -3), dims=(2, 3))
+        m1 = (torch.rand(b, 1, h, w, generator=gen) < 0.02).float() * 255
+        assert [zlib.crc32(t.contiguous().numpy().tobytes()) for t in (i1, i2, m1)] == list(g[f"in_crc_{tag}"])
+        with torch.no_grad():
+            flows = pwc_ref.ffpwc_forward(sd, i1, i2, m1, fusion_type=ft)
+            full = pwc_ref.ffpwc_forward(sd, i1, i2, m1, test_mode=True, fusion_type=ft)
+        for lvl, fl in enumerate(flows):
+            np.testing.assert_allclose(fl.numpy(), g[f"flow{lvl + 2}_{tag}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(full.numpy(), g[f"full_{tag}"], rtol=0, atol=2e-6)
+        assert float(np.abs(g[f"full_{tag}"]).max()) > 0.05
