@@ -7,10 +7,11 @@ deterministic name-hashed weights of ``oracle/weights.py`` and records
 inputs' checksums + outputs as small fixtures.  The GPU box never sees the
 reference — only these vectors travel.
 
-``FF_RAFT_Core/ff_raft.py`` (the 4-line input scaling wrapper) is NOT imported:
-it pulls in ``cv2`` at module scope, which this image lacks.  The fixtures
-therefore pin ``RAFT.forward`` (raft.py:173-236) on already-normalised inputs;
-the scaling itself (ff_raft.py:142-145) is restated in the oracle.
+``FF_RAFT_Core/ff_raft.py`` (init_mask + the input scaling wrapper) is not imported
+HERE: it pulls in ``cv2`` at module scope, which this image lacks.  These fixtures pin
+``RAFT.forward`` (raft.py:173-236) on already-normalised inputs; the wrapper itself is
+pinned separately by ``make_golden_wrapper.py`` (empty ``cv2`` stand-in, the mask modes
+that never call it).
 
 Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """

@@ -488,6 +488,24 @@ def test_mask_modes(modal, det_sd):
     close(fu.cpu(), ref, rtol=0, atol=1e-3, what=f"{modal} flow")
 
 
+@pytest.mark.parametrize("modal", ["point", "frame", "neighborG"])
+def test_wrapper_mask_modes_match_reference_vectors(modal, det_sd):
+    """The whole drop-in call FF_RAFT_FUSION(image1, image2, mask1, mask2) - init_mask, input scaling, RAFT - against
+    vectors from the reference's own wrapper class (ff_raft.py:134-164) for the modes it can run here."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    g = load_golden("wrapper_modes_128x160_b2_it3")
+    cfg = _cfg()
+    cfg.TRAIN.MASK_MODAL, cfg.TRAIN.MASK_DILATE, cfg.TRAIN.KERNEL_SIZE, cfg.TRAIN.KERNEL_SIGMA = modal, 31, 31, 5
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg)
+    m.load_state_dict(det_sd)
+    m = m.to(DEV).eval()
+    inp = orc.shifted_pair(2, 128, 160, seed=17)
+    with torch.no_grad():
+        fl, fu = m(*[t.to(DEV) for t in inp], raft_iters=3, test_mode=True)
+    close(fl.cpu(), g[f"{modal}_flow_low"], rtol=0, atol=1e-3, what=f"{modal} flow_low")
+    close(fu.cpu(), g[f"{modal}_flow_up"], rtol=0, atol=1e-3, what=f"{modal} flow_up")
+
+
 MASK_TABLE_MODES = ("neighborG", "neighborE", "context")
 
 

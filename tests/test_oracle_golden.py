@@ -261,3 +261,20 @@ def test_ffpwc_restatement_matches_reference_layers(ft):
             np.testing.assert_allclose(fl.numpy(), g[f"flow{lvl + 2}_{tag}"], rtol=0, atol=2e-6)
         np.testing.assert_allclose(full.numpy(), g[f"full_{tag}"], rtol=0, atol=2e-6)
         assert float(np.abs(g[f"full_{tag}"]).max()) > 0.05
+
+
+@pytest.mark.parametrize("modal", ["point", "frame", "neighborG"])
+def test_wrapper_mask_modes_match_reference(modal, det_sd):
+    """FF_RAFT_FUSION.forward (ff_raft.py:134-164): init_mask + [0,255] -> [-1,1] scaling + RAFT, against vectors from
+    the reference's own wrapper (tests/golden/make_golden_wrapper.py; the modes that never call OpenCV)."""
+    g = load_golden("wrapper_modes_128x160_b2_it3")
+    inp = orc.shifted_pair(2, 128, 160, seed=17)
+    assert [zlib.crc32(t.contiguous().numpy().tobytes()) for t in inp] == list(g["in_crc"])
+    m1, m2 = orc.init_mask(inp[0], inp[1], inp[2], modal, dilate=31, kernel_size=31, kernel_sigma=5)
+    np.testing.assert_allclose(m1.float().numpy()[:, :, ::2, ::2], g[f"{modal}_mask1"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(m2.float().numpy()[:, :, ::2, ::2], g[f"{modal}_mask2"], rtol=0, atol=2e-4)
+    ref_in = tuple(2 * (t / 255.0) - 1.0 for t in (inp[0], inp[1], m1, m2))
+    with torch.no_grad():
+        fl, fu = orc.raft_forward(det_sd, *ref_in, iters=3, test_mode=True, prefix="flow_net.")
+    np.testing.assert_allclose(fl.numpy(), g[f"{modal}_flow_low"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(fu.numpy(), g[f"{modal}_flow_up"], rtol=0, atol=1e-4)
