@@ -282,3 +282,23 @@ def test_forward_interpolate_warm_start():
     r = torch.randn(2, 10, 14, generator=g)
     out = forward_interpolate(r)
     assert torch.isfinite(out).all() and set(out[0].flatten().tolist()) <= set(r[0].flatten().tolist())
+
+
+def test_flo_and_pfm_against_the_reference_readers_and_writers(tmp_path):
+    """Bytes the reference's writeFlow produced and arrays its readFlow / readPFM returned
+    (tests/golden/make_golden_io.py) vs this package's frame_utils on the same data."""
+    from conftest import load_golden
+    g = load_golden("io_formats")
+    fn = str(tmp_path / "a.flo")
+    frame_utils.writeFlow(fn, g["flow"])
+    assert open(fn, "rb").read() == g["flo_bytes"].tobytes()
+    frame_utils.writeFlow(fn, g["flow"][..., 0], g["flow"][..., 1])
+    assert open(fn, "rb").read() == g["flo_bytes_uv"].tobytes()
+    open(fn, "wb").write(g["flo_bytes"].tobytes())
+    assert np.array_equal(frame_utils.readFlow(fn), g["flo_read"])
+    pf = str(tmp_path / "c.pfm")
+    open(pf, "wb").write(g["pfm_bytes"].tobytes())
+    assert np.array_equal(frame_utils.readPFM(pf), g["pfm_read"])
+    assert np.array_equal(frame_utils.read_gen(pf), g["pfm_read_gen"])
+    open(pf, "wb").write(g["pfm_gray_bytes"].tobytes())
+    assert np.array_equal(frame_utils.readPFM(pf), g["pfm_gray_read"])
