@@ -302,3 +302,24 @@ def test_flo_and_pfm_against_the_reference_readers_and_writers(tmp_path):
     assert np.array_equal(frame_utils.read_gen(pf), g["pfm_read_gen"])
     open(pf, "wb").write(g["pfm_gray_bytes"].tobytes())
     assert np.array_equal(frame_utils.readPFM(pf), g["pfm_gray_read"])
+
+
+def test_input_padder_and_forward_interpolate_against_reference():
+    """core/utils/utils.py:7-54 run in the authoring container (tests/golden/make_golden_utils.py): pad amounts for
+    Sintel / KITTI sizes, padded content, unpad round trip, and the warm-start interpolation of a random flow."""
+    from conftest import load_golden
+    from focusflow_official_amd.utils import InputPadder, forward_interpolate
+    g = load_golden("utils_padder")
+    gen = torch.Generator().manual_seed(3)
+    for i, (h, w, mode) in enumerate([(436, 1024, "sintel"), (375, 1242, "kitti"), (370, 1226, "kitti"), (100, 180, "sintel"),
+                                      (128, 192, "sintel")]):
+        x = torch.randn(1, 2, h, w, generator=gen)
+        assert abs(float(x.sum()) - float(g[f"case{i}_seedcheck"][0])) < 1e-3
+        p = InputPadder(x.shape, mode=mode)
+        y = p.pad(x)[0]
+        assert [h, w, y.shape[-2], y.shape[-1]] + list(p._pad) == list(g[f"case{i}"])
+        assert np.array_equal(y[0, :, :12, :12].numpy(), g[f"case{i}_corner"])
+        assert torch.equal(p.unpad(y), x) and int(g[f"case{i}_unpad_ok"][0]) == 1
+    f = torch.randn(2, 14, 18, generator=gen) * 2
+    assert np.array_equal(f.numpy(), g["fi_in"])
+    assert np.array_equal(forward_interpolate(f).numpy(), g["fi_out"])
