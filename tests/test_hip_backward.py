@@ -347,3 +347,32 @@ def test_odd_plane_sizes_forward_and_backward(det_sd):
         # 1e-2 of the tensor's max, as in the train-step fixture test: the reference's own fp32-vs-fp64 spread on
         # gradients that travel the whole network (encoder stems) is a few 1e-3
         close(params[name].grad.cpu(), sd[name].grad, rtol=1e-2, atol_rel=1e-2, what=name)
+
+
+def test_overfitting_a_fixed_batch_reduces_the_loss(det_sd):
+    """End-to-end sanity of the training path (forward, fused MixLoss, backward on the f16 pipe, shared
+    weight-gradient buffers, clipping, AdamW): fifteen steps on one fixed batch whose ground truth is a constant
+    shift must bring the loss well down, every step finite."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    from focusflow_official_amd.losses import build_losses
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg())
+    m.load_state_dict(det_sd, strict=True)
+    m = m.to(DEV).train()
+    m.flow_net.freeze_bn()
+    inp = [t.to(DEV) for t in orc.shifted_pair(2, 128, 160, seed=21)]
+    flow_gt = torch.zeros(2, 2, 128, 160, device=DEV)
+    flow_gt[:, 0], flow_gt[:, 1] = -5.0, 3.0            # image2 = roll(image1, (3, -5)): flow (x, y) = (-5, 3)
+    valid = torch.ones(2, 128, 160, device=DEV)
+    crit = build_losses("MixLoss", gamma=0.8, max_flow=400, kernel_size=1, sigma=0.01, lamda=1)
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-4, weight_decay=1e-5)
+    losses = []
+    for _ in range(15):
+        preds = m(*inp, raft_iters=4)
+        loss, _ = crit(preds, flow_gt, valid, inp[2])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        assert torch.isfinite(loss) and torch.isfinite(gn)
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.7 * losses[0], losses
