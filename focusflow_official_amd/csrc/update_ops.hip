@@ -115,16 +115,21 @@ __global__ void gru_blend_kernel(const float* __restrict__ z, int z_ld, const fl
     }
 }
 
-// raft.py:159-170.  One block per coarse row (b, h); thread = (w, sub-pixel ij).
+// raft.py:159-170.  One block per 16 coarse pixels of a coarse row (b, h, w0..w0+15); thread = (w, sub-pixel ij).
 // mask channel = k*64 + i*8 + j, k = ky*3+kx (F.unfold order); output row 8h+i, col 8w+j.
+// The mask is read as it lies (a wave = the 64 sub-pixels of one coarse pixel: 256 contiguous bytes per k); the
+// results go through an 8 x 128 LDS tile so that the full-resolution rows are written as 512 contiguous bytes.
+constexpr int UPW = 16;
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ flow, int flow_ld,
                                                        const float* __restrict__ mask, int mask_ld,
                                                        float* __restrict__ out, int H, int W) {
-    const int b = blockIdx.y, h = blockIdx.x;
+    __shared__ float tile[2][8][UPW * 8 + 4];
+    const int b = blockIdx.z, h = blockIdx.y, w0 = blockIdx.x * UPW;
     const long long rowpix = ((long long)b * H + h) * W;
     const int HW8 = 64 * H * W;
-    for (int t = threadIdx.x; t < W * 64; t += 256) {
-        const int w = t >> 6, ij = t & 63, i = ij >> 3, j = ij & 7;
+    for (int t = threadIdx.x; t < UPW * 64; t += 256) {
+        const int wl = t >> 6, w = w0 + wl, ij = t & 63, i = ij >> 3, j = ij & 7;
+        if (w >= W) continue;
         const float* m = mask + (rowpix + w) * mask_ld + ij;
         float mv[9], mx = -INFINITY;
 #pragma unroll
@@ -152,9 +157,15 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             ox += wgt * fx;
             oy += wgt * fy;
         }
-        const long long o = (long long)b * 2 * HW8 + (long long)(8 * h + i) * (8 * W) + 8 * w + j;
-        out[o] = ox;
-        out[o + HW8] = oy;
+        tile[0][i][wl * 8 + j] = ox;
+        tile[1][i][wl * 8 + j] = oy;
+    }
+    __syncthreads();
+    const int ncol = min(UPW, W - w0) * 8;
+    for (int t = threadIdx.x; t < 2 * 8 * UPW * 8; t += 256) {
+        const int c = t & (UPW * 8 - 1), i = (t >> 7) & 7, ch = t >> 10;
+        if (c < ncol)
+            out[(long long)b * 2 * HW8 + (long long)ch * HW8 + (long long)(8 * h + i) * (8 * W) + 8 * w0 + c] = tile[ch][i][c];
     }
 }
 
@@ -297,7 +308,7 @@ extern "C" int ff_upsample_flow(const float* flow, int flow_ld, const float* mas
                                 int H, int W, void* stream) {
     FF_REQUIRE(flow && mask && out && B > 0 && H > 0 && W > 0, "ff_upsample_flow: bad argument");
     FF_REQUIRE(flow_ld >= 2 && mask_ld >= 576, "ff_upsample_flow: flow_ld/mask_ld too small");
-    dim3 grid(H, B);
+    dim3 grid((W + UPW - 1) / UPW, H, B);
     upsample_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(flow, flow_ld, mask, mask_ld, out, H, W);
     return ff::check_launch("ff_upsample_flow");
 }
