@@ -229,9 +229,32 @@ def corr_lookup(levels: List[Tensor], coords: Tensor, radius: int = 4, want_taps
 
 
 # ----------------------------------------------------------------------------
+# Zeroed fp64 statistics buffers come out of one arena per forward pass (one fill instead of one per norm layer).
+# The arena is only handed out between begin_forward() and the next begin_forward(); every slice is used once.
+_stats_arena = None
+_stats_used = 0
+
+
+def begin_forward(device):
+    """Called by the model at the top of a forward pass: a fresh zeroed arena for the norm statistics."""
+    global _stats_arena, _stats_used
+    _stats_arena = torch.zeros(1 << 18, dtype=torch.float64, device=device)     # 2 MB: ~60 norm layers x B x C x 2
+    _stats_used = 0
+
+
+def _zero_stats(s, c, device):
+    global _stats_used
+    n = s * c * 2
+    if _stats_arena is None or _stats_arena.device != device or _stats_used + n > _stats_arena.numel():
+        return torch.zeros((s, c, 2), dtype=torch.float64, device=device)
+    out = _stats_arena[_stats_used:_stats_used + n].view(s, c, 2)
+    _stats_used += n
+    return out
+
+
 def norm_stats(x: Tensor, per_sample: bool) -> Tensor:
     b, h, w, c = x.shape
-    stats = torch.zeros((b if per_sample else 1, c, 2), dtype=torch.float64, device=x.device)
+    stats = _zero_stats(b if per_sample else 1, c, x.device)
     _hip.call("ff_norm_stats", _p(x), _ld(x), b, h * w, c, int(per_sample), _p(stats), _stream())
     return stats
 
@@ -247,18 +270,27 @@ def norm_apply(x: Tensor, stats: Tensor, per_sample: bool, eps: float = 1e-5, ga
 
 
 def bn_fold(bn: torch.nn.BatchNorm2d):
+    """Eval-mode BatchNorm as per-channel (scale, shift) for the conv epilogue; cached until a parameter or
+    running statistic changes (version counters / storage)."""
+    key = tuple((t._version, t.data_ptr()) for t in (bn.running_mean, bn.running_var, bn.weight, bn.bias))
+    cached = getattr(bn, "_ff_fold", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
     c = bn.num_features
     sc = torch.empty(c, dtype=torch.float32, device=bn.weight.device)
     sh = torch.empty_like(sc)
     _require_gpu(bn.weight)
     _hip.call("ff_bn_fold", _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), bn.eps, _p(sc),
               _p(sh), c, _stream())
+    bn._ff_fold = (key, sc, sh)
     return sc, sh
 
 
 def bn_update_running(bn: torch.nn.BatchNorm2d, stats: Tensor, count: int):
     _hip.call("ff_bn_update_running", _p(stats), count, bn.momentum, _p(bn.running_mean), _p(bn.running_var),
               bn.num_features, _stream())
+    for t in (bn.running_mean, bn.running_var):     # written through raw pointers: tell PyTorch (bn_fold's cache key)
+        torch.autograd.graph.increment_version(t)
 
 
 # ----------------------------------------------------------------------------

@@ -61,6 +61,7 @@ class RAFT(nn.Module):
         or (flow_low, flow_up) in test_mode.  raft.py:173-236."""
         b, hh, ww, _ = image1.shape
         h8, w8 = hh // 8, ww // 8
+        ops.begin_forward(image1.device)     # one zeroed arena for this pass's norm statistics
         if torch.is_grad_enabled():
             fn.begin_graph()          # one weight-gradient buffer per conv for this recorded pass (fn.GraphScope)
         try:
