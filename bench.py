@@ -312,6 +312,24 @@ def main():
             "achieved": round(issued, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(issued / peak, 4),
             "note": f"{terms} MFMA term(s) per fp32-accurate product; useful rate {vol_flop / (vol_avg_ms * 1e-3) / 1e12:.1f} TFLOP/s",
             "launches": len(vol_ms), "avg_launch_us": round(vol_avg_ms * 1e3, 1)}
+        # all convolutions of one extra (untimed) step, each launch bracketed by HIP events: where 80 % of the step goes
+        ops.profile_begin("conv")
+        with torch.no_grad():
+            model(*batch, raft_iters=args.iters, test_mode=True)
+        conv_ms = ops.profile_end()["conv"]
+        notes = ops.profile_notes("conv")
+        useful = sum(n[0] for n in notes)
+        issued_fl = sum(n[0] * (3 if n[1] == 1 else 1) for n in notes if n[1] != 0)
+        mfma_ms = sum(t for t, n in zip(conv_ms, notes) if n[1] != 0)
+        tot_ms = sum(conv_ms)
+        line["roofline_conv"] = {
+            "kernel": "every ff_conv2d_fwd launch of one step (conv_patch / conv_split / conv_small kernels)", "bound": "mfma",
+            "achieved": round(issued_fl / (mfma_ms * 1e-3) / 1e12, 1) if mfma_ms > 0 else 0.0, "peak": MFMA_PEAK_TFLOPS["f16"],
+            "unit": "TFLOP/s", "frac": round(issued_fl / (mfma_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f16"], 4) if mfma_ms > 0 else 0.0,
+            "note": f"f16 MFMA FLOP issued (3 per fp32-accurate product) over the summed launch durations; useful "
+                    f"{useful / (tot_ms * 1e-3) / 1e12:.1f} TFLOP/s; the f16 pipe sustains ~1600 TFLOP/s on dense data "
+                    f"(tools/proto/mfma_peak.hip)",
+            "launches": len(conv_ms), "sum_launch_ms": round(tot_ms, 3), "useful_gflop_per_step": round(useful / 1e9, 1)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.height, args.width, args.iters)
         print(json.dumps(line), flush=True)

@@ -58,6 +58,7 @@ def pack_split(rows_f32: Tensor) -> Tensor:
 # launch stream (bench.py's roofline leg).  Off unless profile_begin() is called.
 _prof_on = False
 _prof_events = {}
+_prof_notes = {}      # label -> per-launch annotation (conv: useful FLOP of the launch)
 
 
 def profile_begin(*labels: str):
@@ -65,8 +66,10 @@ def profile_begin(*labels: str):
     global _prof_on
     _prof_on = True
     _prof_events.clear()
+    _prof_notes.clear()
     for lb in labels:
         _prof_events[lb] = []
+        _prof_notes[lb] = []
 
 
 def profile_end():
@@ -79,13 +82,19 @@ def profile_end():
     return out
 
 
-def _timed_call(label, name, *args):
+def profile_notes(label):
+    """Annotations recorded next to the timings of `label` (read before the next profile_begin)."""
+    return list(_prof_notes.get(label, []))
+
+
+def _timed_call(label, name, *args, note=None):
     if _prof_on and label in _prof_events:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         _hip.call(name, *args)
         b.record()
         _prof_events[label].append((a, b))
+        _prof_notes[label].append(note)
     else:
         _hip.call(name, *args)
 
@@ -168,7 +177,7 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     p.dil_h = p.dil_w = dilation
     p.x_amax = x_amax.data_ptr() if x_amax is not None else None
     assert out.shape[:3] == (b, ho, wo) and out.shape[3] >= cout
-    _hip.call("ff_conv2d_fwd", C.byref(p), _stream())
+    _timed_call("conv", "ff_conv2d_fwd", C.byref(p), _stream(), note=(2.0 * b * ho * wo * cout * kh * kw * cin, w_fmt))
     return out
 
 
