@@ -22,6 +22,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TW = 16, BN = 64, ROWB = 128;   // tile height TH = 4*TM (template): 8 rows, or 4 for small problems
+// LDS rows (one patch pixel / one weight row: 32 x0 + 32 x1 halfs = 128 B) sit at a 144-byte pitch instead of being
+// XOR-swizzled: 16 lanes reading 16 B from 16 consecutive rows hit 64 distinct banks, the 8-byte stores of the patch
+// and the 16-byte stores of the weights are conflict-free as well, and - no XOR - every k-slice / term / B tile is an
+// immediate offset from one base register.  PMC on the swizzled version: 35 % of the LDS-active cycles were
+// bank-conflict cycles and the kernel issued 10 VALU instructions per MFMA, mostly swizzle arithmetic.
+constexpr int ROWP = 144;
 
 
 struct PArgs {
@@ -30,8 +36,6 @@ struct PArgs {
     int tiles_x, tiles_y, n_tiles;
     long long w_row_bytes;
 };
-
-__device__ __forceinline__ int swz(int row, int piece) { return piece ^ ((row >> 1) & 7); }
 
 __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
 #pragma unroll
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
     ff::input_scale(p.x_amax, xs, xinv);       // 1, 1 unless the caller passed max|x| (gradients: dgrad on the f16 pipe)
     const int KH = p.KH, KW = p.KW, PH = TH + KH - 1, PW = TW + KW - 1, NPIX = PH * PW;
     char* sP = smem;                          // [NPIX][128 B] patch, split format
-    char* sW = smem + ((NPIX * ROWB + 255) & ~255);   // [2][BN][128 B] weights of one (tap, ci-chunk)
+    char* sW = smem + ((NPIX * ROWP + 255) & ~255);   // [2][BN] weight rows of one (tap, ci-chunk)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -117,8 +121,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
             if (row < NPIX) {
                 f16x4 h0, h1;
                 split4(rp[i] * xs, h0, h1);
-                *reinterpret_cast<f16x4*>(sP + row * ROWB + swz(row, pc) * 16 + half) = h0;
-                if (TERMS == 3) *reinterpret_cast<f16x4*>(sP + row * ROWB + swz(row, 4 + pc) * 16 + half) = h1;
+                *reinterpret_cast<f16x4*>(sP + row * ROWP + pc * 16 + half) = h0;
+                if (TERMS == 3) *reinterpret_cast<f16x4*>(sP + row * ROWP + 64 + pc * 16 + half) = h1;
             }
         }
     };
@@ -128,11 +132,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
             rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[i], kc * ROWB, 0));
     };
     auto store_w = [&](int buf) {
-        char* d = sW + buf * BN * ROWB;
+        char* d = sW + buf * BN * ROWP;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (tid >> 3) + 32 * i;
-            *reinterpret_cast<f32x4*>(d + row * ROWB + swz(row, kq) * 16) = rw[i];
+            *reinterpret_cast<f32x4*>(d + row * ROWP + kq * 16) = rw[i];
         }
     };
 
@@ -147,6 +151,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
     const int lrow = li >> 4, lcol = li & 15;
     const int ntaps = KH * KW;
     const int brow = wn * 32 + li;           // weight LDS row of this lane's output channel
+    const char* abase[TM];                    // this lane's patch row for tap (0, 0), k-half lh, per m-tile
+#pragma unroll
+    for (int t = 0; t < TM; ++t) abase[t] = sP + (((wm * TM + t) * 2 + lrow) * PW + lcol) * ROWP + lh * 16;
 
     load_patch(0);
     load_w(0);
@@ -162,18 +169,19 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
             const int next_kc = last ? (c + 1) : (tap + 1) * a.nci + c;   // K order = (tap, ci): chunk index tap*nci + c
             if (!(last && c + 1 == a.nci) && ABL != 1 && ABL != 2) load_w(last ? c + 1 : next_kc);
             const int dy = tap / KW, dx = tap - dy * KW;
-            const char* cW = sW + wbuf * BN * ROWB;
+            const int tapoff = (dy * PW + dx) * ROWP;              // block-uniform
+            const char* cW = sW + wbuf * BN * ROWP + brow * ROWP + lh * 16;      // this lane's weight row, k-half lh
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 f16x8 a0[TM], a1[TM], b0, b1;
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
-                    const int row = ((wm * TM + t) * 2 + lrow + dy) * PW + lcol + dx;
-                    a0[t] = *reinterpret_cast<const f16x8*>(sP + row * ROWB + swz(row, 2 * s + lh) * 16);
-                    if (TERMS == 3) a1[t] = *reinterpret_cast<const f16x8*>(sP + row * ROWB + swz(row, 4 + 2 * s + lh) * 16);
+                    const char* pa = abase[t] + tapoff;            // + k-slice s (32 B) and term (64 B) as immediates
+                    a0[t] = *reinterpret_cast<const f16x8*>(pa + s * 32);
+                    if (TERMS == 3) a1[t] = *reinterpret_cast<const f16x8*>(pa + 64 + s * 32);
                 }
-                b0 = *reinterpret_cast<const f16x8*>(cW + brow * ROWB + swz(brow, 2 * s + lh) * 16);
-                if (TERMS == 3) b1 = *reinterpret_cast<const f16x8*>(cW + brow * ROWB + swz(brow, 4 + 2 * s + lh) * 16);
+                b0 = *reinterpret_cast<const f16x8*>(cW + s * 32);
+                if (TERMS == 3) b1 = *reinterpret_cast<const f16x8*>(cW + 64 + s * 32);
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
                     if constexpr (ABL == 3) {      // no MFMA: keep operands alive
@@ -287,7 +295,7 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     const int th = force_th ? force_th : (blocks8 < 512 ? 4 : 8);
     a.tiles_y = (p.H + th - 1) / th;
     const int npix = (th + p.KH - 1) * (TW + p.KW - 1);
-    const size_t lds = ((npix * ROWB + 255) & ~255) + 2 * BN * ROWB;
+    const size_t lds = ((npix * ROWP + 255) & ~255) + 2 * BN * ROWP;
     const int nitem = (npix * 8 + 255) / 256;
     const bool t3 = p.w_format == FF_W_F16X3;
     static const int abl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;   // timing experiments (wrong results!)
