@@ -30,6 +30,7 @@ class PackedConv:
         self.kh, self.kw = c0.kernel_size
         self.stride = c0.stride[0]
         self.pad = tuple(c0.padding)
+        self.dil = c0.dilation[0]
         self.cin = c0.in_channels
         self.cin_pad = cin_pad if cin_pad is not None else (self.cin + 3) // 4 * 4
         self.cout = sum(c.out_channels for c in self.convs)
@@ -87,7 +88,17 @@ class PackedConv:
         w, b = self.get()
         if not isinstance(xs, (list, tuple)):
             xs = [xs]
-        return ops.conv2d(xs, w, b, self.cout, self.kh, self.kw, self.stride, self.pad, act=act, w_fmt=self.fmt, **kw)
+        return ops.conv2d(xs, w, b, self.cout, self.kh, self.kw, self.stride, self.pad, act=act, w_fmt=self.fmt,
+                          dilation=self.dil, **kw)
+
+    def params(self):
+        """Parameter tensors in the order ConvFn receives (and returns gradients for) them."""
+        return [t for cv in self.convs for t in (cv.weight, cv.bias)]
+
+    def unpack_wgrad(self, dwp, j, off):
+        """Packed weight gradient rows [off, off + Cout_j) -> gradient of convs[j].weight."""
+        cv = self.convs[j]
+        return ops.unpack_conv_wgrad(dwp, cv.out_channels, self.cin, self.kh, self.kw, self.cin_pad, off)
 
 
 def _make_norm(kind: str, c: int):

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     const int co0 = t1 * BN1, k0 = t2 * BN2;
     const int grp = blockIdx.z;
     const int H = p.H, W = p.W, Wo = p.Wo, HoWo = p.Ho * p.Wo;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;     // dilation (FF-PWC refiner)
 
     const float* dy = p.y + (long long)grp * p.y_gstride;
     const float* xs0 = p.x[0] + (long long)grp * p.x_gstride[0];
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
             if (kok && m < a.M) {
                 const int b = m / HoWo, rem = m - b * HoWo;
                 const int ho = rem / Wo, wo = rem - ho * Wo;
-                const int hi = ho * p.stride - p.pad_h + dyk, wi = wo * p.stride - p.pad_w + dxk;
+                const int hi = ho * p.stride - p.pad_h + dyk * dlh, wi = wo * p.stride - p.pad_w + dxk * dlw;
                 if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
                     v = *reinterpret_cast<const f32x4*>(xpk + (long long)(b * H * W + hi * W + wi) * ldk + cik);
             }
@@ -213,7 +214,8 @@ extern "C" int ff_conv2d_wgrad(const FFConvParams* pp, float* dw, long long dw_g
     FF_REQUIRE(cin > 0, "ff_conv2d_wgrad: no input channels");
     FF_REQUIRE(ff::aligned16(p.y) && p.y_ld % 4 == 0 && p.y_ld >= (p.Cout + 3) / 4 * 4 && p.y_gstride % 4 == 0,
                "ff_conv2d_wgrad: dY must be 16-byte aligned with y_ld a multiple of 4 covering Cout rounded up to 4");
-    const int Ho = (p.H + 2 * p.pad_h - p.KH) / p.stride + 1, Wo = (p.W + 2 * p.pad_w - p.KW) / p.stride + 1;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
+    const int Ho = (p.H + 2 * p.pad_h - dlh * (p.KH - 1) - 1) / p.stride + 1, Wo = (p.W + 2 * p.pad_w - dlw * (p.KW - 1) - 1) / p.stride + 1;
     FF_REQUIRE(Ho == p.Ho && Wo == p.Wo, "ff_conv2d_wgrad: output size mismatch");
     const long long M = (long long)p.B * Ho * Wo;
     FF_REQUIRE(M < (1ll << 30), "ff_conv2d_wgrad: too many pixels");

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
     const int t1 = blockIdx.x / a.n2_tiles, t2 = blockIdx.x - t1 * a.n2_tiles;
     const int co0 = t1 * BN1, k0 = t2 * BN2;
     const int H = p.H, W = p.W, Wo = p.Wo, HoWo = p.Ho * p.Wo;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;     // dilation (FF-PWC refiner)
     float xs, xinv;
     ff::input_scale(p.x_amax, xs, xinv);
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
             if (kok && m < a.M) {
                 const int b = m / HoWo, rem = m - b * HoWo;
                 const int ho = rem / Wo, wo = rem - ho * Wo;
-                const int hi = ho * p.stride - p.pad_h + dyk, wi = wo * p.stride - p.pad_w + dxk;
+                const int hi = ho * p.stride - p.pad_h + dyk * dlh, wi = wo * p.stride - p.pad_w + dxk * dlw;
                 if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
                     v = *reinterpret_cast<const f32x4*>(xpk + (long long)(b * H * W + hi * W + wi) * ldk + cik);
             }

@@ -56,7 +56,7 @@ class GraphScope:
             for cv in pc.convs:
                 co = cv.out_channels
                 if cv.weight.requires_grad:
-                    gw = ops.unpack_conv_wgrad(dwp, co, pc.cin, pc.kh, pc.kw, pc.cin_pad, off)
+                    gw = pc.unpack_wgrad(dwp, pc.convs.index(cv), off)
                     cv.weight.grad = gw if cv.weight.grad is None else cv.weight.grad + gw
                 if cv.bias is not None and cv.bias.requires_grad:
                     gb = db[off:off + co].clone()
@@ -98,7 +98,7 @@ class ConvFn(torch.autograd.Function):
             full = ops.empty_nhwc(bsz, ho, wo, (pc.cout + 3) // 4 * 4, xs[0])
             out = full[..., :pc.cout]
         y = ops.conv2d(xs, w, b, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, act=act, out=out, res=res,
-                       out_scale=out_scale, w_fmt=pc.fmt)
+                       out_scale=out_scale, w_fmt=pc.fmt, dilation=pc.dil)
         if pad_out:
             if fill_tail is not None:
                 fill_tail(full)
@@ -133,8 +133,9 @@ class ConvFn(torch.autograd.Function):
                 gi = ops.dilate2(g, h + 2 * pc.pad[0] - pc.kh + 1, w + 2 * pc.pad[1] - pc.kw + 1)
             elif pc.stride != 1:
                 raise NotImplementedError("stride > 2")
-            dx = ops.conv2d([gi], wd, None, cin_tot, pc.kh, pc.kw, 1, (pc.kh - 1 - pc.pad[0], pc.kw - 1 - pc.pad[1]),
-                            w_fmt=dfmt, x_amax=amax if dfmt else None)
+            d = pc.dil
+            dx = ops.conv2d([gi], wd, None, cin_tot, pc.kh, pc.kw, 1, (d * (pc.kh - 1) - pc.pad[0], d * (pc.kw - 1) - pc.pad[1]),
+                            w_fmt=dfmt, x_amax=amax if dfmt else None, dilation=d)
             off = 0
             for i, x in enumerate(xs):
                 if ctx.needs_input_grad[7 + i]:
@@ -153,20 +154,21 @@ class ConvFn(torch.autograd.Function):
                 kdim = pc.kh * pc.kw * sum(x.shape[3] for x in xs)
                 z = torch.zeros(pc.cout * kdim + pc.cout, dtype=torch.float32, device=g.device)
                 acc = scope.acc[pc] = (z[:pc.cout * kdim].view(pc.cout, kdim), z[pc.cout * kdim:])
-            ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True, dw=acc[0], db=acc[1])
+            ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True, dw=acc[0], db=acc[1],
+                             dilation=pc.dil)
             scope.live[pc] -= 1
             if scope.live[pc] > 0:
                 scope.queue_flush()
                 return tuple(grads + [None] * (2 * len(pc.convs)))
             dwp, db = scope.acc.pop(pc)
         elif need_w:   # weight + bias gradient in one launch (f16 matrix pipe unless the conv precision is fp32)
-            dwp, db = ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True)
+            dwp, db = ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True, dilation=pc.dil)
         off = 0
         for j, cv in enumerate(pc.convs):
             co = cv.out_channels
             gw = gb = None
             if ctx.needs_input_grad[base + 2 * j]:
-                gw = ops.unpack_conv_wgrad(dwp, co, pc.cin, pc.kh, pc.kw, pc.cin_pad, off)
+                gw = pc.unpack_wgrad(dwp, j, off)
             if ctx.needs_input_grad[base + 2 * j + 1]:
                 gb = db[off:off + co]
             grads += [gw, gb]
@@ -369,7 +371,7 @@ def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail
     """Convolution through a PackedConv group.  pad_out: return the channel-padded tensor."""
     if not isinstance(xs, (list, tuple)):
         xs = [xs]
-    params = [t for cv in pc.convs for t in (cv.weight, cv.bias)]
+    params = pc.params()
     if recording(*xs, res, *params):
         args = list(xs) + ([res] if res is not None else []) + params
         return ConvFn.apply(pc, act, out_scale, len(xs), res is not None, pad_out, fill_tail, *args)

@@ -460,8 +460,9 @@ def nhwc_to_nchw(x: Tensor) -> Tensor:
 # ----------------------------------------------------------------------------
 # backward wrappers
 # ----------------------------------------------------------------------------
-def _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo):
+def _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo, dilation=1):
     p = FFConvParams()
+    p.dil_h = p.dil_w = dilation
     for i, x in enumerate(xs):
         p.x[i], p.x_ld[i], p.x_c[i], p.x_gstride[i] = x.data_ptr(), _ld(x), x.shape[3], 0
     p.groups, p.B, p.H, p.W = 1, b, h, w
@@ -473,7 +474,7 @@ def _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo):
 
 def conv2d_wgrad(xs: Sequence[Tensor], g: Tensor, cout: int, kh: int, kw: int, stride: int, pad,
                  g_amax: Optional[Tensor] = None, want_db: bool = False, dw: Optional[Tensor] = None,
-                 db: Optional[Tensor] = None):
+                 db: Optional[Tensor] = None, dilation: int = 1):
     """packed dW [cout][kh*kw*cin] from inputs `xs` and output gradient g (B,Ho,Wo,>=cout, ld % 4 == 0).
     With g_amax (bits of max|g|, act_bwd) and a split conv format the kernel runs on the f16 matrix pipe and can
     also return the bias gradient: -> dW, or (dW, db) when want_db.  `dw` / `db`: existing buffers to ADD into
@@ -484,7 +485,7 @@ def conv2d_wgrad(xs: Sequence[Tensor], g: Tensor, cout: int, kh: int, kw: int, s
     if dw is None:
         dw = torch.zeros((cout, kh * kw * cin), dtype=torch.float32, device=g.device)
     assert dw.shape == (cout, kh * kw * cin) and dw.is_contiguous()
-    p = _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo)
+    p = _conv_params(xs, b, h, w, cout, kh, kw, stride, pad, ho, wo, dilation)
     p.y, p.y_ld = g.data_ptr(), _ld(g)
     fmt = w_format() if g_amax is not None else 0
     if fmt:

@@ -376,3 +376,32 @@ def test_overfitting_a_fixed_batch_reduces_the_loss(det_sd):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+@pytest.mark.parametrize("dil,act", [(2, 4), (4, 0), (16, 4)])
+def test_dilated_leaky_conv_backward(mods, dil, act):
+    """FF-PWC refiner convs (ff_pwcnet.py:350-364): 3x3, dilation = padding in {1,2,4,8,16}, LeakyReLU(0.1):
+    forward, input gradient (same dilation, flipped weights) and weight / bias gradients."""
+    import copy
+    g = torch.Generator().manual_seed(dil)
+    cin, cout, b, h, w = 64, 96, 2, 40, 56
+    x = torch.randn(b, cin, h, w, generator=g, requires_grad=True)
+    cv = nn.Conv2d(cin, cout, 3, 1, dil, dil)
+    with torch.no_grad():
+        cv.weight.copy_(torch.randn(cv.weight.shape, generator=g) / (cin * 9) ** 0.5)
+        cv.bias.copy_(torch.randn(cv.bias.shape, generator=g))
+    ref = cv(x)
+    ref = F.leaky_relu(ref, 0.1) if act == 4 else ref
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    dcv = copy.deepcopy(cv).to(DEV)
+    dcv.weight.grad = dcv.bias.grad = None
+    pc = mods.cce.PackedConv([dcv])
+    assert pc.dil == dil
+    xd = nhwc(x).requires_grad_(True)
+    out = mods.fn.conv(pc, xd, act=act)
+    close(nchw(out), ref.detach(), what="forward")
+    out.backward(nhwc(gy))
+    close(nchw(xd.grad), x.grad, what="dx")
+    close(dcv.weight.grad.cpu(), cv.weight.grad, what="dW")
+    close(dcv.bias.grad.cpu(), cv.bias.grad, what="db")
