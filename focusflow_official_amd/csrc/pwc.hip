@@ -190,6 +190,68 @@ __global__ void backwarp_kernel(const float* __restrict__ in, int in_ld, const f
     }
 }
 
+// Backward of backwarp (ff_pwcnet.py:27-47 = grid_sample(bilinear, zeros, align_corners=False) times a thresholded
+// validity mask, whose own gradient is zero: the mask is overwritten in place with constants).  One wave per
+// output pixel, lane = 4-channel group:
+//   d_in  += w_k * m * gout            scattered to the four source pixels (fp32 atomics; d_in zeroed by the caller)
+//   d_flow = m * sum_c gout_c * d(sample_c)/d(u)  *  W/(W-1) * fscale     (u = ((g+1)*W-1)/2, g = grid + flow/((W-1)/2))
+__global__ __launch_bounds__(256) void backwarp_bwd_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ flow,
+                                                           int flow_ld, float fscale, const float* __restrict__ gout, int g_ld,
+                                                           float* __restrict__ din, int din_ld, float* __restrict__ dflow,
+                                                           int dflow_ld, int B, int H, int W, int C) {
+    const int lane = threadIdx.x & 63, cg = C >> 2;
+    const long long npix = (long long)B * H * W;
+    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4) {
+        const int x = (int)(pix % W), y = (int)((pix / W) % H);
+        const long long b = pix / ((long long)W * H);
+        const float fx = flow[pix * flow_ld] * fscale, fy = flow[pix * flow_ld + 1] * fscale;
+        const float gx = (-1.f + 1.f / W) + x * ((2.f - 2.f / W) / (W - 1)) + fx / ((W - 1.f) / 2.f);
+        const float gy = (-1.f + 1.f / H) + y * ((2.f - 2.f / H) / (H - 1)) + fy / ((H - 1.f) / 2.f);
+        const float ux = ((gx + 1.f) * W - 1.f) / 2.f, uy = ((gy + 1.f) * H - 1.f) / 2.f;
+        const float x0f = floorf(ux), y0f = floorf(uy);
+        const int ix = (int)x0f, iy = (int)y0f;
+        const float wx = ux - x0f, wy = uy - y0f;
+        const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy), w10 = (1.f - wx) * wy, w11 = wx * wy;
+        const bool i00 = (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
+        const bool i01 = (unsigned)(ix + 1) < (unsigned)W && (unsigned)iy < (unsigned)H;
+        const bool i10 = (unsigned)ix < (unsigned)W && (unsigned)(iy + 1) < (unsigned)H;
+        const bool i11 = (unsigned)(ix + 1) < (unsigned)W && (unsigned)(iy + 1) < (unsigned)H;
+        const float ones = (i00 ? w00 : 0.f) + (i01 ? w01 : 0.f) + (i10 ? w10 : 0.f) + (i11 ? w11 : 0.f);
+        const bool on = ones > 0.999f;                          // wave-uniform
+        float dux = 0.f, duy = 0.f;
+        if (on) {
+            const long long base = b * H * W;
+            for (int g = lane; g < cg; g += 64) {
+                const f32x4 go = *reinterpret_cast<const f32x4*>(gout + pix * g_ld + g * 4);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 v00 = i00 ? *reinterpret_cast<const f32x4*>(in + (base + (long long)iy * W + ix) * in_ld + g * 4) : z;
+                const f32x4 v01 = i01 ? *reinterpret_cast<const f32x4*>(in + (base + (long long)iy * W + ix + 1) * in_ld + g * 4) : z;
+                const f32x4 v10 = i10 ? *reinterpret_cast<const f32x4*>(in + (base + (long long)(iy + 1) * W + ix) * in_ld + g * 4) : z;
+                const f32x4 v11 = i11 ? *reinterpret_cast<const f32x4*>(in + (base + (long long)(iy + 1) * W + ix + 1) * in_ld + g * 4) : z;
+                const f32x4 ddx = (v01 - v00) * (1.f - wy) + (v11 - v10) * wy;
+                const f32x4 ddy = (v10 - v00) * (1.f - wx) + (v11 - v01) * wx;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dux += go[j] * ddx[j];
+                    duy += go[j] * ddy[j];
+                    if (din) {
+                        if (i00) atomicAdd(din + (base + (long long)iy * W + ix) * din_ld + g * 4 + j, w00 * go[j]);
+                        if (i01) atomicAdd(din + (base + (long long)iy * W + ix + 1) * din_ld + g * 4 + j, w01 * go[j]);
+                        if (i10) atomicAdd(din + (base + (long long)(iy + 1) * W + ix) * din_ld + g * 4 + j, w10 * go[j]);
+                        if (i11) atomicAdd(din + (base + (long long)(iy + 1) * W + ix + 1) * din_ld + g * 4 + j, w11 * go[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { dux += __shfl_xor(dux, o); duy += __shfl_xor(duy, o); }
+        if (lane == 0 && dflow) {
+            dflow[pix * dflow_ld] = dux * ((float)W / (W - 1.f)) * fscale;
+            dflow[pix * dflow_ld + 1] = duy * ((float)H / (H - 1.f)) * fscale;
+        }
+    }
+}
+
 int check_cv(const char* who, const float* a, int a_ld, const float* b, int b_ld, const float* o, int o_ld, int B, int H,
              int W, int C, int a_c, int o_c) {
     FF_REQUIRE(a && b && o && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "%s: bad shape (C must be a multiple of 4)", who);
@@ -239,4 +301,19 @@ extern "C" int ff_pwc_backwarp(const float* in, int in_ld, const float* flow, in
     if (n > 4096) n = 4096;
     backwarp_kernel<<<(unsigned)n, 256, 0, static_cast<hipStream_t>(stream)>>>(in, in_ld, flow, flow_ld, flow_scale, out, out_ld, B, H, W, C);
     return ff::check_launch("ff_pwc_backwarp");
+}
+
+extern "C" int ff_pwc_backwarp_bwd(const float* in, int in_ld, const float* flow, int flow_ld, float flow_scale, const float* gout,
+                                   int gout_ld, float* din, int din_ld, float* dflow, int dflow_ld, int B, int H, int W, int C,
+                                   void* stream) {
+    FF_REQUIRE(in && flow && gout && (din || dflow), "ff_pwc_backwarp_bwd: null pointer");
+    FF_REQUIRE(B > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0 && in_ld >= C && gout_ld >= C && flow_ld >= 2 && (!din || din_ld >= C) &&
+               (!dflow || dflow_ld >= 2), "ff_pwc_backwarp_bwd: bad shape");
+    FF_REQUIRE(in_ld % 4 == 0 && gout_ld % 4 == 0 && ff::aligned16(in) && ff::aligned16(gout), "ff_pwc_backwarp_bwd: alignment");
+    const long long npix = (long long)B * H * W;
+    long long blocks = (npix + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    backwarp_bwd_kernel<<<(unsigned)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(in, in_ld, flow, flow_ld, flow_scale, gout, gout_ld,
+                                                                                      din, din_ld, dflow, dflow_ld, B, H, W, C);
+    return ff::check_launch("ff_pwc_backwarp_bwd");
 }

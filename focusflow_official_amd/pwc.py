@@ -51,11 +51,40 @@ def FunctionCorrelation(tenOne: torch.Tensor, tenTwo: torch.Tensor) -> torch.Ten
     return _FunctionCorrelation.apply(tenOne, tenTwo)
 
 
-def backwarp(tenInput: torch.Tensor, tenFlow: torch.Tensor, flow_scale: float = 1.0) -> torch.Tensor:
-    """NHWC input (B,H,W,C), flow (B,H,W,>=2) [x,y] in pixels (times flow_scale) -> warped (B,H,W,C) with the
-    validity mask applied."""
+def _backwarp_fwd(tenInput, tenFlow, flow_scale):
     b, h, w, c = tenInput.shape
     out = empty_nhwc(b, h, w, c, tenInput)
     _hip.call("ff_pwc_backwarp", _p(tenInput), _ld(tenInput), _p(tenFlow), _ld(tenFlow), float(flow_scale), _p(out), c,
               b, h, w, c, _stream())
     return out
+
+
+class _Backwarp(torch.autograd.Function):
+    """grid_sample(bilinear, zeros, align_corners=False) x validity mask; the mask itself carries no gradient
+    (ff_pwcnet.py:45 overwrites it with constants)."""
+
+    @staticmethod
+    def forward(ctx, tenInput, tenFlow, flow_scale):
+        tenInput, tenFlow = tenInput.contiguous(), tenFlow.contiguous()
+        ctx.save_for_backward(tenInput, tenFlow)
+        ctx.scale = float(flow_scale)
+        return _backwarp_fwd(tenInput, tenFlow, flow_scale)
+
+    @staticmethod
+    def backward(ctx, gout):
+        tenInput, tenFlow = ctx.saved_tensors
+        gout = gout.contiguous()
+        b, h, w, c = tenInput.shape
+        din = torch.zeros_like(tenInput) if ctx.needs_input_grad[0] else None
+        dflow = torch.zeros_like(tenFlow) if ctx.needs_input_grad[1] else None      # channels >= 2 (padding) stay zero
+        _hip.call("ff_pwc_backwarp_bwd", _p(tenInput), _ld(tenInput), _p(tenFlow), _ld(tenFlow), ctx.scale, _p(gout), _ld(gout),
+                  _p(din), c, _p(dflow), tenFlow.shape[3], b, h, w, c, _stream())
+        return din, dflow, None
+
+
+def backwarp(tenInput: torch.Tensor, tenFlow: torch.Tensor, flow_scale: float = 1.0) -> torch.Tensor:
+    """NHWC input (B,H,W,C), flow (B,H,W,>=2) [x,y] in pixels (times flow_scale) -> warped (B,H,W,C) with the
+    validity mask applied."""
+    if torch.is_grad_enabled() and (tenInput.requires_grad or tenFlow.requires_grad):
+        return _Backwarp.apply(tenInput, tenFlow, flow_scale)
+    return _backwarp_fwd(tenInput, tenFlow, flow_scale)

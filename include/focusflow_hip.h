@@ -236,6 +236,11 @@ int ff_pwc_gout_transpose(const float* g, int g_ld, float* gt, int gt_ld, int B,
 /* out = grid_sample(in, grid + flow, bilinear, zeros, align_corners=False) * (warped ones > 0.999) */
 int ff_pwc_backwarp(const float* in, int in_ld, const float* flow, int flow_ld, float flow_scale,
                     float* out, int out_ld, int B, int H, int W, int C, void* stream);
+/* its backward (GridSampler2DBackward times the validity mask, whose own gradient is zero: ff_pwcnet.py:45 overwrites
+ * it with constants): din (nullable, CALLER ZEROES, fp32 atomics) and dflow (nullable, channels 0/1 written) */
+int ff_pwc_backwarp_bwd(const float* in, int in_ld, const float* flow, int flow_ld, float flow_scale, const float* gout,
+                        int gout_ld, float* din, int din_ld, float* dflow, int dflow_ld, int B, int H, int W, int C,
+                        void* stream);
 
 /* ========================================================================
  * Fused sequence loss (core/models/ff-raft/losses/losses.py:18-130: EPELoss, CPCL, MixLoss).

@@ -171,3 +171,31 @@ def test_ffpwcnet_matches_reference_layer_vectors(ft):
         for lvl, fl in enumerate(flows):
             close(fl.cpu(), torch.from_numpy(g[f"flow{lvl + 2}_{tag}"]), tol=2e-4, what=f"{ft} {tag} flow level {lvl + 2}")
         close(full.cpu(), torch.from_numpy(g[f"full_{tag}"]), tol=2e-4, what=f"{ft} {tag} test_mode flow")
+
+
+@pytest.mark.parametrize("b,c,h,w,scale", [(2, 32, 28, 40, 5.0), (1, 196, 7, 16, 0.625), (1, 64, 17, 23, 2.5)])
+def test_backwarp_backward(b, c, h, w, scale):
+    """Gradients of backwarp w.r.t. the warped features and the flow vs autograd through the oracle's restatement
+    (ATen grid_sample + the constant validity mask, ff_pwcnet.py:27-47)."""
+    from focusflow_official_amd import pwc
+    g = torch.Generator().manual_seed(b * 100 + c)
+    x = torch.randn(b, c, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    fl = (torch.randn(b, 2, h, w, generator=g, dtype=torch.float64) * 1.5).requires_grad_(True)
+    gout = torch.randn(b, c, h, w, generator=g, dtype=torch.float64)
+    ref = pwc_ref.backwarp(x, fl * scale)
+    ref.backward(gout)
+    xd = x.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    fd = torch.zeros(b, h, w, 4, device=DEV)
+    fd[..., :2] = fl.detach().float().permute(0, 2, 3, 1).to(DEV)
+    fd.requires_grad_(True)
+    out = pwc.backwarp(xd, fd, scale)
+    close(out.detach().cpu().permute(0, 3, 1, 2), ref.detach(), tol=2e-5, what="backwarp fwd")
+    out.backward(gout.float().permute(0, 2, 3, 1).contiguous().to(DEV))
+    # pixels whose sample position sits within rounding distance of a cell border may pick the neighbouring cell in
+    # fp32: compare with a small budget of outliers, as the forward test does
+    dx = xd.grad.cpu().permute(0, 3, 1, 2).double()
+    dfl = fd.grad.cpu()[..., :2].permute(0, 3, 1, 2).double()
+    for got, want, what in ((dx, x.grad, "d input"), (dfl, fl.grad, "d flow")):
+        err = (got - want).abs() / (want.abs().max() + 1e-12)
+        assert float((err > 2e-4).float().mean()) < 2e-3, f"{what}: {float(err.max()):.3e}"
+    assert float(fd.grad[..., 2:].abs().max()) == 0.0
