@@ -14,13 +14,14 @@ it.  Packed weights get zero columns at the pad channels.
 
 Built: 'point' masks, every fusion type, any input size (sizes that are not multiples of 64 are bilinearly
 resized first and the flow is resized / rescaled back, as the reference does; BASELINE config 4, 448x1024,
-needs no resize).  Training (backward of transposed conv / backwarp) is a later row.
+needs no resize).  Training: when gradients are recorded every step goes through an autograd Function whose backward is HIP as well
+(conv / transposed conv / dilated conv gradients, cost volume, backwarp); torch.cat builds the DenseNet tensors.
 """
 import torch
 import torch.nn as nn
 
-from . import _hip, ops, pwc
-from .cce import FusionUnit
+from . import _hip, fn, ops, pwc
+from .cce import FusionUnit, PackedConv
 from .ops import ACT_LEAKY, ACT_NONE, _p, _stream
 
 LEVEL_CH = [16, 32, 64, 96, 128, 196]
@@ -69,6 +70,113 @@ class _Packed:
                           dilation=dilation)
 
 
+class _TrainPacked(PackedConv):
+    """PackedConv for the autograd path when the input is a padded-piece tensor (pieces = [(real, padded), ...]) and /
+    or the module is a ConvTranspose2d (run as a stride-1 conv over the zero-dilated input with the flipped,
+    transposed kernel).  The kernels see a "virtual" weight (Cout, sum(padded), k, k); gradients are mapped back."""
+
+    def __init__(self, conv, pieces, transposed=False):
+        self.convs = [conv]
+        self.transposed = transposed
+        w = conv.weight
+        self.cout = w.shape[1] if transposed else w.shape[0]
+        self.kh, self.kw = w.shape[2], w.shape[3]
+        self.stride = 1 if transposed else conv.stride[0]
+        self.pad = (self.kh - 1 - conv.padding[0], self.kw - 1 - conv.padding[1]) if transposed else tuple(conv.padding)
+        self.dil = 1 if transposed else conv.dilation[0]
+        self.cin = self.cin_pad = sum(p for _, p in pieces)
+        idx, pos = [], 0
+        for real, padded in pieces:
+            idx += list(range(pos, pos + real))
+            pos += padded
+        assert len(idx) == (w.shape[0] if transposed else w.shape[1])
+        self._idx = torch.tensor(idx, dtype=torch.long)
+        self._key = self._dkey = None
+        self.w = self.b = self.wd = None
+
+    def _virtual(self):
+        cv = self.convs[0]
+        w = cv.weight.detach()
+        if self.transposed:   # ConvTranspose2d [Cin][Cout][k][k] -> forward conv [Cout][Cin][k][k], flipped
+            w = w.permute(1, 0, 2, 3).flip(2, 3)
+        wp = torch.zeros((self.cout, self.cin_pad, self.kh, self.kw), dtype=torch.float32, device=w.device)
+        wp[:, self._idx.to(w.device)] = w
+        return wp
+
+    def get(self):
+        cv = self.convs[0]
+        key = (ops.conv_precision(), cv.weight._version, cv.weight.data_ptr(), cv.bias._version)
+        if key != self._key:
+            wp = self._virtual()
+            self.w = torch.empty((self.cout, self.kh * self.kw * self.cin_pad), dtype=torch.float32, device=wp.device)
+            ops.pack_conv_weight(wp, self.w, self.cin_pad, 0)
+            small = self.cout <= 2 and (self.kh, self.kw, self.stride, self.dil) == (3, 3, 1, 1) and self.pad == (1, 1)
+            self.fmt = 0 if small else ops.w_format()
+            if self.fmt:
+                self.w = ops.pack_split(self.w)
+            self.b = cv.bias.detach()
+            self._key = key
+        return self.w, self.b
+
+    def get_dgrad(self):
+        cv = self.convs[0]
+        key = (ops.conv_precision(), cv.weight._version, cv.weight.data_ptr())
+        if key != self._dkey:
+            cout_pad = (self.cout + 3) // 4 * 4
+            self.wd = torch.zeros((self.cin_pad, self.kh * self.kw * cout_pad), dtype=torch.float32, device=cv.weight.device)
+            ops.pack_conv_weight_dgrad(self._virtual().contiguous(), self.wd, cout_pad, 0)
+            self.dfmt = ops.w_format()
+            if self.dfmt:
+                self.wd = ops.pack_split(self.wd)
+            self._dkey = key
+        return self.wd, self.dfmt
+
+    def unpack_wgrad(self, dwp, j, off):
+        full = ops.unpack_conv_wgrad(dwp, self.cout, self.cin_pad, self.kh, self.kw, self.cin_pad, off)   # virtual layout
+        g = full[:, self._idx.to(full.device)]
+        return g.flip(2, 3).permute(1, 0, 2, 3).contiguous() if self.transposed else g.contiguous()
+
+
+class _Dilate2(torch.autograd.Function):
+    """Zero-dilation by 2 (the first half of a stride-2 transposed convolution); backward = the even samples."""
+
+    @staticmethod
+    def forward(ctx, x):
+        b, h, w, _ = x.shape
+        return ops.dilate2(x.contiguous(), 2 * h - 1, 2 * w - 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, ::2, ::2, :].contiguous()
+
+
+class _CostVolume84(torch.autograd.Function):
+    """FunctionCorrelation written into an 84-channel tensor (81 + 3 zero pad channels: conv inputs come in groups of 4)."""
+
+    @staticmethod
+    def forward(ctx, one, two):
+        one, two = one.contiguous(), two.contiguous()
+        ctx.save_for_backward(one, two)
+        b, h, w, _ = one.shape
+        out = torch.zeros((b, h, w, 84), dtype=torch.float32, device=one.device)
+        pwc._cv_fwd(one, two, out=out[..., :81])
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        one, two = ctx.saved_tensors
+        gout = gout.contiguous()
+        b, h, w, _ = gout.shape
+        g81 = gout[..., :81]
+        g_one = pwc._cv_bwd(g81, two) if ctx.needs_input_grad[0] else None
+        g_two = None
+        if ctx.needs_input_grad[1]:
+            gt = ops.empty_nhwc(b, h, w, 81, gout)
+            _hip.call("ff_pwc_gout_transpose", _p(g81), ops._ld(g81), _p(gt), 81, b, h, w, _stream())
+            g_two = pwc._cv_bwd(gt, one)
+        return g_one, g_two
+
+
 def _stage(cin, c):
     return nn.Sequential(nn.Conv2d(cin, c, 3, 2, 1), nn.LeakyReLU(0.1), nn.Conv2d(c, c, 3, 1, 1), nn.LeakyReLU(0.1),
                          nn.Conv2d(c, c, 3, 1, 1), nn.LeakyReLU(0.1))
@@ -89,6 +197,20 @@ class Extractor(nn.Module):
                 self._packs[prefix + name] = [_Packed(st[0], [(cin, _pad4(cin))]), _Packed(st[2], [(c, c)]), _Packed(st[4], [(c, c)])]
             setattr(self, f"fusion{lvl + 1}", FusionUnit(c, fusion_type, lvl < 5))
             cin = c
+        # autograd path: plain PackedConvs (the first conv of every branch reads a 4-channel NHWC4 image)
+        self._tpacks = {k: [PackedConv([getattr(self, k)[2 * i]], 4 if (i == 0 and k.endswith("netOne")) else None) for i in range(3)]
+                        for k in self._packs}
+
+    def run_train(self, x, mask):
+        feats = []
+        for lvl, name in enumerate(self.NAMES):
+            for pk in self._tpacks[name]:
+                x = fn.conv(pk, x, act=ACT_LEAKY)
+            for pk in self._tpacks["mask_" + name]:
+                mask = fn.conv(pk, mask, act=ACT_LEAKY)
+            mask, x = getattr(self, f"fusion{lvl + 1}").run(mask, x)
+            feats.append(x)
+        return feats
 
     def run(self, x, mask):
         feats = []
@@ -127,6 +249,27 @@ class Decoder(nn.Module):
         self.netSix = nn.Sequential(nn.Conv2d(c + 448, 2, 3, 1, 1))
         self._six = _Packed(self.netSix[0], grown + self.base)
         self.width = 448 + sum(p for _, p in self.base)
+        # autograd path: the same padded-piece layouts, through ConvFn
+        self._tconvs = [_TrainPacked(pk.conv, pk.pieces) for _, pk in self._convs]
+        self._tsix = _TrainPacked(self.netSix[0], grown + self.base)
+        if level < 6:
+            self._tupflow = _TrainPacked(self.netUpflow, [(2, 4)], transposed=True)
+            self._tupfeat = _TrainPacked(self.netUpfeat, self._upfeat.pieces, transposed=True)
+
+    def run_train(self, one, two, prev):
+        """Autograd twin of run(): torch.cat builds the DenseNet tensor (same padded-piece channel order)."""
+        zero_tail = lambda full: full[..., 2:].zero_()      # noqa: E731  (2 real channels + 2 zero pads)
+        if prev is None:
+            feat = fn.ActFn.apply(_CostVolume84.apply(one, two), ACT_LEAKY)
+        else:
+            flow = fn.conv(self._tupflow, _Dilate2.apply(prev["tenFlow"]), pad_out=True, fill_tail=zero_tail)
+            upfeat = fn.conv(self._tupfeat, _Dilate2.apply(prev["tenFeat"]), pad_out=True, fill_tail=zero_tail)
+            warped = pwc.backwarp(two, flow, BACKWARP_SCALE[self.level])
+            vol = fn.ActFn.apply(_CostVolume84.apply(one, warped), ACT_LEAKY)
+            feat = torch.cat([vol, one, flow, upfeat], 3)
+        for pk in self._tconvs:
+            feat = torch.cat([fn.conv(pk, feat, act=ACT_LEAKY), feat], 3)
+        return {"tenFlow": fn.conv(self._tsix, feat, pad_out=True, fill_tail=zero_tail), "tenFeat": feat}
 
     def run(self, one, two, prev):
         """-> dict(tenFlow (B,h,w,4 padded), tenFeat = the level buffer)."""
@@ -168,6 +311,15 @@ class Refiner(nn.Module):
         self.netMain = nn.Sequential(*layers)
         first = [(c, c) for _, c in GROWTH] + [(81, 84), (32, 32), (2, 4), (2, 4)]
         self._packs = [_Packed(self.netMain[0], first)] + [_Packed(self.netMain[2 * i], [(chans[i][0], chans[i][0])]) for i in range(1, 7)]
+        self._tpacks = [_TrainPacked(self.netMain[0], first)] + [PackedConv([self.netMain[2 * i]]) for i in range(1, 7)]
+
+    def run_train(self, feat, flow):
+        x = feat
+        for i, pk in enumerate(self._tpacks):
+            if i < 6:
+                x = fn.conv(pk, x, act=ACT_LEAKY)
+            else:   # tenFlow + netRefiner(tenFeat), ff_pwcnet.py:424: the residual add rides in the conv epilogue
+                return fn.conv(pk, x, res=flow[..., :2])
 
     def run(self, feat, flow):
         x = feat
@@ -214,8 +366,7 @@ class FF_PWCNET(nn.Module):
         return dst
 
     def forward(self, tenOne, tenTwo, mask1, mask2, test_mode=False):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("FF_PWCNET on HIP is inference-only this round: call it under torch.no_grad()")
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         ops._require_gpu(tenOne)
         b, _, h0, w0 = tenOne.shape
         assert mask1.shape[1] == 1
@@ -228,19 +379,35 @@ class FF_PWCNET(nn.Module):
         else:
             i1, i2, m1 = self._resized4(tenOne, b, h, w), self._resized4(tenTwo, b, h, w), self._resized4(mask1, b, h, w)
         m2 = self._nhwc4(None, b, h, w, tenOne, fill=255.0)           # ones_like(mask1) * 255
-        f1 = self.netExtractor.run(i1, m1)
-        f2 = self.netExtractor.run(i2, m2)
+        decoders = ((6, self.netSix), (5, self.netFiv), (4, self.netFou), (3, self.netThr), (2, self.netTwo))
         est = None
         flows = []
-        for level, dec in ((6, self.netSix), (5, self.netFiv), (4, self.netFou), (3, self.netThr), (2, self.netTwo)):
-            est = dec.run(f1[level - 1], f2[level - 1], est)
-            if level == 2:
-                est["tenFlow"] = self.netRefiner.run(est["tenFeat"], est["tenFlow"])
-            flows.insert(0, est["tenFlow"])
+        if train:   # every step through an autograd Function (fn.GraphScope shares the extractor's weight gradients)
+            fn.begin_graph()
+            try:
+                f1 = self.netExtractor.run_train(i1, m1)
+                f2 = self.netExtractor.run_train(i2, m2)
+                for level, dec in decoders:
+                    est = dec.run_train(f1[level - 1], f2[level - 1], est)
+                    if level == 2:
+                        est["tenFlow"] = self.netRefiner.run_train(est["tenFeat"], est["tenFlow"])
+                    flows.insert(0, est["tenFlow"])
+            finally:
+                fn.end_graph()
+        else:
+            f1 = self.netExtractor.run(i1, m1)
+            f2 = self.netExtractor.run(i2, m2)
+            for level, dec in decoders:
+                est = dec.run(f1[level - 1], f2[level - 1], est)
+                if level == 2:
+                    est["tenFlow"] = self.netRefiner.run(est["tenFeat"], est["tenFlow"])
+                flows.insert(0, est["tenFlow"])
         if test_mode:
             fl = est["tenFlow"][..., :2]
             out = torch.empty((b, 2, h0, w0), dtype=torch.float32, device=tenOne.device)     # back to the caller's size,
             _hip.call("ff_resize_bilinear", _p(fl), ops._ld(fl), 2, fl.shape[1], fl.shape[2], _p(out), b, h0, w0,
                       float(w0) / w, float(h0) / h, _stream())                                   # flow rescaled (:427-431)
             return out
+        if train:   # NCHW views: the loss reads them as they are, autograd needs no extra node
+            return [f[..., :2].permute(0, 3, 1, 2) for f in flows]
         return [ops.nhwc_to_nchw(f[..., :2]) for f in flows]
