@@ -260,6 +260,23 @@ int ff_loss_accumulate(const float* pred, const float* flow_gt, const float* vma
 int ff_epe_metric(const float* pred, const float* flow_gt, const float* vmap, double* out2, int B, int H, int W,
                   void* stream);
 
+/* FF-PWC multi-scale losses (core/models/ff-pwcnet/losses/losses.py:19-261: EPELoss / CPCL / MixLoss, dense ground truth).
+ * All tensors NCHW fp32: out (B,2,h,w) one pyramid level, target (B,2,H,W), mask (B,1,H,W), gmask (B,h,w).
+ *   ff_pwc_loss_mask   gmask = G * (bilinear(mask -> h x w, align_corners=False) > 0), zero padded (:107-112, :187-191);
+ *                      *msum (fp64, CALLER ZEROES) += sum gmask
+ *   ff_pwc_loss_scale  target area-interpolated to h x w (:66, :149); E = |t-o|_2 (l1q = 0, 'pretrain') or (|t-o|_1 + eps)^q;
+ *                      *loss (fp64, CALLER ZEROES) += sum (w_plain + w_mask * gmask) * E, w_mask = w_mask_num / *msum
+ *                      (0 if *msum == 0 and zero_if_empty: MixLoss :182-183); mask_over_batch: gmask summed over the batch
+ *                      for every sample (CPCL's (B,h,w) x (B,1,h,w) broadcast, :114); grad (nullable) = d(that)/d(out)
+ *   ff_pwc_epe_mean    out2 (fp64, CALLER ZEROES) += { sum of E over all pixels of (B,2,H,W) pred vs target, pixel count } */
+int ff_pwc_loss_mask(const float* mask, const float* gauss, int ks, float* gmask, double* msum, int B, int H, int W, int h,
+                     int w, void* stream);
+int ff_pwc_loss_scale(const float* out, const float* target, const float* gmask, const double* msum, float w_plain,
+                      float w_mask_num, int zero_if_empty, int mask_over_batch, int l1q, float eps, float q, float* grad,
+                      double* loss, int B, int H, int W, int h, int w, void* stream);
+int ff_pwc_epe_mean(const float* pred, const float* target, int l1q, float eps, float q, double* out2, int B, int H, int W,
+                    void* stream);
+
 /* init_mask modes neighborG (0) / neighborE (1) / context (2), ff_raft.py:23-72, fused with the
  * [0,255] -> [-1,1] scaling: mask (B,1,H,W) [+ image (B,3,H,W)] -> NHWC4.  `table` = host-built k x k
  * Gaussian (get_kernel, :13-21) or ellipse structuring element; tmp (B*H*W floats) and gmax (1 word)

@@ -47,3 +47,33 @@ def test_loss_full_size_properties():
     l0, m0 = fn([gt.clone(), gt.clone()], gt, valid, mask)
     assert abs(l2.item() - 2 * l1.item()) < 1e-4 * l1.item()
     assert l0.item() == 0.0 and m0["epe"] == 0.0
+
+
+@pytest.mark.parametrize("tag", ["EPELoss_pretrain_k1", "EPELoss_finetune_k1", "CPCL_pretrain_k1", "CPCL_pretrain_k5", "CPCL_finetune_k1",
+                                 "CPCL_finetune_k5", "MixLoss_pretrain_k1", "MixLoss_pretrain_k5", "MixLoss_finetune_k1",
+                                 "MixLoss_finetune_k5"])
+def test_pwc_multiscale_losses_match_reference(tag):
+    """FF-PWC's EPELoss / CPCL / MixLoss (core/models/ff-pwcnet/losses/losses.py) on five pyramid levels: loss value,
+    the 'epe' metric and the gradient w.r.t. every level vs vectors from the reference's own module."""
+    from argparse import Namespace
+    from conftest import load_golden
+    from focusflow_official_amd import pwc_losses
+    g = load_golden("pwc_losses")
+    lt, mode, k = tag.split("_")
+    ks, sigma = (1, 0.01) if k == "k1" else (5, 1.7)
+    cfg = Namespace(TRAIN=Namespace(LOSS_TYPE=lt, LOSS_MODE=mode, LOSS_WEIGHTS=[0.005, 0.01, 0.02, 0.08, 0.32], LOSS_Q=0.4,
+                                    LOSS_EPSILON=0.01, LOSS_KERNEL_SIZE=ks, LOSS_SIGMA=sigma, LOSS_LAMDA=0.7))
+    crit = pwc_losses.build_losses(cfg)
+    target = torch.from_numpy(g["target"]).to(DEV)
+    mask = torch.from_numpy(g["mask"]).to(DEV)
+    preds = [torch.from_numpy(g[f"pred{i}"]).to(DEV).requires_grad_(True) for i in range(5)]
+    loss, res = crit(preds, target, False) if lt == "EPELoss" else crit(preds, target, mask, False)
+    loss.backward()
+    want_loss, want_epe = g[tag + "_loss"]
+    assert abs(loss.item() - want_loss) < 2e-5 * abs(want_loss), (loss.item(), want_loss)
+    assert abs(float(res["epe"]) - want_epe) < 2e-5 * abs(want_epe)
+    for i, p in enumerate(preds):
+        want = g[f"{tag}_grad{i}"]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want, rtol=2e-4, atol=2e-6 * float(np.abs(want).max()), err_msg=f"level {i}")
+    with pytest.raises(NotImplementedError):
+        crit(preds, target, True) if lt == "EPELoss" else crit(preds, target, mask, True)
