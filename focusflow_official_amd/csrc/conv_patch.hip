@@ -147,8 +147,14 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
 
     // lane -> output pixel of m-tile t: rows 2t (lanes 0-15) and 2t+1 (lanes 16-31), columns 0..15
+    // A ds_read_b128 is served in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): a group mixes columns of
+    // both pixel rows of the m-tile, and at the 144-byte pitch two patch rows share banks iff their indices agree
+    // mod 16.  The second pixel row sits PW = 16 + KW-1 rows further on, so its lanes take their columns rotated by
+    // KW-1: every group then reads 16 rows that differ mod 16 (it was a 2-way conflict in every group: 35 % of the
+    // LDS cycles).  Tap and m-tile offsets shift all lanes alike and keep that.
     const int li = lane & 31, lh = lane >> 5;
-    const int lrow = li >> 4, lcol = li & 15;
+    const int rot = (KW - 1) & 15;
+    const int lrow = li >> 4, lcol = ((li & 15) - lrow * rot) & 15;
     const int ntaps = KH * KW;
     const int brow = wn * 32 + li;           // weight LDS row of this lane's output channel
     const char* abase[TM];                    // this lane's patch row for tap (0, 0), k-half lh, per m-tile
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + (pi & 15);
+                    const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + ((pi - (pi >> 4) * rot) & 15);
                     rr[r] = (y < H && x < W) ? p.res[(((long long)bimg * H + y) * W + x) * p.res_ld + n] : 0.f;
                 }
 #pragma unroll
@@ -239,8 +245,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;        // 0..31: row = pi>>4, col = pi&15
-                const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + (pi & 15);
+                const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;        // 0..31: row = pi>>4, col = pi&15 rotated as the loads
+                const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + ((pi - (pi >> 4) * rot) & 15);
                 if (y >= H || x >= W) continue;
                 p.y[(((long long)bimg * H + y) * W + x) * p.y_ld + n] = vv[r];
             }
