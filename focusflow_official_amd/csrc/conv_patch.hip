@@ -5,7 +5,8 @@
 // 32-channel chunk of the input, stages the tile PLUS ITS HALO ((8+KH-1) x (16+KW-1) pixels) in LDS once —
 // already converted to the split format [x0: 32 fp16 | x1: 32 fp16] — and then walks the KH*KW taps over
 // that stationary patch: a tap only changes which LDS rows a lane reads.  Per tap the only new bytes are
-// the 64x32 weight chunk (8 KB, L2-resident, double-buffered).  Activation traffic and conversion work
+// the 64x32 weight chunk (8 KB, L2-resident; double-buffered, or single-buffered in the high-occupancy variants
+// conv_patch_kernel_occ: 35 KB of LDS, four blocks per CU).  Activation traffic and conversion work
 // drop by KH*KW, address arithmetic is precomputed once per block (buffer loads, hardware zero padding).
 //
 // Block = 256 threads = 4 waves (2 x 2): wave (wm, wn) computes output rows 4wm..4wm+3 of the tile
@@ -21,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TW = 16, BN = 64, ROWB = 128;   // tile height TH = 4*TM (template): 8 rows, or 4 for small problems
+constexpr int TW = 16, ROWB = 128;   // tile height TH = 4*TM (template): 16, 8 or 4 rows; BN = 64*TN output channels
 // LDS rows (one patch pixel / one weight row: 32 x0 + 32 x1 halfs = 128 B) sit at a 144-byte pitch instead of being
 // XOR-swizzled: 16 lanes reading 16 B from 16 consecutive rows hit 64 distinct banks, the 8-byte stores of the patch
 // and the 16-byte stores of the weights are conflict-free as well, and - no XOR - every k-slice / term / B tile is an
@@ -37,22 +38,25 @@ struct PArgs {
     long long w_row_bytes;
 };
 
-__device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {     // both halves on v's scale (ff_common.h)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const _Float16 a = (_Float16)v[j];
         h0[j] = a;
-        h1[j] = (_Float16)((v[j] - (float)a) * 2048.f);
+        h1[j] = (_Float16)(v[j] - (float)a);
     }
 }
 
-template <int TERMS, int NITEM, int TM, int ABL = 0>   // NITEM = patch items per thread; TM = MFMA tiles per wave; ABL = timing-only ablation
-__global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
-    constexpr int TH = 4 * TM;
+// NITEM = patch items per thread; TM x TN = 32-pixel x 32-channel MFMA tiles per wave (block: 2 x 2 waves =
+// 64 TM pixels x 64 TN channels); ABL = timing-only ablation
+template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB>   // WB = weight buffers in LDS
+__device__ __forceinline__ void conv_patch_body(const PArgs& a) {
+    constexpr int TH = 4 * TM, BN = 64 * TN, NW = 2 * TN;       // NW = 16-byte weight pieces per thread and tap
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FFConvParams& p = a.p;
     float xs, xinv;
     ff::input_scale(p.x_amax, xs, xinv);       // 1, 1 unless the caller passed max|x| (gradients: dgrad on the f16 pipe)
+    xs *= ff::XSPLIT; xinv *= ff::SPLIT_INV;   // operand scales of the split format
     const int KH = p.KH, KW = p.KW, PH = TH + KH - 1, PW = TW + KW - 1, NPIX = PH * PW;
     char* sP = smem;                          // [NPIX][128 B] patch, split format
     char* sW = smem + ((NPIX * ROWP + 255) & ~255);   // [2][BN] weight rows of one (tap, ci-chunk)
@@ -90,15 +94,15 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
         }
     }
     const int kq = tid & 7;
-    // weight pieces of this thread: BN rows x 8 pieces = 512 -> 2 per thread
-    int woff[2];
+    // weight pieces of this thread: BN rows x 8 pieces -> NW per thread
+    int woff[NW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NW; ++i) {
         const int n = n0 + (tid >> 3) + 32 * i;
         woff[i] = n < p.Cout ? (int)(n * a.w_row_bytes) + kq * 16 : 0x7fffffff;
     }
 
-    f32x4 rp[NITEM], rw[2];
+    f32x4 rp[NITEM], rw[NW];
     auto load_patch = [&](int c) {          // 32-channel chunk c of the concatenated input (block-uniform)
         int ci0 = c * 32;
         __amdgpu_buffer_rsrc_t rs;
@@ -128,23 +132,25 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
     };
     auto load_w = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NW; ++i)
             rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[i], kc * ROWB, 0));
     };
     auto store_w = [&](int buf) {
         char* d = sW + buf * BN * ROWP;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NW; ++i) {
             const int row = (tid >> 3) + 32 * i;
             *reinterpret_cast<f32x4*>(d + row * ROWP + kq * 16) = rw[i];
         }
     };
 
-    f32x16 acc[TM], accx[TM];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // lane -> output pixel of m-tile t: rows 2t (lanes 0-15) and 2t+1 (lanes 16-31), columns 0..15
     // A ds_read_b128 is served in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): a group mixes columns of
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
     const int rot = (KW - 1) & 15;
     const int lrow = li >> 4, lcol = ((li & 15) - lrow * rot) & 15;
     const int ntaps = KH * KW;
-    const int brow = wn * 32 + li;           // weight LDS row of this lane's output channel
+    const int brow = wn * TN * 32 + li;      // weight LDS row of this lane's first output channel (n-tile j: + 32 j)
     const char* abase[TM];                    // this lane's patch row for tap (0, 0), k-half lh, per m-tile
 #pragma unroll
     for (int t = 0; t < TM; ++t) abase[t] = sP + (((wm * TM + t) * 2 + lrow) * PW + lcol) * ROWP + lh * 16;
@@ -179,55 +185,61 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
             const char* cW = sW + wbuf * BN * ROWP + brow * ROWP + lh * 16;      // this lane's weight row, k-half lh
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                f16x8 a0[TM], a1[TM], b0, b1;
+                f16x8 a0[TM], a1[TM], b0[TN], b1[TN];
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
                     const char* pa = abase[t] + tapoff;            // + k-slice s (32 B) and term (64 B) as immediates
                     a0[t] = *reinterpret_cast<const f16x8*>(pa + s * 32);
                     if (TERMS == 3) a1[t] = *reinterpret_cast<const f16x8*>(pa + 64 + s * 32);
                 }
-                b0 = *reinterpret_cast<const f16x8*>(cW + s * 32);
-                if (TERMS == 3) b1 = *reinterpret_cast<const f16x8*>(cW + 64 + s * 32);
 #pragma unroll
-                for (int t = 0; t < TM; ++t) {
-                    if constexpr (ABL == 3) {      // no MFMA: keep operands alive
-                        asm volatile("" :: "v"(a0[t]), "v"(b0));
-                        if (TERMS == 3) asm volatile("" :: "v"(a1[t]), "v"(b1));
-                        continue;
-                    }
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b0, acc[t], 0, 0, 0);
-                    if (TERMS == 3) {
-                        accx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b1, accx[t], 0, 0, 0);
-                        accx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[t], b0, accx[t], 0, 0, 0);
-                    }
+                for (int j = 0; j < TN; ++j) {
+                    b0[j] = *reinterpret_cast<const f16x8*>(cW + j * 32 * ROWP + s * 32);
+                    if (TERMS == 3) b1[j] = *reinterpret_cast<const f16x8*>(cW + j * 32 * ROWP + 64 + s * 32);
                 }
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (ABL == 3) {      // no MFMA: keep operands alive
+                            asm volatile("" :: "v"(a0[t]), "v"(b0[j]));
+                            if (TERMS == 3) asm volatile("" :: "v"(a1[t]), "v"(b1[j]));
+                            continue;
+                        }
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b0[j], acc[t][j], 0, 0, 0);
+                        if (TERMS == 3) {
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b1[j], acc[t][j], 0, 0, 0);
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[t], b0[j], acc[t][j], 0, 0, 0);
+                        }
+                    }
             }
             if (!last && ABL != 2) {          // next tap's weights go to the other buffer
-                store_w(wbuf ^ 1);
+                if (WB == 1) __syncthreads(); // ... or, with one buffer, wait until everybody has read this tap's
+                store_w(WB == 1 ? 0 : wbuf ^ 1);
                 __syncthreads();
-                wbuf ^= 1;
+                if (WB == 2) wbuf ^= 1;
             }
         }
-        wbuf ^= 1;                            // the chunk-boundary store_w(wbuf) above targets the free buffer
+        if (WB == 2) wbuf ^= 1;               // the chunk-boundary store_w(wbuf) above targets the free buffer
     }
 
-    // epilogue: acc[t][r]: column n = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*lh = pixel index within the m-tile
-    const int n = n0 + wn * 32 + li;
-    if (n < p.Cout) {
+    // epilogue: acc[t][j][r]: column n = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*lh = pixel index within the m-tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + li;
+        if (n >= p.Cout) continue;
         const float bias = p.bias ? p.bias[n] : 0.f;
         const float cs = p.ch_scale ? p.ch_scale[n] : 1.f;
         const float ct = p.ch_scale ? p.ch_shift[n] : 0.f;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            // Three passes per tile: values first (this frees the accx registers), then ALL residual loads of the
-            // tile together (res may alias y as far as the compiler knows: inside the store loop they become 16
-            // serial load -> store round trips per lane), then add + store.
+            // Three passes per tile: values first, then ALL residual loads of the tile together (res may alias y as
+            // far as the compiler knows: inside the store loop they become 16 serial load -> store round trips per
+            // lane), then add + store.
             float vv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[t][r];
-                if (TERMS == 3) v += accx[t][r] * (1.f / 2048.f);
-                v = v * xinv + bias;
+                float v = acc[t][j][r] * xinv + bias;
                 v *= p.out_scale;
                 if (p.ch_scale) v = v * cs + ct;
                 vv[r] = ff::apply_act(v, p.act);
@@ -254,15 +266,28 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) {
     }
 }
 
-template <int TERMS, int NITEM, int TM, int ABL = 0>
+template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
+__global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, WB>(a); }
+// one weight buffer: 35 KB of LDS, so four blocks fit a CU if the registers allow four waves per SIMD
+template <int TERMS, int NITEM, int TM, int TN, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, 0, 1>(a); }
+
+template <int TERMS, int NITEM, int TM, int TN, int OCC>
+int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
+    const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC><<<(unsigned)blocks, 256, lds, s>>>(a);
+    return ff::check_launch("ff_conv2d_fwd(patch)");
+}
+
+template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
 int launch(const PArgs& a, size_t lds, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<TERMS, NITEM, TM, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<TERMS, NITEM, TM, TN, ABL, WB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         once = true;
     }
     const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
-    conv_patch_kernel<TERMS, NITEM, TM, ABL><<<(unsigned)blocks, 256, lds, s>>>(a);
+    conv_patch_kernel<TERMS, NITEM, TM, TN, ABL, WB><<<(unsigned)blocks, 256, lds, s>>>(a);
     return ff::check_launch("ff_conv2d_fwd(patch)");
 }
 
@@ -291,32 +316,47 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     a.Cin = cin;
     a.nci = cin / 32;
     a.tiles_x = (p.W + TW - 1) / TW;
-    a.n_tiles = (p.Cout + BN - 1) / BN;
     a.w_row_bytes = (long long)((p.KH * p.KW * cin + 31) / 32) * ROWB;
     max_bytes = std::max(max_bytes, (long long)p.Cout * a.w_row_bytes);
     if (max_bytes >= (1ll << 31)) return 1;
-    // 8x16 tiles unless that leaves the chip under-filled (update-block convs at 1/8 resolution): then 4x16
+    // Tile choice: th = 8 rows x 16 columns x 64 channels per block unless that leaves the chip under-filled (update
+    // block at 1/8 resolution: 4 rows).  The larger register tiles (FF_PATCH_TH=16: 256 pixels; FF_PATCH_TN=2: 128
+    // channels) exist for measurement only - they halve weight or LDS traffic per MFMA but run at 2 blocks per CU and
+    // lose 13-18 %.
     static const int force_th = getenv("FF_PATCH_TH") ? atoi(getenv("FF_PATCH_TH")) : 0;
-    const long long blocks8 = (long long)p.B * ((p.H + 7) / 8) * a.tiles_x * a.n_tiles;
-    const int th = force_th ? force_th : (blocks8 < 512 ? 4 : 8);
+    static const int force_tn = getenv("FF_PATCH_TN") ? atoi(getenv("FF_PATCH_TN")) : 0;
+    auto nblocks = [&](int th, int tn) { return (long long)p.B * ((p.H + th - 1) / th) * a.tiles_x * ((p.Cout + 64 * tn - 1) / (64 * tn)); };
+    int th = nblocks(8, 1) < 512 ? 4 : 8, tn = 1;
+    if (force_th) th = force_th;
+    if (force_tn) tn = force_tn;
     a.tiles_y = (p.H + th - 1) / th;
+    a.n_tiles = (p.Cout + 64 * tn - 1) / (64 * tn);
     const int npix = (th + p.KH - 1) * (TW + p.KW - 1);
-    const size_t lds = ((npix * ROWP + 255) & ~255) + 2 * BN * ROWP;
+    static const int lds_pad = getenv("FF_PATCH_LDS_PAD") ? atoi(getenv("FF_PATCH_LDS_PAD")) : 0;   // occupancy experiments
     const int nitem = (npix * 8 + 255) / 256;
     const bool t3 = p.w_format == FF_W_F16X3;
+    // Occupancy is what this kernel responds to (3 -> 2 blocks per CU: +15-25 % time; 3 -> 4: -5-10 %): with ONE weight
+    // buffer (a second barrier per tap instead) the 8-row tile needs 35 KB of LDS and the 4-row tile 25 KB, so 4 / 5
+    // blocks fit a CU once the registers are capped to match (amdgpu_waves_per_eu).
+    static const int wb1 = getenv("FF_PATCH_WB1") ? atoi(getenv("FF_PATCH_WB1")) : 3;   // bit 0: 8-row tiles, bit 1: 4-row tiles
+    const bool occ = t3 && tn == 1 && ((th == 8 && nitem <= 6 && (wb1 & 1)) || (th == 4 && nitem <= 4 && (wb1 & 2)));
+    const size_t lds = ((npix * ROWP + 255) & ~255) + (occ ? 1 : 2) * 64 * tn * ROWP + lds_pad;
+    if (lds > 96 * 1024) return 1;
     static const int abl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;   // timing experiments (wrong results!)
-    if (abl && th == 8 && nitem <= 6 && t3) {
-        if (abl == 1) return launch<3, 6, 2, 1>(a, lds, s);
-        if (abl == 2) return launch<3, 6, 2, 2>(a, lds, s);
-        return launch<3, 6, 2, 3>(a, lds, s);
+    if (abl && th == 8 && tn == 1 && nitem <= 6 && t3) {
+        if (abl == 1) return launch<3, 6, 2, 1, 1>(a, lds, s);
+        if (abl == 2) return launch<3, 6, 2, 1, 2>(a, lds, s);
+        return launch<3, 6, 2, 1, 3>(a, lds, s);
     }
-    if (th == 8) {
-        if (nitem <= 6) return t3 ? launch<3, 6, 2>(a, lds, s) : launch<1, 6, 2>(a, lds, s);
-        if (nitem <= 10) return t3 ? launch<3, 10, 2>(a, lds, s) : launch<1, 10, 2>(a, lds, s);
-    } else {
-        if (nitem <= 4) return t3 ? launch<3, 4, 1>(a, lds, s) : launch<1, 4, 1>(a, lds, s);
-        if (nitem <= 8) return t3 ? launch<3, 8, 1>(a, lds, s) : launch<1, 8, 1>(a, lds, s);
-    }
+    if (occ) return th == 8 ? launch_occ<3, 6, 2, 1, 4>(a, lds, s) : launch_occ<3, 4, 1, 1, 5>(a, lds, s);
+#define FF_PATCH_CASE(TH_, TN_, NI_) \
+    if (th == TH_ && tn == TN_ && nitem <= NI_) return t3 ? launch<3, NI_, TH_ / 4, TN_>(a, lds, s) : launch<1, NI_, TH_ / 4, TN_>(a, lds, s);
+    FF_PATCH_CASE(8, 1, 6) FF_PATCH_CASE(8, 1, 10)
+    FF_PATCH_CASE(4, 1, 4) FF_PATCH_CASE(4, 1, 8)
+    FF_PATCH_CASE(8, 2, 6) FF_PATCH_CASE(8, 2, 10)
+    FF_PATCH_CASE(4, 2, 4) FF_PATCH_CASE(4, 2, 8)
+    FF_PATCH_CASE(16, 1, 11) FF_PATCH_CASE(16, 1, 16)
+#undef FF_PATCH_CASE
     return 1;
 }
 }  // namespace ff

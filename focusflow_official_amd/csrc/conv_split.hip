@@ -43,7 +43,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
     for (int j = 0; j < 4; ++j) {
         const _Float16 a = (_Float16)v[j];
         h0[j] = a;
-        h1[j] = (_Float16)((v[j] - (float)a) * 2048.f);
+        h1[j] = (_Float16)(v[j] - (float)a);
     }
 }
 
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
     const FFConvParams& p = a.p;
     float xs, xinv;
     ff::input_scale(p.x_amax, xs, xinv);       // 1, 1 unless the caller passed max|x| (gradients: dgrad on the f16 pipe)
+    xs *= ff::XSPLIT; xinv *= ff::SPLIT_INV;   // operand scales of the split format (ff_common.h)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int nblk = gridDim.x;
@@ -199,13 +200,13 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
         }
     };
 
-    f32x16 acc[TM][TN], accx[TM][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (a.K + BK - 1) / BK;
     const int li = lane & 31, lh = lane >> 5;
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[i], b0[j], acc[i][j], 0, 0, 0);
                     if (TERMS == 3) {
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[i], b1[j], accx[i][j], 0, 0, 0);
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b0[j], accx[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[i], b1[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b0[j], acc[i][j], 0, 0, 0);
                     }
                 }
         }
@@ -273,14 +274,13 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
         const float ct = p.ch_scale ? p.ch_shift[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            // Three passes per tile: values first (frees the accx registers), then ALL residual loads of the tile
+            // Three passes per tile: values first, then ALL residual loads of the tile
             // together (the compiler must assume res aliases y: inside the store loop they become 16 serial
             // load -> store round trips per lane), then add + store.
             float vv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r];
-                if (TERMS == 3) v += accx[i][j][r] * (1.f / 2048.f);
                 v = v * xinv + bias;
                 v *= p.out_scale;
                 if (p.ch_scale) v = v * cs + ct;
@@ -378,9 +378,10 @@ __global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __res
         const long long r = rc / nchunks;
         const int k = c * 32 + kk;
         const float v = k < K ? src[r * K + k] : 0.f;
-        const _Float16 h0 = (_Float16)v;
+        const float sv = v * ff::WSPLIT;
+        const _Float16 h0 = (_Float16)sv;
         dst[rc * 64 + kk] = h0;
-        dst[rc * 64 + 32 + kk] = (_Float16)((v - (float)h0) * 2048.f);
+        dst[rc * 64 + 32 + kk] = (_Float16)(sv - (float)h0);
     }
 }
 

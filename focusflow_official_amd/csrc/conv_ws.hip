@@ -54,7 +54,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
     for (int j = 0; j < 4; ++j) {
         const _Float16 a = (_Float16)v[j];
         h0[j] = a;
-        h1[j] = (_Float16)((v[j] - (float)a) * 2048.f);
+        h1[j] = (_Float16)(v[j] - (float)a);
     }
 }
 
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
     auto store_px = [&](int off, const f32x4 v) {     // off = LDS byte offset of the x0 half-group (x1: piece + 4)
         f16x4 h0, h1;
-        split4(v, h0, h1);
+        split4(v * ff::XSPLIT, h0, h1);
         *reinterpret_cast<f16x4*>(smem + off) = h0;
         if (TERMS == 3) *reinterpret_cast<f16x4*>(smem + off + 64) = h1;
     };
@@ -275,11 +275,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int q = 0;
     for (int k = 0; k < n_mine; ++k) {
         const Tile tl = decode(k);
-        f32x16 acc[2], accx[2];
+        f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         for (int c = 0; c < nci; ++c, ++q) {
             // per-chunk base pointers; every tap / k-slice / term below is a compile-time offset from them
             // (folds into the ds_read offset field: no per-step address arithmetic, nothing to hoist and spill)
@@ -318,9 +318,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[tt], w0, acc[tt], 0, 0, 0);
                         if (TERMS == 3) {
 #pragma unroll
-                            for (int tt = 0; tt < 2; ++tt) accx[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[tt], w1, accx[tt], 0, 0, 0);
+                            for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[tt], w1, acc[tt], 0, 0, 0);
 #pragma unroll
-                            for (int tt = 0; tt < 2; ++tt) accx[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[tt], w0, accx[tt], 0, 0, 0);
+                            for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[tt], w0, acc[tt], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -342,9 +342,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const int y = tl.y0 + (wm * 2 + tt) * 2 + (pi >> 4), x = tl.x0 + (pi & 15);
                     if (y >= H || x >= W) continue;
                     const long long m = ((long long)tl.bimg * H + y) * W + x;
-                    float v = acc[tt][r];
-                    if (TERMS == 3) v += accx[tt][r] * (1.f / 2048.f);
-                    v += bias;
+                    float v = acc[tt][r] * ff::SPLIT_INV + bias;
                     v *= p.out_scale;
                     if (p.ch_scale) v = v * cs + ct;
                     v = ff::apply_act(v, p.act);

@@ -29,6 +29,14 @@ inline int check_launch(const char* what) {
 }
 
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s);  // conv_split.hip
+// Split operands (precision f16x3).  An fp32 value v travels as two halfs at ONE power-of-two scale s:
+//   h0 = f16(s v),  h1 = f16(s v - h0)            (activations: s = 2^2 applied by the loaders; packed rows: s = 2^4)
+// so x w ~ (x0 w0 + x0 w1 + x1 w0) / (sx sw) with all three products on the same scale: ONE fp32 accumulator per
+// tile (the earlier format scaled h1 by 2^11 and needed a second accumulator for the two cross terms).  h1 is
+// a denormal half when |s v| < 2^-3; v_mfma_f32_32x32x16_f16 keeps denormal inputs (tools/proto/mfma_denorm.hip), so
+// the representation error is max(2^-22 |v|, 2^-25 / s): fp32-like for every value that matters in a dot product.
+// Limits: |x| < 16376 (activations), |w| < 4094 (packed rows).
+constexpr float XSPLIT = 4.f, WSPLIT = 16.f, SPLIT_INV = 1.f / 64.f;
 // power-of-two input scale of the split formats (FFConvParams.x_amax): xs puts max|x| at 2^10, xinv undoes it
 __device__ __forceinline__ void input_scale(const unsigned int* x_amax, float& xs, float& xinv) {
     xs = 1.f; xinv = 1.f;

@@ -40,8 +40,8 @@ extern "C" {
 
 /* weight formats of FFConvParams.w */
 #define FF_W_F32 0     /* fp32 rows [Cout][K]: exact fp32 MFMA (v_mfma_f32_32x32x2_f32)            */
-#define FF_W_F16X3 1   /* rows from ff_pack_split_f16: x = x0 + 2^-11*x1 in fp16, 3 f16 MFMAs per  */
-                       /* product term set — fp32-level accuracy at 5.3x the matrix rate           */
+#define FF_W_F16X3 1   /* rows from ff_pack_split_f16: 16 w = w0 + w1 in fp16, 3 f16 MFMAs per       */
+                       /* product term set - fp32-level accuracy at 5.3x the matrix rate           */
 #define FF_W_F16 2     /* same rows, only the x0*w0 term: plain fp16 operands (reduced precision)  */
 
 const char* ff_last_error(void);
@@ -96,7 +96,9 @@ int ff_conv2d_fwd(const FFConvParams* p, void* stream);
 int ff_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW,
                         float* dst, int cin_pad, int cout_offset, void* stream);
 /* fp32 rows [rows][K] -> split rows [rows][ceil(K/32)]{x0: 32 fp16, x1: 32 fp16} (128 B per
- * 32-k chunk, zero padded) for FF_W_F16X3 / FF_W_F16.  Values must satisfy |x| < 65504. */
+ * 32-k chunk, zero padded) for FF_W_F16X3 / FF_W_F16: x0 = fp16(16 v), x1 = fp16(16 v - x0), both halves on the
+ * same scale (one accumulator serves all three product terms).  Values must satisfy |v| < 4094; the convolutions'
+ * activations (split the same way at scale 4 inside the kernels) |x| < 16376. */
 int ff_pack_split_f16(const float* src_rows, void* dst, long long rows, int K, void* stream);
 
 /* ------------------------------------------------------------------------
