@@ -10,10 +10,16 @@
 // consecutive rows (conflict-free) and a 32-row MFMA tile is 32 consecutive rows read with ds_read_b128.
 //
 // dY is far below fp16's range: it is scaled by the power of two that puts max|dY| (FFConvParams.x_amax, from
-// ff_act_bwd) at 2^10, undone in the epilogue.  Xcol holds activations (|x| < 65504 as in the forward).
+// ff_act_bwd) at 2^10, undone in the epilogue.  Both operands use the same-scale split of ff_common.h (both halves
+// on the operand's scale, x 4), so the three product terms share ONE accumulator per MFMA tile; Xcol holds
+// activations (|x| < 16376 as in the forward).
 // The bias gradient (column sums of dY) rides along in the blocks of the first k-tile.
-// Block tile 128 co x 64 k (64 x 128 when Cout <= 64), 32-pixel chunks double-buffered in LDS, pixel range split over blockIdx.y; the
-// 128 x 64 result goes through LDS so that every atomic wave-instruction adds 256 contiguous bytes of dW.
+// Block tile 128 co x 128 k (64 x 128 when Cout <= 64), 32-pixel chunks double-buffered in LDS, pixel range split over
+// blockIdx.y; the result goes through LDS so that every atomic wave-instruction adds 256 contiguous bytes of dW.
+// The kernel is bound by LDS stores (the transposing 8-byte runs move 85 B/clk per CU against 256 B/clk for reads) and
+// by im2col re-reads out of L2, both per tile ROW + COLUMN, while the MFMA work grows with rows x columns: with one
+// accumulator per tile the 128 x 128 tile costs the registers the 128 x 64 tile did with two, at a third less LDS
+// and L2 traffic per MFMA.
 #include <algorithm>
 #include <cstdlib>
 #include "ff_common.h"
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
     constexpr int A_BYTES = BN1 * PITCH, B_BYTES = BN2 * PITCH;
     constexpr int QA = Stage<BN1>::Q, PA = Stage<BN1>::PX, QB = Stage<BN2>::Q, PB = Stage<BN2>::PX;
     constexpr int TA = BN1 / 64, TB = BN2 / 64;               // 32-row MFMA tiles per wave (2 x 2 waves)
-    static_assert(TA * TB == 2, "tile must be 128x64 or 64x128");
+    static_assert(TA * TB == 2 || TA * TB == 4, "tile must be 128x128, 128x64 or 64x128");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A_BYTES + B_BYTES]; reused by the epilogue
     const FFConvParams& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -61,6 +67,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
     const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;     // dilation (FF-PWC refiner)
     float xs, xinv;
     ff::input_scale(p.x_amax, xs, xinv);
+    xs *= ff::XSPLIT; xinv *= 1.f / (ff::XSPLIT * ff::XSPLIT);      // both operands split at scale 4 (ff_common.h)
 
     // dY staging: channel quad ga, pixels PA*ra .. of the chunk
     const int ga = tid % QA, ra = tid / QA;
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
         for (int i = 0; i < 4; ++i) {
             const float sv = v[i] * scale;
             h0[i] = (_Float16)sv;
-            h1[i] = (_Float16)((sv - (float)h0[i]) * 2048.f);
+            h1[i] = (_Float16)(sv - (float)h0[i]);
         }
         if (npx == 4) {
             *reinterpret_cast<f16x4*>(row) = (f16x4){h0[0], h0[1], h0[2], h0[3]};
@@ -139,17 +146,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
             float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < PB; ++i) v[i] = rbv[i][j];
-            put(dB + (j * QB + gb) * PITCH + rb * PB * 2, v, PB, 1.f);
+            put(dB + (j * QB + gb) * PITCH + rb * PB * 2, v, PB, ff::XSPLIT);
         }
     };
 
-    f32x16 acc[TA][TB], accx[TA][TB];
+    f32x16 acc[TA][TB];
 #pragma unroll
     for (int i = 0; i < TA; ++i)
 #pragma unroll
         for (int j = 0; j < TB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int chunk0 = blockIdx.y * a.chunks_per_split;
     const int nchunks_total = (a.M + RK - 1) / RK;
@@ -183,8 +190,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
                 for (int j = 0; j < TB; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y0[i], x0[j], acc[i][j], 0, 0, 0);
                     if (TERMS == 3) {
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y0[i], x1[j], accx[i][j], 0, 0, 0);
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y1[i], x0[j], accx[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y0[i], x1[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y1[i], x0[j], acc[i][j], 0, 0, 0);
                     }
                 }
         }
@@ -207,9 +214,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WsArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int arow = (wm * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // row jj*QA + g holds co 4*g + jj
                 const int coreal = (arow % QA) * 4 + arow / QA;
-                float v = acc[i][j][r];
-                if (TERMS == 3) v += accx[i][j][r] * (1.f / 2048.f);
-                so[coreal * SP + kreal] = v * osc;
+                so[coreal * SP + kreal] = acc[i][j][r] * osc;
             }
         }
     float* sb = so + BN1 * SP;                                  // [256/QA][BN1] bias partials
@@ -245,6 +250,12 @@ int launch(WsArgs& a, int M, hipStream_t s) {
     splits = (nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     dim3 grid(a.n1_tiles * a.n2_tiles, splits, 1);
     const size_t lds = std::max<size_t>(2 * (BN1 + BN2) * PITCH, (BN1 * (BN2 + 1) + (256 / (BN1 / 4)) * BN1) * sizeof(float));
+    static bool attr_set = false;       // 128 x 128: 72 KB of staging
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<1, BN1, BN2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<3, BN1, BN2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     if (p.w_format == FF_W_F16) conv_wgrad_split_kernel<1, BN1, BN2><<<grid, 256, lds, s>>>(a);
     else conv_wgrad_split_kernel<3, BN1, BN2><<<grid, 256, lds, s>>>(a);
     return ff::check_launch("ff_conv2d_wgrad(split)");
@@ -263,7 +274,12 @@ int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int c
     a.Cin = cin;
     a.K = p.KH * p.KW * cin;
     // a 128-row tile of output channels would be half empty for Cout <= 64 (and 3/4 full for 96): go wide in k instead
+    static const int tile = getenv("FF_WGRAD_TILE") ? atoi(getenv("FF_WGRAD_TILE")) : 0;   // tuning: 1 = 128x64, 2 = 128x128 always
     if (p.Cout <= 64) return launch<64, 128>(a, M, s);
+    // 128 x 128 pays where the tile is full and the reduction long (tools/wgrad_table.py: 256 -> 192 3x3 181 -> 158 us,
+    // 128 -> 512 3x3 196 -> 181, 96 -> 96 3x3 159 -> 140); narrow or short problems lose blocks and run 15-50 % slower
+    const bool big = (p.Cout > 128 && a.K >= 1024) || (p.Cout == 96 && a.K >= 864);
+    if (tile == 2 || (tile == 0 && big)) return launch<128, 128>(a, M, s);
     return launch<128, 64>(a, M, s);
 }
 }  // namespace ff
