@@ -47,14 +47,15 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, int TERMS, int NST, bool UNI>
-__global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
+template <int WM, int WN, int TM, int TN, int TERMS, int NST, bool UNI, int NB>   // NB = LDS buffers per operand (2, or 1: see _occ)
+__device__ __forceinline__ void conv_split_body(const KernArgs& a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LA = BM / 32, LB = BN / 32;
     static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(NB == 2 || NST == 1, "the single-buffer variant has no register ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                        // [2][BM][128 B]
-    char* sB = smem + 2 * BM * ROWB;        // [2][BN][128 B]
+    char* sA = smem;                        // [NB][BM][128 B]
+    char* sB = smem + NB * BM * ROWB;       // [NB][BN][128 B]
 
     const FFConvParams& p = a.p;
     float xs, xinv;
@@ -257,9 +258,14 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
             if (kc < nk) {
                 if (kc + NST < nk) { if (UNI) stage_load_uni(kc + NST, ra[st], rb[st]); else stage_load(kc + NST, ra[st], rb[st]); }
                 compute(cur);
-                if (kc + 1 < nk) stage_store(cur ^ 1, ra[(st + 1) % NST], rb[(st + 1) % NST]);
-                __syncthreads();
-                cur ^= 1;
+                if (NB == 1) {              // one buffer: everybody must be done reading before it is overwritten
+                    if (kc + 1 < nk) { __syncthreads(); stage_store(0, ra[0], rb[0]); }
+                    __syncthreads();
+                } else {
+                    if (kc + 1 < nk) stage_store(cur ^ 1, ra[(st + 1) % NST], rb[(st + 1) % NST]);
+                    __syncthreads();
+                    cur ^= 1;
+                }
             }
         }
     }
@@ -306,6 +312,15 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) {
 }
 
 template <int WM, int WN, int TM, int TN, int TERMS, int NST, bool UNI>
+__global__ __launch_bounds__(256) void conv_split_kernel(const KernArgs a) { conv_split_body<WM, WN, TM, TN, TERMS, NST, UNI, 2>(a); }
+// One LDS buffer per operand (a second barrier per chunk) and registers capped for OCC waves per SIMD: the 128 x 64
+// tile then needs 24 KB instead of 48 and four blocks share a CU (the lever of conv_patch.hip).
+template <int WM, int WN, int TM, int TN, int TERMS, bool UNI, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_split_kernel_occ(const KernArgs a) {
+    conv_split_body<WM, WN, TM, TN, TERMS, 1, UNI, 1>(a);
+}
+
+template <int WM, int WN, int TM, int TN, int TERMS, int NST, bool UNI>
 int launch_u(const KernArgs& a, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t lds = 2 * (BM + BN) * ROWB;
@@ -319,6 +334,13 @@ int launch_u(const KernArgs& a, hipStream_t s) {
     k.m_tiles = (a.M + BM - 1) / BM;
     k.n_tiles = (a.p.Cout + BN - 1) / BN;
     dim3 grid(k.m_tiles * k.n_tiles, a.p.groups);
+    static const int occ = getenv("FF_SPLIT_OCC") ? atoi(getenv("FF_SPLIT_OCC")) : 1;
+    if constexpr (NST == 1 && TERMS == 3 && WM == 2 && TM == 2 && TN == 1) {
+        if (occ) {
+            conv_split_kernel_occ<WM, WN, TM, TN, TERMS, UNI, 4><<<grid, 256, lds / 2, s>>>(k);
+            return ff::check_launch("ff_conv2d_fwd(split)");
+        }
+    }
     conv_split_kernel<WM, WN, TM, TN, TERMS, NST, UNI><<<grid, 256, lds, s>>>(k);
     return ff::check_launch("ff_conv2d_fwd(split)");
 }
