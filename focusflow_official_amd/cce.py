@@ -6,7 +6,7 @@ but the modules below only HOLD parameters: ``nn.Conv2d`` / ``nn.BatchNorm2d``
 instances are never called.  The forward is a sequence of libfocusflow_hip
 launches on NHWC fp32 tensors.
 """
-from typing import Optional, Sequence
+from typing import Tuple, Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -24,14 +24,20 @@ class PackedConv:
     whenever a source parameter changes (version counter) or moves.
     """
 
-    def __init__(self, convs: Sequence[nn.Conv2d], cin_pad: Optional[int] = None):
+    def __init__(self, convs: Sequence[nn.Conv2d], cin_pad: Optional[int] = None,
+                 cin_slices: Optional[Sequence[Tuple[int, int]]] = None, use_bias: bool = True):
+        """cin_slices: take only these input-channel ranges of the weights, in this order (a convolution is linear
+        in its input channels: the GRU splits off the part that meets the loop-invariant context features);
+        use_bias=False leaves the bias to the other part.  Sliced groups are forward-only."""
         self.convs = list(convs)
         c0 = self.convs[0]
         self.kh, self.kw = c0.kernel_size
         self.stride = c0.stride[0]
         self.pad = tuple(c0.padding)
         self.dil = c0.dilation[0]
-        self.cin = c0.in_channels
+        self.cin_slices = list(cin_slices) if cin_slices is not None else None
+        self.use_bias = use_bias
+        self.cin = c0.in_channels if cin_slices is None else sum(hi - lo for lo, hi in cin_slices)
         self.cin_pad = cin_pad if cin_pad is not None else (self.cin + 3) // 4 * 4
         self.cout = sum(c.out_channels for c in self.convs)
         for c in self.convs:
@@ -52,8 +58,11 @@ class PackedConv:
             self.b = torch.zeros(self.cout, dtype=torch.float32, device=dev)   # bias=False convs (SA) keep zeros
             off = 0
             for c in self.convs:
-                ops.pack_conv_weight(c.weight.detach(), self.w, self.cin_pad, off)
-                if c.bias is not None:
+                wt = c.weight.detach()
+                if self.cin_slices is not None:
+                    wt = torch.cat([wt[:, lo:hi] for lo, hi in self.cin_slices], 1).contiguous()
+                ops.pack_conv_weight(wt, self.w, self.cin_pad, off)
+                if c.bias is not None and self.use_bias:
                     self.b[off:off + c.out_channels].copy_(c.bias.detach())  # device memcpy
                 off += c.out_channels
             # 1- and 2-channel 3x3 heads stay in fp32 rows: ff_conv2d_fwd runs them as dot products on the vector ALU
@@ -69,6 +78,7 @@ class PackedConv:
         """Weights of the input-gradient convolution: [cin_pad][KH][KW][cout_pad], flipped + transposed, in the
         active conv format (fp32 rows, or fp16-split rows: the dgrad then runs on the f16 matrix pipe with the
         gradient scaled by a power of two, see FFConvParams.x_amax).  Returns (rows, format)."""
+        assert self.cin_slices is None, "channel-sliced conv groups are forward-only"
         key = (ops.conv_precision(),) + tuple((c.weight._version, c.weight.data_ptr()) for c in self.convs)
         if key != self._dkey:
             cout_pad = (self.cout + 3) // 4 * 4

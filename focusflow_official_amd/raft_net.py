@@ -1,4 +1,6 @@
 """RAFT graph on the HIP path (raft.py:40-236, the 'parallel' inside-fusion build)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -7,6 +9,8 @@ from .cce import BasicParallelFusionLayer
 from .corr_block import CorrBlock
 from .ops import ACT_RELU, ACT_TANH
 from .update_block import BasicUpdateBlock
+
+_GRU_CTX_ONCE = os.environ.get("FF_GRU_CTX_ONCE", "1") != "0"      # measurement switch (see SepConvGRU.prepare)
 
 
 class RAFT(nn.Module):
@@ -95,6 +99,8 @@ class RAFT(nn.Module):
         # (raft.py:226-236).  Default: do the same work.  skip_unused_upsample (opt-in, inference only) computes
         # the mask head + convex up-sampling for the last iteration only; flow_low / flow_up are bit-identical.
         lazy = bool(getattr(self, "skip_unused_upsample", False)) and test_mode and not taped
+        # the context features' share of the GRU gate convolutions does not change over the iterations
+        gru_pre = None if (taped or torch.is_grad_enabled() or not _GRU_CTX_ONCE) else self.update_block.gru.prepare(inp)
         for it in range(iters):
             # coords1 is advanced in place by ff_coords_step (raw pointer: autograd cannot see it), so a
             # recorded lookup keeps its own snapshot for the backward scatter
@@ -103,7 +109,7 @@ class RAFT(nn.Module):
             ops.coords_step(coords1, None, flow4, None)                   # flow = coords1 - coords0
             fill = lambda motion, c=coords1: ops.coords_step(c, None, None, motion[..., 126:])  # noqa: E731
             need_mask = not lazy or it == iters - 1
-            net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask)
+            net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre)
             flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
             ops.coords_step(coords1, delta.detach(), flow4, None)         # coords1 += delta
             if not need_mask:

@@ -35,10 +35,31 @@ class SepConvGRU(nn.Module):
         self._zr = [PackedConv([self.convz1, self.convr1]), PackedConv([self.convz2, self.convr2])]
         self._q = [PackedConv([self.convq1]), PackedConv([self.convq2])]
         self.hidden_dim = hidden_dim
+        # x = cat[inp, motion] (update.py:132) and `inp` - the context features - is the same in every iteration, so
+        # its share of the six gate convolutions is computed once per forward (prepare) and enters the per-iteration
+        # convolutions over [h, motion] as a pre-activation addend: a third of the GRU's matrix work leaves the loop.
+        hm, ctx = [(0, hidden_dim), (hidden_dim + 128, c)], [(hidden_dim, hidden_dim + 128)]
+        self._zr_hm = [PackedConv(g.convs, cin_slices=hm) for g in self._zr]
+        self._q_hm = [PackedConv(g.convs, cin_slices=hm) for g in self._q]
+        self._zr_ctx = [PackedConv(g.convs, cin_slices=ctx, use_bias=False) for g in self._zr]
+        self._q_ctx = [PackedConv(g.convs, cin_slices=ctx, use_bias=False) for g in self._q]
 
-    def run(self, h, xs):
-        """h: (B,H,W,128); xs: list of NHWC segments forming x.  update.py:45-60."""
+    def prepare(self, inp):
+        """Inference: the context features' contribution to z|r and q of both passes, [(zr_pre, q_pre)] x 2."""
+        assert inp.shape[3] == 128
+        return [(zc(inp), qc(inp)) for zc, qc in zip(self._zr_ctx, self._q_ctx)]
+
+    def run(self, h, xs, pre=None):
+        """h: (B,H,W,128); xs: list of NHWC segments forming x.  update.py:45-60.  pre: prepare(xs[0]) - then
+        xs[0] itself is not read again."""
         c = self.hidden_dim
+        if pre is not None:
+            for zr_conv, q_conv, (zr_pre, q_pre) in zip(self._zr_hm, self._q_hm, pre):
+                zr = zr_conv([h] + xs[1:], res=zr_pre, act_res=ACT_SIGMOID)     # sigmoid(conv([h, motion]) + b + pre)
+                rh = ops.gru_rh(zr[..., c:], h)
+                q = q_conv([rh] + xs[1:], res=q_pre, act_res=ACT_TANH)
+                h = ops.gru_blend(zr[..., :c], q, h)
+            return h
         for zr_conv, q_conv in zip(self._zr, self._q):
             zr = fn.conv(zr_conv, [h] + xs, act=ACT_SIGMOID)    # z = zr[..., :c], r = zr[..., c:]
             taped = fn.recording(zr, h)
@@ -84,11 +105,11 @@ class BasicUpdateBlock(nn.Module):
         self._flow2 = PackedConv([self.flow_head.conv2])
         self._mask2 = PackedConv([self.mask[2]])
 
-    def run(self, net, inp, corr, flow4, fill_flow, need_mask=True):
+    def run(self, net, inp, corr, flow4, fill_flow, need_mask=True, gru_pre=None):
         """-> (net, up_mask, delta_flow), all NHWC.  update.py:126-135.  need_mask=False (inference only, opt-in)
         leaves out the up-sampling mask head when the caller is going to discard it."""
         motion = self.encoder.run(flow4, corr, fill_flow)
-        net = self.gru.run(net, [inp, motion])
+        net = self.gru.run(net, [inp, motion], gru_pre)
         if not need_mask:
             return net, None, fn.conv(self._flow2, fn.conv(self._head1, net, act=ACT_RELU))
         hid = fn.conv(self._heads, net, act=ACT_RELU)                      # [flow-head 256 | mask-head 256]

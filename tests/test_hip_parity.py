@@ -400,6 +400,23 @@ def test_skip_unused_upsample_is_bit_identical(det_sd):
     assert torch.equal(fl0, fl1) and torch.equal(fu0, fu1)
 
 
+def test_gru_context_share_computed_once_matches_per_iteration_convs(det_sd, monkeypatch):
+    """Inference computes the context features' share of the six GRU gate convolutions once per forward
+    (SepConvGRU.prepare: x = cat[inp, motion] and inp never changes, update.py:132) and adds it in the epilogue of
+    the per-iteration convolutions over [h, motion].  Same arithmetic up to the summation order: the flows must agree
+    with the full 384-channel convolutions to fp32 rounding."""
+    from focusflow_official_amd import raft_net
+    m = _model(det_sd)
+    inp = [t.to(DEV) for t in orc.shifted_pair(2, 128, 192, seed=4)]
+    with torch.no_grad():
+        monkeypatch.setattr(raft_net, "_GRU_CTX_ONCE", False)
+        fl0, fu0 = m(*inp, raft_iters=6, test_mode=True)
+        monkeypatch.setattr(raft_net, "_GRU_CTX_ONCE", True)
+        fl1, fu1 = m(*inp, raft_iters=6, test_mode=True)
+    close(fl1.cpu(), fl0.cpu(), rtol=0, atol=2e-5, what="flow_low")
+    close(fu1.cpu(), fu0.cpu(), rtol=0, atol=1e-4, what="flow_up")
+
+
 def test_config5_shape_540x960_padded(det_sd):
     """BASELINE config 5's frame size: 540x960 replicate-padded to 544x960 (68x120 at 1/8: level 3 is 8x15, odd
     widths at two pyramid levels), against the CPU oracle.  Few iterations on purpose: with synthetic weights the
