@@ -341,6 +341,12 @@ int launch_u(const KernArgs& a, hipStream_t s) {
             return ff::check_launch("ff_conv2d_fwd(split)");
         }
     }
+    if constexpr (NST == 1 && TERMS == 3 && WM == 4 && TN == 3) {      // 128 x 96 (Cout = 96 layers): 56 KB -> 28 KB, 2 -> 3 blocks
+        if (occ) {
+            conv_split_kernel_occ<WM, WN, TM, TN, TERMS, UNI, 3><<<grid, 256, lds / 2, s>>>(k);
+            return ff::check_launch("ff_conv2d_fwd(split)");
+        }
+    }
     conv_split_kernel<WM, WN, TM, TN, TERMS, NST, UNI><<<grid, 256, lds, s>>>(k);
     return ff::check_launch("ff_conv2d_fwd(split)");
 }
