@@ -1,6 +1,6 @@
 """One-off check of BASELINE config 5 (B=1, 540x960 padded to 544x960, iters=32): HIP path vs the CPU oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from argparse import Namespace
 import torch
 from focusflow_official_amd import FF_RAFT_FUSION

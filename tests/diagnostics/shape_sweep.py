@@ -1,6 +1,6 @@
 """One-off robustness sweep: HIP forward vs the CPU oracle over odd frame sizes, batch sizes and fusion types."""
 import os, sys, itertools, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from argparse import Namespace
 import torch
 from focusflow_official_amd import FF_RAFT_FUSION

@@ -1,6 +1,6 @@
 """Second robustness sweep: mask modes at odd sizes, batch extremes, iteration counts, flow_init, non-contiguous inputs."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from argparse import Namespace
 import torch
 from focusflow_official_amd import FF_RAFT_FUSION

@@ -294,7 +294,7 @@ def test_frozen_bn_training_step_gives_gradients(det_sd):
                  "flow_net.update_block.gru.convq1.weight", "flow_net.fnet.fusion3.img2mask.conv.weight"]:
         ref_g = sd[name].grad
         # 1e-2: at this size the step sits next to a discrete event (a ReLU / window-corner flip between the CPU and the
-        # GPU forward): the exact-fp32 conv mode differs from the CPU oracle by the same 0.5 % (tools/debug/frozen_bn_grads.py)
+        # GPU forward): the exact-fp32 conv mode differs from the CPU oracle by the same 0.5 % (tests/diagnostics/frozen_bn_grads.py)
         close(params[name].grad.cpu(), ref_g, rtol=1e-2, atol_rel=1e-2, what=name)
 
 

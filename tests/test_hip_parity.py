@@ -421,7 +421,7 @@ def test_config5_shape_540x960_padded(det_sd):
     """BASELINE config 5's frame size: 540x960 replicate-padded to 544x960 (68x120 at 1/8: level 3 is 8x15, odd
     widths at two pyramid levels), against the CPU oracle.  Few iterations on purpose: with synthetic weights the
     recurrence is not contractive at this size — the reference's own arithmetic run in fp32 and in fp64 differs by
-    3e-3 px after 12 iterations and 0.45 px after 32 (tools/check_c5.py) — so parity is asserted where
+    3e-3 px after 12 iterations and 0.45 px after 32 (tests/diagnostics/check_c5.py) — so parity is asserted where
     rounding noise has not been amplified yet."""
     from focusflow_official_amd.utils import InputPadder
     inp = orc.shifted_pair(1, 540, 960, seed=3)
