@@ -347,20 +347,23 @@ __global__ void gru_blend_bwd_kernel(const float* __restrict__ dhn, int dhn_ld, 
     }
 }
 
-// Convex upsampling backward.  One block per coarse row (b,h); dflow contributions
-// for rows h-1..h+1 are reduced in LDS, then added to dflow with atomics.
+// Convex upsampling backward.  One block per coarse row (b,h) and half of its pixels; a wave is one coarse pixel (its
+// 64 lanes = the 8x8 sub-pixels), so the flow gradient of each of the 9 taps is first summed over the wave and then
+// added to the row's LDS accumulator by ONE lane (it was 64 same-address LDS atomics per tap and component: the
+// kernel ran at 0.25 TB/s); rows h-1..h+1 go to dflow with global atomics at the end.
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ flow,
                                                            int flow_ld, const float* __restrict__ mask, int mask_ld,
                                                            float* __restrict__ dflow, float* __restrict__ dmask, int H,
                                                            int W) {
     extern __shared__ float acc[];   // [3][W][2]
     const int b = blockIdx.y, h = blockIdx.x;
+    const int wbeg = (int)((long long)W * blockIdx.z / gridDim.z), wend = (int)((long long)W * (blockIdx.z + 1) / gridDim.z);
     for (int i = threadIdx.x; i < 3 * W * 2; i += 256) acc[i] = 0.f;
     __syncthreads();
     const long long rowpix = ((long long)b * H + h) * W;
     const int HW8 = 64 * H * W;
-    for (int t = threadIdx.x; t < W * 64; t += 256) {
-        const int w = t >> 6, ij = t & 63, i = ij >> 3, j = ij & 7;
+    const int ij = threadIdx.x & 63, i = ij >> 3, j = ij & 7;
+    for (int w = wbeg + (threadIdx.x >> 6); w < wend; w += 4) {
         const float* m = mask + (rowpix + w) * mask_ld + ij;
         float pk[9], mx = -INFINITY;
 #pragma unroll
@@ -382,13 +385,21 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
             pk[k] /= den;
             const int yy = h + k / 3 - 1, xx = w + k % 3 - 1;
             float fx = 0.f, fy = 0.f;
-            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;      // wave-uniform
             if (in) {
                 const float* f = flow + (((long long)b * H + yy) * W + xx) * flow_ld;
                 fx = 8.f * f[0];
                 fy = 8.f * f[1];
-                atomicAdd(&acc[((k / 3) * W + xx) * 2], 8.f * pk[k] * gx);
-                atomicAdd(&acc[((k / 3) * W + xx) * 2 + 1], 8.f * pk[k] * gy);
+                float ax = 8.f * pk[k] * gx, ay = 8.f * pk[k] * gy;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    ax += __shfl_xor(ax, d);
+                    ay += __shfl_xor(ay, d);
+                }
+                if (ij == 0) {
+                    atomicAdd(&acc[((k / 3) * W + xx) * 2], ax);
+                    atomicAdd(&acc[((k / 3) * W + xx) * 2 + 1], ay);
+                }
             }
             s[k] = gx * fx + gy * fy;
             dot += pk[k] * s[k];
@@ -398,11 +409,11 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
         for (int k = 0; k < 9; ++k) dm[k * 64] = pk[k] * (s[k] - dot);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 3 * W * 2; i += 256) {
-        const int rr = i / (W * 2), rem = i - rr * W * 2;
+    for (int i2 = threadIdx.x; i2 < 3 * W * 2; i2 += 256) {
+        const int rr = i2 / (W * 2), rem = i2 - rr * W * 2;
         const int yy = h + rr - 1;
-        if ((unsigned)yy < (unsigned)H && acc[i] != 0.f)
-            atomicAdd(dflow + (((long long)b * H + yy) * W) * 2 + rem, acc[i]);
+        if ((unsigned)yy < (unsigned)H && acc[i2] != 0.f)
+            atomicAdd(dflow + (((long long)b * H + yy) * W) * 2 + rem, acc[i2]);
     }
 }
 
@@ -500,6 +511,6 @@ extern "C" int ff_upsample_flow_bwd(const float* dout_nchw, const float* flow, i
     FF_REQUIRE(dout_nchw && flow && mask && dflow && dmask && B > 0 && H > 0 && W > 0 && flow_ld >= 2 && mask_ld >= 576,
                "ff_upsample_flow_bwd: bad argument");
     const size_t lds = (size_t)3 * W * 2 * sizeof(float);
-    upsample_bwd_kernel<<<dim3(H, B), 256, lds, static_cast<hipStream_t>(stream)>>>(dout_nchw, flow, flow_ld, mask, mask_ld, dflow, dmask, H, W);
+    upsample_bwd_kernel<<<dim3(H, B, W >= 16 ? 2 : 1), 256, lds, static_cast<hipStream_t>(stream)>>>(dout_nchw, flow, flow_ld, mask, mask_ld, dflow, dmask, H, W);
     return ff::check_launch("ff_upsample_flow_bwd");
 }
