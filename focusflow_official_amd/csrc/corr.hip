@@ -290,7 +290,10 @@ extern "C" int ff_corr_lookup_fwd(const float* const* levels, int num_levels, in
     a.num_levels = num_levels;
     static const int variant = getenv("FF_LOOKUP_GENERIC") ? 0 : 1;   // A/B switch for profiling only
     if (variant == 1 && num_levels == 4 && radius == 4) {
-        long long blocks = queries < 256 * 32 ? queries : 256 * 32;
+        // one wave per block; 78 VGPRs = 6 waves per SIMD = 24 per CU resident: a grid of 256 x 24 runs as ONE round of
+        // waves (4 queries each at B = 8), 256 x 32 as one round plus a third of a second one
+        static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 24;
+        long long blocks = queries < 256ll * wpc ? queries : 256ll * wpc;
         lookup_wave_kernel<<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
         return ff::check_launch("ff_corr_lookup_fwd");
     }
