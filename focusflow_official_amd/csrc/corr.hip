@@ -129,6 +129,11 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
 constexpr int WROWS = 11, WCOLS = 16, NWIN = WROWS * WCOLS;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ALLVEC: every level's width is a multiple of 4 (W/8 a multiple of 32): only the 16-byte staging path is compiled.
+// No load sits under a branch: out-of-range lanes read a valid dummy address and the zero padding is applied by a
+// select when the window goes to LDS.  (With the loads inside `if (in range)` the compiler serialised the four
+// levels' loads with s_waitcnt vmcnt(0) between them: four DRAM round trips per query instead of one.)
+template <bool ALLVEC>
 __global__ __launch_bounds__(64) void lookup_wave_kernel(const LookupArgs a) {
     __shared__ __attribute__((aligned(16))) float win[4 * NWIN];
     __shared__ int tab_i[2][4][2][9];
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(64) void lookup_wave_kernel(const LookupArgs a) {
     const int t_lv = min(lane / 9, 3), t_o = lane - (lane / 9) * 9;   // tap role
     const float t_inv = 1.f / (float)(1 << t_lv);
     const int t_h = h0 >> t_lv, t_w = w0 >> t_lv;
-    const bool t_vec = (t_w & 3) == 0;
+    const bool t_vec = ALLVEC || (t_w & 3) == 0;
     const int s_r = lane >> 2, s_g = lane & 3;                        // vector staging role (lane < 44)
     const int d_r0 = lane / 11, d_c0 = lane - d_r0 * 11;              // dword staging role
     const int d_r1 = (lane + 64) / 11, d_c1 = (lane + 64) - d_r1 * 11;
@@ -171,34 +176,40 @@ __global__ __launch_bounds__(64) void lookup_wave_kernel(const LookupArgs a) {
 
     f32x4 rv[4];        // vector path: one float4 per level (lanes < 44)
     float rd[4][2];     // dword path: two floats per level
+    unsigned okm = 0;   // bit lv (vector) / bits 4+2lv, 5+2lv (dword): the load was inside the plane
     auto issue_loads = [&](long long q, int buf) {
+        okm = 0;
 #pragma unroll
         for (int lv = 0; lv < 4; ++lv) {   // compile-time level: plane pointer and sizes stay scalar
             const int hl = h0 >> lv, wl = w0 >> lv;
             const float* pl = a.lvl[lv] + q * (long long)(hl * wl);
             const int gx0 = org[buf][lv][0], gy0 = org[buf][lv][1];
-            if ((wl & 3) == 0) {
+            if (ALLVEC || (wl & 3) == 0) {
                 const int gy = gy0 + s_r, gx = gx0 + 4 * s_g;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (lane < 44 && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl)
-                    v = *reinterpret_cast<const f32x4*>(pl + gy * wl + gx);
-                rv[lv] = v;
+                const bool ok = lane < 44 && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl;
+                rv[lv] = *reinterpret_cast<const f32x4*>(pl + (ok ? gy * wl + gx : 0));
+                okm |= ok ? 1u << lv : 0u;
             } else {
                 int gy = gy0 + d_r0, gx = gx0 + d_c0;
-                rd[lv][0] = ((unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl) ? pl[gy * wl + gx] : 0.f;
+                bool ok = (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl;
+                rd[lv][0] = pl[ok ? gy * wl + gx : 0];
+                okm |= ok ? 1u << (4 + 2 * lv) : 0u;
                 gy = gy0 + d_r1, gx = gx0 + d_c1;
-                rd[lv][1] = (lane < 121 - 64 && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl) ? pl[gy * wl + gx] : 0.f;
+                ok = lane < 121 - 64 && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl;
+                rd[lv][1] = pl[ok ? gy * wl + gx : 0];
+                okm |= ok ? 1u << (5 + 2 * lv) : 0u;
             }
         }
     };
     auto store_window = [&]() {
 #pragma unroll
         for (int lv = 0; lv < 4; ++lv) {
-            if (((w0 >> lv) & 3) == 0) {
-                if (lane < 44) *reinterpret_cast<f32x4*>(&win[lv * NWIN + s_r * WCOLS + 4 * s_g]) = rv[lv];
+            if (ALLVEC || ((w0 >> lv) & 3) == 0) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                if (lane < 44) *reinterpret_cast<f32x4*>(&win[lv * NWIN + s_r * WCOLS + 4 * s_g]) = (okm >> lv & 1u) ? rv[lv] : z;
             } else {
-                win[lv * NWIN + d_r0 * WCOLS + d_c0] = rd[lv][0];
-                if (lane < 121 - 64) win[lv * NWIN + d_r1 * WCOLS + d_c1] = rd[lv][1];
+                win[lv * NWIN + d_r0 * WCOLS + d_c0] = (okm >> (4 + 2 * lv) & 1u) ? rd[lv][0] : 0.f;
+                if (lane < 121 - 64) win[lv * NWIN + d_r1 * WCOLS + d_c1] = (okm >> (5 + 2 * lv) & 1u) ? rd[lv][1] : 0.f;
             }
         }
     };
@@ -212,15 +223,12 @@ __global__ __launch_bounds__(64) void lookup_wave_kernel(const LookupArgs a) {
     for (;;) {
         const long long qn = q + gridDim.x;
         const bool has_next = qn < a.queries;
-        float cxn = 0.f, cyn = 0.f;
-        if (has_next) {
-            cxn = a.coords[qn * 2];
-            cyn = a.coords[qn * 2 + 1];
-        }
+        const long long qs = has_next ? qn : q;          // the last round re-stages its own query: nothing under a branch
+        const float cxn = a.coords[qs * 2], cyn = a.coords[qs * 2 + 1];
         store_window();                                  // waits for this query's window loads
-        if (has_next) publish_taps(qn, cxn, cyn, cur ^ 1);
+        publish_taps(qs, cxn, cyn, cur ^ 1);
         __syncthreads();                                 // win + both table sets visible
-        if (has_next) issue_loads(qn, cur ^ 1);          // in flight during the blend below
+        issue_loads(qs, cur ^ 1);                        // in flight during the blend below
         float* orow = a.out + q * a.out_ld;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -294,7 +302,9 @@ extern "C" int ff_corr_lookup_fwd(const float* const* levels, int num_levels, in
         // waves (4 queries each at B = 8), 256 x 32 as one round plus a third of a second one
         static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 24;
         long long blocks = queries < 256ll * wpc ? queries : 256ll * wpc;
-        lookup_wave_kernel<<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
+        const bool allvec = ((a.w[0] | a.w[1] | a.w[2] | a.w[3]) & 3) == 0;
+        if (allvec) lookup_wave_kernel<true><<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
+        else lookup_wave_kernel<false><<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
         return ff::check_launch("ff_corr_lookup_fwd");
     }
     const long long total = queries * nk;
