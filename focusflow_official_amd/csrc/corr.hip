@@ -187,7 +187,9 @@ __global__ __launch_bounds__(64) void lookup_wave_kernel(const LookupArgs a) {
             if (ALLVEC || (wl & 3) == 0) {
                 const int gy = gy0 + s_r, gx = gx0 + 4 * s_g;
                 const bool ok = lane < 44 && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl;
-                rv[lv] = *reinterpret_cast<const f32x4*>(pl + (ok ? gy * wl + gx : 0));
+                // lanes without a load of their own re-read a line of the window (clamped row / column): no extra traffic
+                const int gyc = min(max(gy0 + min(s_r, WROWS - 1), 0), hl - 1), gxc = min(max(gx, 0), wl - 4);
+                rv[lv] = *reinterpret_cast<const f32x4*>(pl + gyc * wl + gxc);
                 okm |= ok ? 1u << lv : 0u;
             } else {
                 int gy = gy0 + d_r0, gx = gx0 + d_c0;
