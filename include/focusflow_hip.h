@@ -194,7 +194,9 @@ int ff_unpack_conv_wgrad(const float* packed, int Cout, int Cin, int KH, int KW,
  * dst[ci][KH-1-kh][KW-1-kw][cout_offset+co] = w[co][ci][kh][kw]  (CALLER ZEROES dst) */
 int ff_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int KH, int KW, float* dst,
                               int cout_pad, int cout_offset, void* stream);
-/* g = dy * act'(y) * scale (activation derivative from the forward OUTPUT), zero-padded to Cpad */
+/* g = dy * act'(y) * scale (activation derivative from the forward OUTPUT), zero-padded to Cpad; amax (nullable,
+ * CALLER ZEROES): bits of max|g|.  g == dy is allowed (then nothing is stored: the call only measures max|dy|, for
+ * activation-free convolutions whose gradient needs no copy) */
 int ff_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* g, int g_ld,
                long long npix, int C, int Cpad, int act, float scale, unsigned int* amax, void* stream);
 /* zero-dilation by 2: dst[b][2y][2x][:] = src[b][y][x][:] (input gradient of stride-2 convs) */
