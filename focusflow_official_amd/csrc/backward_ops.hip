@@ -299,17 +299,34 @@ __global__ __launch_bounds__(64) void lookup_bwd_kernel(const LookupBwdArgs a) {
             }
         }
         __syncthreads();
+        // read-modify-write of the query's own planes: all twelve loads first (unconditional, lanes with nothing to
+        // add read element 0), then the stores - inside `if (...) pl[i] += v` every element was a dependent round trip
+        constexpr int NE = (BW_N + 63) / 64;
+        float cur[4][NE], add[4][NE];
+        int idx[4][NE];
 #pragma unroll
         for (int lv = 0; lv < 4; ++lv) {
             const int hl = a.h0 >> lv, wl = a.w0 >> lv;
-            float* pl = a.dlvl[lv] + q * (long long)(hl * wl);
+            const float* pl = a.dlvl[lv] + q * (long long)(hl * wl);
             const int gx0 = org[lv][0], gy0 = org[lv][1];
-            for (int e = lane; e < BW_N; e += 64) {
+#pragma unroll
+            for (int t = 0; t < NE; ++t) {
+                const int e = min(lane + 64 * t, BW_N - 1);
                 const int r = e / BW_COLS, c = e - r * BW_COLS;
                 const int gy = gy0 + r, gx = gx0 + c;
                 const float v = win[lv * BW_N + e];
-                if (v != 0.f && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl) pl[gy * wl + gx] += v;
+                const bool ok = lane + 64 * t < BW_N && v != 0.f && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl;
+                idx[lv][t] = ok ? gy * wl + gx : -1;
+                add[lv][t] = v;
+                cur[lv][t] = pl[ok ? gy * wl + gx : 0];
             }
+        }
+#pragma unroll
+        for (int lv = 0; lv < 4; ++lv) {
+            float* pl = a.dlvl[lv] + q * (long long)((a.h0 >> lv) * (a.w0 >> lv));
+#pragma unroll
+            for (int t = 0; t < NE; ++t)
+                if (idx[lv][t] >= 0) pl[idx[lv][t]] = cur[lv][t] + add[lv][t];
         }
         __syncthreads();
     }

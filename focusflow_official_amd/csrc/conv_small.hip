@@ -44,10 +44,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SArgs a) {
         const int cpos = cbase + lane * 4;
         const bool cok = cpos < a.Cin;
         // which segment holds cpos (segments are multiples of 4 channels, so a float4 never straddles two)
-        const float* xp = nullptr;
-        int ld = 0, cs = cpos;
+        const float* xp = p.x[0];            // lanes past the last channel load a valid dummy (segment 0, channel 0)
+        int ld = p.x_ld[0], cs = 0;
         if (cok) {
             const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
+            cs = cpos;
             if (cs < c0) { xp = p.x[0]; ld = p.x_ld[0]; }
             else if (cs < c01) { xp = p.x[1]; ld = p.x_ld[1]; cs -= c0; }
             else { xp = p.x[2]; ld = p.x_ld[2]; cs -= c01; }
@@ -58,11 +59,13 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SArgs a) {
 #pragma unroll
             for (int t = 0; t < 9; ++t)
                 w[c][t] = cok ? *reinterpret_cast<const f32x4*>(p.w + (long long)c * K + t * a.Cin + cpos) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        // no load under a branch (the compiler would wait for each before issuing the next): out-of-image taps read a
+        // clamped pixel and are zeroed by a select
         auto load = [&](int yy, int xx) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                v = *reinterpret_cast<const f32x4*>(xp + ((long long)(b * H + yy) * W + xx) * ld + cs);
-            return v;
+            const bool ok = cok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + ((long long)(b * H + yc) * W + xc) * ld + cs);
+            return ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
         };
         f32x4 col[3][3];                     // col[slot][dy]: window columns x-1, x, x+1 rotate through 3 slots
 #pragma unroll

@@ -146,13 +146,12 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         float ox = 0.f, oy = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
+            // no load under a branch (nine dependent L2 round trips otherwise): clamp, load, select
             const int yy = h + k / 3 - 1, xx = w + k % 3 - 1;
-            float fx = 0.f, fy = 0.f;
-            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                const float* f = flow + (((long long)b * H + yy) * W + xx) * flow_ld;
-                fx = 8.f * f[0];
-                fy = 8.f * f[1];
-            }
+            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const float* f = flow + (((long long)b * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)) * flow_ld;
+            const float f0 = f[0], f1 = f[1];
+            const float fx = in ? 8.f * f0 : 0.f, fy = in ? 8.f * f1 : 0.f;
             const float wgt = mv[k] / den;
             ox += wgt * fx;
             oy += wgt * fy;
