@@ -49,7 +49,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {   
 
 // NITEM = patch items per thread; TM x TN = 32-pixel x 32-channel MFMA tiles per wave (block: 2 x 2 waves =
 // 64 TM pixels x 64 TN channels); ABL = timing-only ablation
-template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB>   // WB = weight buffers in LDS
+template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false>   // WB = weight buffers in LDS
 __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
     constexpr int TH = 4 * TM, BN = 64 * TN, NW = 2 * TN;       // NW = 16-byte weight pieces per thread and tap
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,6 +180,10 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
             const bool last = tap + 1 == ntaps;
             const int next_kc = last ? (c + 1) : (tap + 1) * a.nci + c;   // K order = (tap, ci): chunk index tap*nci + c
             if (!(last && c + 1 == a.nci) && ABL != 1 && ABL != 2) load_w(last ? c + 1 : next_kc);
+            // Keep the next tap's weight loads HERE: left alone, the scheduler sinks them below this tap's MFMAs
+            // (8 fewer live registers) to two MFMAs before the store that waits for them - an L2 round trip per tap
+            // with nothing to hide it.
+            if (PIN) __builtin_amdgcn_sched_barrier(0);
             const int dy = tap / KW, dx = tap - dy * KW;
             const int tapoff = (dy * PW + dx) * ROWP;              // block-uniform
             const char* cW = sW + wbuf * BN * ROWP + brow * ROWP + lh * 16;      // this lane's weight row, k-half lh
@@ -269,12 +273,17 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, WB>(a); }
 // one weight buffer: 35 KB of LDS, so four blocks fit a CU if the registers allow four waves per SIMD
-template <int TERMS, int NITEM, int TM, int TN, int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, 0, 1>(a); }
+template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, 0, 1, PIN>(a); }
 
 template <int TERMS, int NITEM, int TM, int TN, int OCC>
 int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
     const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    static const bool pin = !(getenv("FF_PATCH_PIN") && atoi(getenv("FF_PATCH_PIN")) == 0);      // A/B switch
+    if (!pin) {
+        conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, false><<<(unsigned)blocks, 256, lds, s>>>(a);
+        return ff::check_launch("ff_conv2d_fwd(patch)");
+    }
     conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC><<<(unsigned)blocks, 256, lds, s>>>(a);
     return ff::check_launch("ff_conv2d_fwd(patch)");
 }
