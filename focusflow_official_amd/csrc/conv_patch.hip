@@ -218,9 +218,9 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
                     }
             }
             if (!last && ABL != 2) {          // next tap's weights go to the other buffer
-                if (WB == 1) __syncthreads(); // ... or, with one buffer, wait until everybody has read this tap's
+                if (WB == 1 && ABL != 4) __syncthreads(); // ... or, with one buffer, wait until everybody has read this tap's
                 store_w(WB == 1 ? 0 : wbuf ^ 1);
-                __syncthreads();
+                if (ABL != 4) __syncthreads();            // ABL 4: timing only, no per-tap barriers (WRONG results)
                 if (WB == 2) wbuf ^= 1;
             }
         }
@@ -273,13 +273,18 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, WB>(a); }
 // one weight buffer: 35 KB of LDS, so four blocks fit a CU if the registers allow four waves per SIMD
-template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, 0, 1, PIN>(a); }
+template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN>(a); }
 
 template <int TERMS, int NITEM, int TM, int TN, int OCC>
 int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
     const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
     static const bool pin = !(getenv("FF_PATCH_PIN") && atoi(getenv("FF_PATCH_PIN")) == 0);      // A/B switch
+    static const bool nobar = getenv("FF_PATCH_ABLATE") && atoi(getenv("FF_PATCH_ABLATE")) == 4;   // timing only
+    if (nobar) {
+        conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 4><<<(unsigned)blocks, 256, lds, s>>>(a);
+        return ff::check_launch("ff_conv2d_fwd(patch)");
+    }
     if (!pin) {
         conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, false><<<(unsigned)blocks, 256, lds, s>>>(a);
         return ff::check_launch("ff_conv2d_fwd(patch)");
@@ -352,7 +357,7 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     const size_t lds = ((npix * ROWP + 255) & ~255) + (occ ? 1 : 2) * 64 * tn * ROWP + lds_pad;
     if (lds > 96 * 1024) return 1;
     static const int abl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;   // timing experiments (wrong results!)
-    if (abl && th == 8 && tn == 1 && nitem <= 6 && t3) {
+    if (abl && abl != 4 && th == 8 && tn == 1 && nitem <= 6 && t3) {
         if (abl == 1) return launch<3, 6, 2, 1, 1>(a, lds, s);
         if (abl == 2) return launch<3, 6, 2, 1, 2>(a, lds, s);
         return launch<3, 6, 2, 1, 3>(a, lds, s);
