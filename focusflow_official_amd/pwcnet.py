@@ -33,6 +33,12 @@ def _pad4(c):
     return (c + 3) // 4 * 4
 
 
+# Inference buffers pad the 81-channel volume to 96 and the two 2-channel pieces (up-sampled flow / feature) to 16 each:
+# every DenseNet input then has a multiple of 32 channels and takes the patch-stationary / block-uniform conv kernels
+# instead of the generic im2col loader (which was 65 % of the forward).  The autograd path keeps the 84 / 4 / 4 layout.
+VOLP, FLP = 96, 16
+
+
 class _Packed:
     """Packed weights of one conv whose input is a padded-piece buffer: `pieces` = [(real, padded), ...]."""
 
@@ -230,31 +236,33 @@ class Decoder(nn.Module):
         self.level = level
         cur = {6: 81, 5: 81 + 128 + 4, 4: 81 + 96 + 4, 3: 81 + 64 + 4, 2: 81 + 32 + 4}
         c_one = {6: 0, 5: 128, 4: 96, 3: 64, 2: 32}[level]
-        self.base = [(81, 84)] + ([(c_one, c_one), (2, 4), (2, 4)] if level < 6 else [])
+        self.base = [(81, VOLP)] + ([(c_one, c_one), (2, FLP), (2, FLP)] if level < 6 else [])
+        base_t = [(81, 84)] + ([(c_one, c_one), (2, 4), (2, 4)] if level < 6 else [])       # autograd path
         if level < 6:
             prev_c1 = {5: 0, 4: 128, 3: 96, 2: 64}[level]     # tenOne channels of the PREVIOUS (coarser) level
             self.netUpflow = nn.ConvTranspose2d(2, 2, 4, 2, 1)
             self.netUpfeat = nn.ConvTranspose2d(cur[level + 1] + 448, 2, 4, 2, 1)
-            prev_base = [(81, 84)] + ([(prev_c1, prev_c1), (2, 4), (2, 4)] if level + 1 < 6 else [])
+            prev_base = [(81, VOLP)] + ([(prev_c1, prev_c1), (2, FLP), (2, FLP)] if level + 1 < 6 else [])
+            prev_base_t = [(81, 84)] + ([(prev_c1, prev_c1), (2, 4), (2, 4)] if level + 1 < 6 else [])
             self._upflow = _Packed(self.netUpflow, [(2, 4)], transposed=True)
             self._upfeat = _Packed(self.netUpfeat, [(c, c) for _, c in GROWTH] + prev_base, transposed=True)
         c = cur[level]
         grown = []
         self._convs = []
+        self._tconvs = []                          # autograd path: the 84 / 4 / 4 padded-piece layout, through ConvFn
         for name, co in reversed(GROWTH):          # netOne first
             conv = nn.Conv2d(c + sum(g for g, _ in grown), co, 3, 1, 1)
             setattr(self, name, nn.Sequential(conv, nn.LeakyReLU(0.1)))
             self._convs.append((name, _Packed(conv, grown + self.base)))
+            self._tconvs.append(_TrainPacked(conv, grown + base_t))
             grown = [(co, co)] + grown
         self.netSix = nn.Sequential(nn.Conv2d(c + 448, 2, 3, 1, 1))
         self._six = _Packed(self.netSix[0], grown + self.base)
         self.width = 448 + sum(p for _, p in self.base)
-        # autograd path: the same padded-piece layouts, through ConvFn
-        self._tconvs = [_TrainPacked(pk.conv, pk.pieces) for _, pk in self._convs]
-        self._tsix = _TrainPacked(self.netSix[0], grown + self.base)
+        self._tsix = _TrainPacked(self.netSix[0], grown + base_t)
         if level < 6:
             self._tupflow = _TrainPacked(self.netUpflow, [(2, 4)], transposed=True)
-            self._tupfeat = _TrainPacked(self.netUpfeat, self._upfeat.pieces, transposed=True)
+            self._tupfeat = _TrainPacked(self.netUpfeat, [(c, c) for _, c in GROWTH] + prev_base_t, transposed=True)
 
     def run_train(self, one, two, prev):
         """Autograd twin of run(): torch.cat builds the DenseNet tensor (same padded-piece channel order)."""
@@ -278,15 +286,15 @@ class Decoder(nn.Module):
         if prev is None:
             warped = two
         else:
-            flow_slot = buf[..., 448 + 84 + one.shape[3]: 448 + 84 + one.shape[3] + 4]
-            feat_slot = buf[..., 448 + 84 + one.shape[3] + 4:]
+            flow_slot = buf[..., 448 + VOLP + one.shape[3]: 448 + VOLP + one.shape[3] + FLP]
+            feat_slot = buf[..., 448 + VOLP + one.shape[3] + FLP:]
             pf, pb = prev["tenFlow"], prev["tenFeat"]
             hp, wp = pf.shape[1], pf.shape[2]
             self._upflow(ops.dilate2(pf, 2 * hp - 1, 2 * wp - 1), pad=2, out=flow_slot[..., :2])      # ConvTranspose2d
             self._upfeat(ops.dilate2(pb, 2 * hp - 1, 2 * wp - 1), pad=2, out=feat_slot[..., :2])
             warped = pwc.backwarp(two, flow_slot, BACKWARP_SCALE[self.level])
-            ops.act_copy(one, buf[..., 448 + 84: 448 + 84 + one.shape[3]], ACT_NONE)
-        vol = buf[..., 448:448 + 84]
+            ops.act_copy(one, buf[..., 448 + VOLP: 448 + VOLP + one.shape[3]], ACT_NONE)
+        vol = buf[..., 448:448 + VOLP]
         pwc._cv_fwd(one, warped, out=vol[..., :81])
         ops.act_copy(vol, vol, ACT_LEAKY)                     # leaky_relu(volume); the 3 pad channels stay 0
         off = 448
@@ -309,9 +317,10 @@ class Refiner(nn.Module):
             if i < 6:
                 layers.append(nn.LeakyReLU(0.1))
         self.netMain = nn.Sequential(*layers)
-        first = [(c, c) for _, c in GROWTH] + [(81, 84), (32, 32), (2, 4), (2, 4)]
+        first = [(c, c) for _, c in GROWTH] + [(81, VOLP), (32, 32), (2, FLP), (2, FLP)]
+        first_t = [(c, c) for _, c in GROWTH] + [(81, 84), (32, 32), (2, 4), (2, 4)]
         self._packs = [_Packed(self.netMain[0], first)] + [_Packed(self.netMain[2 * i], [(chans[i][0], chans[i][0])]) for i in range(1, 7)]
-        self._tpacks = [_TrainPacked(self.netMain[0], first)] + [PackedConv([self.netMain[2 * i]]) for i in range(1, 7)]
+        self._tpacks = [_TrainPacked(self.netMain[0], first_t)] + [PackedConv([self.netMain[2 * i]]) for i in range(1, 7)]
 
     def run_train(self, feat, flow):
         x = feat
