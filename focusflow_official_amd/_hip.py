@@ -27,6 +27,7 @@ class FFConvParams(C.Structure):
         ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
         ("act", C.c_int), ("act_res", C.c_int), ("w_format", C.c_int),
         ("dil_h", C.c_int), ("dil_w", C.c_int), ("x_amax", _fp),
+        ("in_scale", _fp), ("in_shift", _fp), ("in_act", C.c_int),
     ]
 
 
@@ -38,6 +39,7 @@ _SIGS = {
     "ff_norm_stats": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "ff_norm_apply": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_float,
                       _fp, _fp, C.c_int, _fp, C.c_int, _fp],
+    "ff_norm_coeffs": [_fp, C.c_int, C.c_int, _ll, C.c_float, _fp, _fp, _fp, _fp, _fp],
     "ff_bn_fold": [_fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_int, _fp],
     "ff_bn_update_running": [_fp, _ll, C.c_float, _fp, _fp, C.c_int, _fp],
     "ff_prep_input": [_fp, C.c_int, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp],

@@ -8,13 +8,18 @@ launches on NHWC fp32 tensors.
 """
 from typing import Tuple, Optional, Sequence
 
+import os
+
 import torch
 import torch.nn as nn
 
-from . import fn, ops
+from . import _hip, fn, ops
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 EPS = 1e-5
+
+
+_NORM_ON_LOAD = os.environ.get("FF_NORM_ON_LOAD", "1") != "0"      # measurement switch (ResidualBlock conv2 normalises while loading)
 
 
 class PackedConv:
@@ -308,6 +313,19 @@ class BasicParallelFusionLayer(nn.Module):
         return pc(x, act=act, res=res, act_res=ACT_RELU)  # 'none'
 
     def _block(self, blk: ResidualBlock, x):
+        p2 = blk._p2
+        if (_NORM_ON_LOAD and self.norm_fn == "instance" and not torch.is_grad_enabled() and ops.w_format() == _hip.W_F16X3
+                and p2.cin % 32 == 0 and (p2.kh, p2.kw, p2.stride) == (3, 3, 1)):
+            # inference: conv2 applies relu(norm1(.)) while it loads conv1's raw output - one full read + write of the
+            # activation less per block (same coefficients, same arithmetic as ff_norm_apply: bit-identical results)
+            t1 = blk._p1(x)
+            st = ops.norm_stats(t1, per_sample=True)
+            sc, sh = ops.norm_coeffs(st, t1.shape[1] * t1.shape[2], EPS)
+            if blk.downsample is not None:
+                x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
+            t2 = p2(t1, in_scale=sc, in_shift=sh, in_act=ACT_RELU)
+            st2 = ops.norm_stats(t2, per_sample=True)
+            return ops.norm_apply(t2, st2, True, EPS, act=ACT_RELU, res=x, out=t2)
         y = self._conv_norm(x, blk._p1, blk.norm1, ACT_RELU)
         if blk.downsample is not None:
             x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)

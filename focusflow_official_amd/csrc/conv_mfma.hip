@@ -279,6 +279,11 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     FF_REQUIRE(M < (1ll << 30) && (long long)p.B * p.H * p.W < (1ll << 30), "ff_conv2d_fwd: too many pixels");
 
     FF_REQUIRE(p.w_format >= FF_W_F32 && p.w_format <= FF_W_F16, "ff_conv2d_fwd: bad w_format %d", p.w_format);
+    FF_REQUIRE((p.in_scale == nullptr) == (p.in_shift == nullptr), "ff_conv2d_fwd: in_scale/in_shift must come together");
+    FF_REQUIRE(!p.in_scale || (p.w_format == FF_W_F16X3 && p.groups == 1 && p.x_c[1] == 0 && !p.x_amax && p.KH == 3 && p.KW == 3 &&
+                               p.stride == 1 && cin % 32 == 0 && (p.in_act == FF_ACT_NONE || p.in_act == FF_ACT_RELU) &&
+                               ff::aligned16(p.in_scale) && ff::aligned16(p.in_shift)),
+               "ff_conv2d_fwd: in_scale needs the f16x3 patch kernel (one segment, 3x3, stride 1, Cin %% 32 == 0)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (p.w_format != FF_W_F32) return ff::conv2d_fwd_split(p, (int)M, cin, s);
     if (const int rc = ff::conv2d_fwd_small(p, cin, s); rc != 1) return rc;    // 1- and 2-channel 3x3 heads: vector ALU

@@ -49,7 +49,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {   
 
 // NITEM = patch items per thread; TM x TN = 32-pixel x 32-channel MFMA tiles per wave (block: 2 x 2 waves =
 // 64 TM pixels x 64 TN channels); ABL = timing-only ablation
-template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false>   // WB = weight buffers in LDS
+template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false, bool INORM = false>   // WB = weight buffers in LDS
 __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
     constexpr int TH = 4 * TM, BN = 64 * TN, NW = 2 * TN;       // NW = 16-byte weight pieces per thread and tap
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,8 +103,14 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
     }
 
     f32x4 rp[NITEM], rw[NW];
+    f32x4 nmul = {1.f, 1.f, 1.f, 1.f}, nadd = {0.f, 0.f, 0.f, 0.f};   // INORM: the chunk's (scale, shift) of this thread's 4 channels
     auto load_patch = [&](int c) {          // 32-channel chunk c of the concatenated input (block-uniform)
         int ci0 = c * 32;
+        if (INORM) {                        // FFConvParams.in_scale / in_shift: one segment, tables [B][Cin]
+            const long long t = (long long)bimg * a.Cin + ci0 + kq * 4;
+            nmul = *reinterpret_cast<const f32x4*>(p.in_scale + t);
+            nadd = *reinterpret_cast<const f32x4*>(p.in_shift + t);
+        }
         __amdgpu_buffer_rsrc_t rs;
         int ldb;
         if (ci0 < c0) { rs = rs0; ldb = p.x_ld[0] * 4; }
@@ -124,7 +130,16 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
             const int row = prow[i];
             if (row < NPIX) {
                 f16x4 h0, h1;
-                split4(rp[i] * xs, h0, h1);
+                f32x4 v = rp[i];
+                if (INORM) {                // the producer's normalisation (+ ReLU) on the way in; padding is zero AFTER it
+                    v = v * nmul + nadd;
+                    if (p.in_act == FF_ACT_RELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    if (ppix[i] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                split4(v * xs, h0, h1);
                 *reinterpret_cast<f16x4*>(sP + row * ROWP + pc * 16 + half) = h0;
                 if (TERMS == 3) *reinterpret_cast<f16x4*>(sP + row * ROWP + 64 + pc * 16 + half) = h1;
             }
@@ -273,13 +288,17 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, WB>(a); }
 // one weight buffer: 35 KB of LDS, so four blocks fit a CU if the registers allow four waves per SIMD
-template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN>(a); }
+template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0, bool INORM = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN, INORM>(a); }
 
 template <int TERMS, int NITEM, int TM, int TN, int OCC>
 int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
     const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
     static const bool pin = !(getenv("FF_PATCH_PIN") && atoi(getenv("FF_PATCH_PIN")) == 0);      // A/B switch
+    if (a.p.in_scale) {          // normalise-on-load variant
+        conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+        return ff::check_launch("ff_conv2d_fwd(patch)");
+    }
     static const bool nobar = getenv("FF_PATCH_ABLATE") && atoi(getenv("FF_PATCH_ABLATE")) == 4;   // timing only
     if (nobar) {
         conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 4><<<(unsigned)blocks, 256, lds, s>>>(a);
@@ -363,6 +382,7 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
         return launch<3, 6, 2, 1, 3>(a, lds, s);
     }
     if (occ) return th == 8 ? launch_occ<3, 6, 2, 1, 4>(a, lds, s) : launch_occ<3, 4, 1, 1, 5>(a, lds, s);
+    if (p.in_scale) return 1;            // only the two variants above normalise while loading (the caller fails loudly)
 #define FF_PATCH_CASE(TH_, TN_, NI_) \
     if (th == TH_ && tn == TN_ && nitem <= NI_) return t3 ? launch<3, NI_, TH_ / 4, TN_>(a, lds, s) : launch<1, NI_, TH_ / 4, TN_>(a, lds, s);
     FF_PATCH_CASE(8, 1, 6) FF_PATCH_CASE(8, 1, 10)

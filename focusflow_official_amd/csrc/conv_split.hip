@@ -422,6 +422,7 @@ int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s) {
     if (rc != 1) return rc;
     rc = conv2d_fwd_patch(p, cin, s);                // same shapes, single-role waves (small grids / FF_WS_CONV=0)
     if (rc != 1) return rc;
+    if (p.in_scale) return fail(FF_EINVAL, "ff_conv2d_fwd: in_scale/in_shift: the patch kernel declined this shape");
     KernArgs a;
     a.p = p;
     a.M = M;

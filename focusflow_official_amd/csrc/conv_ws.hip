@@ -379,7 +379,7 @@ int conv2d_fwd_ws(const FFConvParams& p, int cin, hipStream_t s) {
     static const bool enabled = getenv("FF_WS_CONV") != nullptr ? atoi(getenv("FF_WS_CONV")) != 0 : false;   // opt-in: on par with conv_patch.hip, see DESIGN.md
     if (!enabled) return 1;
     const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
-    if (p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1 || p.x_amax) return 1;
+    if (p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1 || p.x_amax || p.in_scale) return 1;
     if (p.pad_h != p.KH / 2 || p.pad_w != p.KW / 2) return 1;
     const int shape = p.KH * 16 + p.KW;
     if (shape != 0x33 && shape != 0x15 && shape != 0x51) return 1;

@@ -96,6 +96,24 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     }
 }
 
+// the coefficients norm_apply_kernel computes in its prologue, as tables (same arithmetic, so a consumer that applies
+// them while loading sees bit-identical normalised values)
+__global__ void norm_coeffs_kernel(const double* __restrict__ stats, int total, int C, double inv_count, float eps,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % C;
+    const double mean = stats[i * 2] * inv_count;
+    double var = stats[i * 2 + 1] * inv_count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float gm = gamma ? gamma[c] : 1.f;
+    const float bt = beta ? beta[c] : 0.f;
+    scale[i] = rstd * gm;
+    shift[i] = bt - (float)mean * rstd * gm;
+}
+
 __global__ void bn_fold_kernel(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
                                float* sc, float* sh, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -145,6 +163,15 @@ extern "C" int ff_norm_apply(const float* x, int ld, float* y, int y_ld, int B, 
     norm_apply_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(x, ld, y, y_ld, HW, C, stats, per_sample,
                                                                           inv_count, eps, gamma, beta, act, res, res_ld);
     return ff::check_launch("ff_norm_apply");
+}
+
+extern "C" int ff_norm_coeffs(const double* stats, int S, int C, long long count, float eps, const float* gamma,
+                              const float* beta, float* scale, float* shift, void* stream) {
+    FF_REQUIRE(stats && scale && shift && S > 0 && C > 0 && count > 0, "ff_norm_coeffs: bad argument");
+    const int total = S * C;
+    norm_coeffs_kernel<<<(total + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(stats, total, C, 1.0 / (double)count, eps,
+                                                                                          gamma, beta, scale, shift);
+    return ff::check_launch("ff_norm_coeffs");
 }
 
 extern "C" int ff_bn_fold(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,

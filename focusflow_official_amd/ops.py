@@ -138,7 +138,8 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
            stride: int = 1, pad=(0, 0), act: int = ACT_NONE, out: Optional[Tensor] = None,
            res: Optional[Tensor] = None, act_res: int = ACT_NONE, ch_scale: Optional[Tensor] = None,
            ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0, dilation: int = 1,
-           x_amax: Optional[Tensor] = None) -> Tensor:
+           x_amax: Optional[Tensor] = None, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None,
+           in_act: int = ACT_NONE) -> Tensor:
     """Convolution over the channel-concatenation of `xs` (see FFConvParams).  `wpack` is fp32
     [Cout][K] (w_fmt 0) or the split rows of pack_split (w_fmt 1/2).  x_amax: device word holding the bits of
     max|x| (act_bwd): the split formats then scale the input by a power of two so that gradients fit fp16."""
@@ -176,6 +177,9 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     p.act, p.act_res, p.w_format = act, act_res, w_fmt
     p.dil_h = p.dil_w = dilation
     p.x_amax = x_amax.data_ptr() if x_amax is not None else None
+    if in_scale is not None:   # norm_coeffs tables [B][Cin]: the input is read as in_act(x * scale + shift) (normalise-on-load)
+        assert in_scale.shape == in_shift.shape == (b, cin) and in_scale.is_contiguous() and in_shift.is_contiguous()
+        p.in_scale, p.in_shift, p.in_act = in_scale.data_ptr(), in_shift.data_ptr(), in_act
     assert out.shape[:3] == (b, ho, wo) and out.shape[3] >= cout
     _timed_call("conv", "ff_conv2d_fwd", C.byref(p), _stream(), note=(2.0 * b * ho * wo * cout * kh * kw * cin, w_fmt))
     return out
@@ -266,6 +270,14 @@ def norm_stats(x: Tensor, per_sample: bool) -> Tensor:
     stats = _zero_stats(b if per_sample else 1, c, x.device)
     _hip.call("ff_norm_stats", _p(x), _ld(x), b, h * w, c, int(per_sample), _p(stats), _stream())
     return stats
+
+
+def norm_coeffs(stats: Tensor, count: int, eps: float = 1e-5, gamma=None, beta=None):
+    """The (scale, shift) tables norm_apply would use, fp32 [S][C] each, for conv2d(in_scale=..., in_shift=...)."""
+    s_, c, _ = stats.shape
+    out = torch.empty((2, s_, c), dtype=torch.float32, device=stats.device)
+    _hip.call("ff_norm_coeffs", _p(stats), s_, c, count, eps, _p(gamma), _p(beta), _p(out[0]), _p(out[1]), _stream())
+    return out[0], out[1]
 
 
 def norm_apply(x: Tensor, stats: Tensor, per_sample: bool, eps: float = 1e-5, gamma=None, beta=None,

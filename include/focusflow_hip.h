@@ -86,6 +86,11 @@ typedef struct FFConvParams {
     const unsigned int* x_amax;        /* NULL, or device word = bits of max|x| over the input (ff_act_bwd): the split
                                         * formats then read x * 2^k (k puts the maximum at 2^10) and undo it in the
                                         * epilogue - gradients lie far below fp16's range (dgrad on the f16 pipe)   */
+    const float* in_scale;             /* NULL, or per (image, input channel) tables [B][Cin] from ff_norm_coeffs: the   */
+    const float* in_shift;             /* convolution reads in_act(x * in_scale + in_shift) - the normalisation (+ ReLU) */
+    int in_act;                        /* of its producer applied while loading, zero padding AFTER it.  One segment,    */
+                                       /* groups == 1, split formats, stride-1 3x3 with Cin % 32 == 0 (patch kernel);    */
+                                       /* in_act: FF_ACT_NONE or FF_ACT_RELU                                             */
 } FFConvParams;
 
 int ff_conv2d_fwd(const FFConvParams* p, void* stream);
@@ -108,6 +113,8 @@ int ff_pack_split_f16(const float* src_rows, void* dst, long long rows, int K, v
  *                   (per_sample=1) or 0 (batch statistics).  `stats` must be
  *                   zeroed by the caller (hipMemsetAsync) before the call.
  *   ff_norm_apply : y = act((x-mean)*rstd*gamma + beta) ; if res: y = relu(y+res)
+ *   ff_norm_coeffs: the (scale, shift) ff_norm_apply would use, as fp32 tables [S][C] (S = B if per_sample else 1),
+ *                   for a consumer convolution that normalises while loading (FFConvParams.in_scale / in_shift)
  *   ff_bn_fold    : eval-mode BatchNorm as a per-channel scale/shift for the
  *                   convolution epilogue.
  *   ff_bn_update_running : running-stat update of a train-mode BatchNorm.
@@ -118,6 +125,8 @@ int ff_norm_apply(const float* x, int ld, float* y, int y_ld, int B, int HW, int
                   const double* stats, int per_sample, float eps,
                   const float* gamma, const float* beta, int act,
                   const float* res, int res_ld, void* stream);
+int ff_norm_coeffs(const double* stats, int S, int C, long long count, float eps, const float* gamma, const float* beta,
+                   float* scale, float* shift, void* stream);
 int ff_bn_fold(const float* running_mean, const float* running_var, const float* gamma,
                const float* beta, float eps, float* ch_scale, float* ch_shift, int C, void* stream);
 int ff_bn_update_running(const double* stats, long long count, float momentum,

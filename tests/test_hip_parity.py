@@ -417,6 +417,37 @@ def test_gru_context_share_computed_once_matches_per_iteration_convs(det_sd, mon
     close(fu1.cpu(), fu0.cpu(), rtol=0, atol=1e-4, what="flow_up")
 
 
+@pytest.mark.parametrize("b,c,h,w", [(2, 64, 40, 48), (16, 64, 64, 128), (3, 96, 31, 47), (2, 128, 16, 24)])
+def test_conv_normalises_its_input_while_loading(ops, b, c, h, w):
+    """FFConvParams.in_scale / in_shift: conv(relu(instance_norm(x))) with the normalisation applied inside the conv's
+    loader (ff_norm_coeffs tables) must give the bits of norm_apply followed by the plain conv - same coefficients,
+    same fp32 operations, zero padding after the normalisation."""
+    g = torch.Generator().manual_seed(b * 100 + c)
+    x = nhwc(torch.randn(b, c, h, w, generator=g) * 2 + 0.7)
+    wt = torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    bias = torch.randn(c, generator=g)
+    wp = torch.empty(c, 9 * c, device=DEV)
+    ops.pack_conv_weight(wt.to(DEV), wp, c)
+    wp = ops.pack_split(wp)
+    st = ops.norm_stats(x, per_sample=True)
+    ref = ops.conv2d([ops.norm_apply(x, st, True, 1e-5, act=1)], wp, bias.to(DEV), c, 3, 3, 1, 1, w_fmt=1)
+    sc, sh = ops.norm_coeffs(st, h * w, 1e-5)
+    out = ops.conv2d([x], wp, bias.to(DEV), c, 3, 3, 1, 1, w_fmt=1, in_scale=sc, in_shift=sh, in_act=1)
+    assert torch.equal(out, ref)
+
+
+def test_normalise_on_load_forward_is_bit_identical(det_sd, monkeypatch):
+    from focusflow_official_amd import cce
+    m = _model(det_sd)
+    inp = [t.to(DEV) for t in orc.shifted_pair(2, 128, 192, seed=6)]
+    with torch.no_grad():
+        monkeypatch.setattr(cce, "_NORM_ON_LOAD", False)
+        fl0, fu0 = m(*inp, raft_iters=3, test_mode=True)
+        monkeypatch.setattr(cce, "_NORM_ON_LOAD", True)
+        fl1, fu1 = m(*inp, raft_iters=3, test_mode=True)
+    assert torch.equal(fl0, fl1) and torch.equal(fu0, fu1)
+
+
 def test_config5_shape_540x960_padded(det_sd):
     """BASELINE config 5's frame size: 540x960 replicate-padded to 544x960 (68x120 at 1/8: level 3 is 8x15, odd
     widths at two pyramid levels), against the CPU oracle.  Few iterations on purpose: with synthetic weights the
