@@ -105,8 +105,9 @@ class RAFT(nn.Module):
             # coords1 is advanced in place by ff_coords_step (raw pointer: autograd cannot see it), so a
             # recorded lookup keeps its own snapshot for the backward scatter
             corr = corr_fn(coords1.clone() if taped else coords1)
-            flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
-            ops.coords_step(coords1, None, flow4, None)                   # flow = coords1 - coords0
+            if it == 0 or taped:   # later iterations: the flow written with the coordinate update below is this very tensor
+                flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
+                ops.coords_step(coords1, None, flow4, None)               # flow = coords1 - coords0
             fill = lambda motion, c=coords1: ops.coords_step(c, None, None, motion[..., 126:])  # noqa: E731
             need_mask = not lazy or it == iters - 1
             net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre)
