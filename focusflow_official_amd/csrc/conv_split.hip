@@ -163,23 +163,24 @@ __device__ __forceinline__ void conv_split_body(const KernArgs& a) {
         const int dy = tap / p.KW, dx = tap - dy * p.KW;
         const float* xp;
         int ld;
-        if (ci < c0) { xp = xs0; ld = p.x_ld[0]; }
+        if (!kok) { xp = xs0; ld = p.x_ld[0]; ci = 0; }
+        else if (ci < c0) { xp = xs0; ld = p.x_ld[0]; }
         else if (ci < c01) { xp = xs1; ld = p.x_ld[1]; ci -= c0; }
         else { xp = xs2; ld = p.x_ld[2]; ci -= c01; }
+        // No load under a branch (each would be waited for before the next is issued: LA + LB dependent round trips per
+        // chunk): masked rows read the segment's first pixel and are zeroed by a select.
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int hi = hi0[i] + dy * dlh, wi = wi0[i] + dx * dlw;
             const bool ok = kok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(xp + (long long)(img[i] + hi * W + wi) * ld + ci);
-            ra[i] = v;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (ok ? (long long)(img[i] + hi * W + wi) * ld + ci : 0ll));
+            ra[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {   // weights: 16-byte piece kq of this chunk's 128-byte row, already split
             const int n = n0 + rbase + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(wbase + (long long)n * a.w_row_bytes + (long long)kc * ROWB + kq * 16);
-            rb[i] = v;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + (long long)min(n, p.Cout - 1) * a.w_row_bytes + (long long)kc * ROWB + kq * 16);
+            rb[i] = n < p.Cout ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stage_store = [&](int buf, const f32x4 (&ra)[LA], const f32x4 (&rb)[LB]) {
