@@ -7,12 +7,25 @@ launches + 4 gate kernels per iteration:
   epilogue on cat[r*h, x] (3 input segments, no concat buffer) ; blend   (x2)
   [flow_head.conv1|mask.0] fused Cout=512 with relu ; flow_head.conv2 ; mask.2 (x0.25)
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import fn, ops
 from .cce import PackedConv
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+
+
+_SIDE_STREAM = os.environ.get("FF_SIDE_STREAM", "1") != "0"      # measurement switch (BasicMotionEncoder.run)
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
 
 
 class FlowHead(nn.Module):
@@ -87,6 +100,24 @@ class BasicMotionEncoder(nn.Module):
         """flow4: (B,H,W,4) zero-padded flow.  Returns motion (B,H,W,128): 126 conv channels, and
         `fill_flow(motion)` writes the flow into channels 126:128 (torch.cat([out, flow]), update.py:97)."""
         c1 = self._c1p if corr.shape[3] == self._c1p.cin_pad else self._c1
+        if _SIDE_STREAM and not torch.is_grad_enabled():
+            # Inference: the flow branch (convf1 -> convf2) does not depend on the lookup and neither branch fills the
+            # chip at 1/8 resolution (576 and 384 blocks on 1024 slots): run it on a second HIP stream beside
+            # convc1 -> convc2.  It starts behind the lookup (event), so the lookup's own timing stays clean.
+            main = torch.cuda.current_stream()
+            side = _side_stream(flow4.device)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                flo = self._f2(self._f1(flow4, act=ACT_RELU), act=ACT_RELU)
+                join = torch.cuda.Event()
+                join.record(side)
+            flow4.record_stream(side)          # allocated on the main stream, read on the side stream
+            cor = self._c2(c1(corr, act=ACT_RELU), act=ACT_RELU)
+            main.wait_event(join)
+            flo.record_stream(main)            # allocated on the side stream, read on the main stream
+            return fn.conv(self._cv, [cor, flo], act=ACT_RELU, pad_out=True, fill_tail=fill_flow)
         cor = fn.conv(self._c2, fn.conv(c1, corr, act=ACT_RELU), act=ACT_RELU)
         flo = fn.conv(self._f2, fn.conv(self._f1, flow4, act=ACT_RELU), act=ACT_RELU)
         return fn.conv(self._cv, [cor, flo], act=ACT_RELU, pad_out=True, fill_tail=fill_flow)
