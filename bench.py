@@ -127,6 +127,43 @@ def timed_region(step, steps, world, sync, device=None):
     return elapsed, out
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as CHILD processes with the
+    torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, train.py:94-132 of the reference reads the same
+    variables) and relay their output.  The parent never touches the GPU and never replaces itself (no exec):
+    it waits for the children and exits with the worst return code.  If a rank dies the others are terminated."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                log(f"rank {r} exited with {code}: stopping the other ranks")
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def harness_selftest(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -228,6 +265,9 @@ def main():
                     help="no model: a sleep() stands in for the step so the multi-rank harness (sharding, barrier, "
                          "max-over-ranks timing, single JSON line) can be tested on CPU with gloo")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare (the N=1 command with a different --gpus): become the launcher; nothing above initialised HIP
+        sys.exit(self_launch(args.gpus))
     if args.harness_selftest:
         return harness_selftest(args)
 

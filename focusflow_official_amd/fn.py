@@ -28,14 +28,16 @@ class GraphScope:
 
     A conv that is applied many times in one graph (the update block: 12 iterations; fnet: both frames) would hand
     autograd one weight-gradient tensor per application - per application a zero-fill, an un-pack launch and an
-    accumulation add (about 1800 small launches per training step).  Inside a scope the wgrad kernel instead adds
-    into one buffer per conv (it accumulates with atomics anyway) and only the LAST application to run its backward
-    returns the total to autograd, so hooks (DDP) still see exactly one gradient per parameter.  If a backward pass
-    ends with applications that never ran (a loss that does not reach some of them), `flush` adds what was
-    accumulated straight into `.grad`."""
+    accumulation add (about 1800 small launches per training step).  Inside a scope every application of a conv is
+    wired to ONE `ParamGate` node per conv instead of to the parameters themselves: the wgrad kernel adds into one
+    buffer per conv (it accumulates with atomics anyway), the applications return no parameter gradient, and the gate -
+    which the autograd engine runs exactly once per backward pass, after every application the loss reaches has run -
+    hands the total to the parameters THROUGH autograd.  Hooks (DDP's reducer, find_unused_parameters=False) therefore
+    see exactly one gradient per parameter, also when the loss reaches only some of the applications, and a second
+    backward over a retained graph starts from an empty buffer again."""
 
     def __init__(self):
-        self.live, self.acc, self._cb_queued = {}, {}, False
+        self.acc, self.gates = {}, {}
         self._amax_pool, self._amax_used = None, 0
 
     def amax_word(self, device):
@@ -44,26 +46,40 @@ class GraphScope:
         self._amax_used += 1
         return self._amax_pool[self._amax_used - 1:self._amax_used]
 
-    def queue_flush(self):
-        if not self._cb_queued:
-            self._cb_queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+    def gated(self, pc, params):
+        """The aliases of pc's parameters that this pass's applications take as inputs (one gate per conv group)."""
+        g = self.gates.get(pc)
+        if g is None:
+            it = iter(ParamGate.apply(self, pc, *[p for p in params if p is not None]))
+            g = self.gates[pc] = [None if p is None else next(it) for p in params]
+        return g
 
-    def flush(self):
-        self._cb_queued = False
-        for pc, (dwp, db) in list(self.acc.items()):
-            off = 0
-            for cv in pc.convs:
-                co = cv.out_channels
-                if cv.weight.requires_grad:
-                    gw = pc.unpack_wgrad(dwp, pc.convs.index(cv), off)
-                    cv.weight.grad = gw if cv.weight.grad is None else cv.weight.grad + gw
-                if cv.bias is not None and cv.bias.requires_grad:
-                    gb = db[off:off + co].clone()
-                    cv.bias.grad = gb if cv.bias.grad is None else cv.bias.grad + gb
-                off += co
-        self.acc.clear()
-        self.live.clear()
+
+class ParamGate(torch.autograd.Function):
+    """Identity on a conv group's parameters; its backward delivers the weight/bias gradients that the group's
+    applications accumulated in `scope.acc[pc]` during this backward pass."""
+
+    @staticmethod
+    def forward(ctx, scope, pc, *params):
+        ctx.scope, ctx.pc = scope, pc
+        ctx.set_materialize_grads(False)
+        return tuple(p.view_as(p) for p in params)
+
+    @staticmethod
+    def backward(ctx, *unused):
+        pc = ctx.pc
+        acc = ctx.scope.acc.pop(pc, None)
+        grads: List[Optional[Tensor]] = [None, None]
+        off, k = 0, 2                     # k: position among this node's inputs (None parameters were not passed)
+        for j, cv in enumerate(pc.convs):
+            co = cv.out_channels
+            grads.append(pc.unpack_wgrad(acc[0], j, off) if acc is not None and ctx.needs_input_grad[k] else None)
+            k += 1
+            if cv.bias is not None:
+                grads.append(acc[1][off:off + co].clone() if acc is not None and ctx.needs_input_grad[k] else None)
+                k += 1
+            off += co
+        return tuple(grads)
 
 
 _scope: Optional[GraphScope] = None
@@ -81,11 +97,14 @@ def end_graph():
     _scope = None
 
 
+NFIX = 8   # non-tensor arguments of ConvFn.forward
+
+
 class ConvFn(torch.autograd.Function):
     """y = act(conv(cat(xs)) + bias) * ... (+ res).  tensors = xs..., [res], (w_i, b_i)..."""
 
     @staticmethod
-    def forward(ctx, pc, act, out_scale, nseg, has_res, pad_out, fill_tail, *tensors):
+    def forward(ctx, pc, act, out_scale, nseg, has_res, pad_out, fill_tail, scope, *tensors):
         xs = list(tensors[:nseg])
         res = tensors[nseg] if has_res else None
         assert not (has_res and act != ACT_NONE), "residual + activation is only fused on the inference path"
@@ -104,11 +123,9 @@ class ConvFn(torch.autograd.Function):
                 fill_tail(full)
             y = full
         ctx.pc, ctx.act, ctx.out_scale, ctx.nseg, ctx.has_res = pc, act, out_scale, nseg, has_res
+        ctx.nparam = len(tensors) - nseg - (1 if has_res else 0)
         ctx.save_for_backward(*xs, y if act != ACT_NONE else None)
-        ctx.scope = None
-        if _scope is not None and ops.w_format() and any(ctx.needs_input_grad[7 + nseg + (1 if has_res else 0):]):
-            ctx.scope = _scope
-            _scope.live[pc] = _scope.live.get(pc, 0) + 1
+        ctx.scope = scope      # not None: the parameter inputs are this pass's ParamGate aliases
         return y
 
     @staticmethod
@@ -120,9 +137,9 @@ class ConvFn(torch.autograd.Function):
         scope = ctx.scope
         g, amax = ops.act_bwd(dy, y, act, ctx.out_scale, pc.cout, want_amax=True,    # (B,Ho,Wo,Cpad), zero padded
                               amax=scope.amax_word(dy.device) if scope is not None else None)
-        grads: List[Optional[Tensor]] = [None] * 7
+        grads: List[Optional[Tensor]] = [None] * NFIX
         # input gradient: forward conv over g with flipped/transposed weights
-        need_dx = any(ctx.needs_input_grad[7 + i] for i in range(nseg))
+        need_dx = any(ctx.needs_input_grad[NFIX + i] for i in range(nseg))
         dxs = [None] * nseg
         if need_dx:
             wd, dfmt = pc.get_dgrad()
@@ -138,14 +155,14 @@ class ConvFn(torch.autograd.Function):
                             w_fmt=dfmt, x_amax=amax if dfmt else None, dilation=d)
             off = 0
             for i, x in enumerate(xs):
-                if ctx.needs_input_grad[7 + i]:
+                if ctx.needs_input_grad[NFIX + i]:
                     dxs[i] = dx[..., off:off + x.shape[3]]
                 off += x.shape[3]
         grads += dxs
         if ctx.has_res:
             grads.append(dy)                                           # y = conv + res
         # parameter gradients
-        base = 7 + nseg + (1 if ctx.has_res else 0)
+        base = NFIX + nseg + (1 if ctx.has_res else 0)
         need_w = any(ctx.needs_input_grad[base:])
         dwp = db = None
         if need_w and scope is not None:   # shared weights: add into the conv's buffer, deliver with the last application
@@ -156,11 +173,7 @@ class ConvFn(torch.autograd.Function):
                 acc = scope.acc[pc] = (z[:pc.cout * kdim].view(pc.cout, kdim), z[pc.cout * kdim:])
             ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True, dw=acc[0], db=acc[1],
                              dilation=pc.dil)
-            scope.live[pc] -= 1
-            if scope.live[pc] > 0:
-                scope.queue_flush()
-                return tuple(grads + [None] * (2 * len(pc.convs)))
-            dwp, db = scope.acc.pop(pc)
+            return tuple(grads + [None] * ctx.nparam)      # the pass's ParamGate delivers the total
         elif need_w:   # weight + bias gradient in one launch (f16 matrix pipe unless the conv precision is fp32)
             dwp, db = ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True, dilation=pc.dil)
         off = 0
@@ -373,8 +386,11 @@ def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail
         xs = [xs]
     params = pc.params()
     if recording(*xs, res, *params):
+        scope = None
+        if _scope is not None and ops.w_format() and recording(*params):
+            scope, params = _scope, _scope.gated(pc, params)
         args = list(xs) + ([res] if res is not None else []) + params
-        return ConvFn.apply(pc, act, out_scale, len(xs), res is not None, pad_out, fill_tail, *args)
+        return ConvFn.apply(pc, act, out_scale, len(xs), res is not None, pad_out, fill_tail, scope, *args)
     if pad_out:
         b, h, w, _ = xs[0].shape
         ho = (h + 2 * pc.pad[0] - pc.kh) // pc.stride + 1

@@ -16,7 +16,7 @@ from conftest import ROOT, golden_spec
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, partial):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from argparse import Namespace
@@ -37,7 +37,9 @@ def _worker(rank, world, port, out_dir):
     inp = orc.shifted_pair(2, 128, 128, seed=21)
     mine = [t[rank:rank + 1].to(dev) for t in inp]
     preds = ddp(*mine, raft_iters=2)
-    loss = sum(p.abs().mean() for p in preds)
+    # partial: the loss reaches only the last prediction, so some applications of the shared update-block convs never
+    # run their backward - DDP (find_unused_parameters=False) must still see one gradient per parameter (fn.ParamGate)
+    loss = preds[-1].abs().mean() if partial else sum(p.abs().mean() for p in preds)
     (loss * world).backward()                                   # train.py:313-316
     grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
     assert all(g is not None for g in grads.values())
@@ -47,12 +49,13 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_ddp_two_ranks_match_full_batch(tmp_path):
+@pytest.mark.parametrize("partial", [False, True])
+def test_ddp_two_ranks_match_full_batch(tmp_path, partial):
     from argparse import Namespace
     from focusflow_official_amd import FF_RAFT_FUSION
     from oracle import ffraft_ref as orc
     from oracle.weights import det_tensor
-    mp.spawn(_worker, args=(2, 29533, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, 29533 + int(partial), str(tmp_path), partial), nprocs=2, join=True)
     ddp_grads = torch.load(os.path.join(tmp_path, "ddp_grads.pt"))
     cfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"),
                     MODEL=Namespace(FUSION_TYPE="1x1conv", LOAD_MODULE_TO_BRANCH=False))
@@ -65,7 +68,7 @@ def test_ddp_two_ranks_match_full_batch(tmp_path):
     preds = model(*inp, raft_iters=2)
     # full batch: mean over 2 samples of per-sample means == sum of the two ranks' losses / 2 * ... :
     # rank loss_r = sum_i mean_over_sample_r(|p_i|); DDP averages world*loss_r over ranks = sum_r loss_r
-    loss = sum(torch.stack([p[r].abs().mean() for r in range(2)]).sum() for p in preds)
+    loss = sum(torch.stack([p[r].abs().mean() for r in range(2)]).sum() for p in (preds[-1:] if partial else preds))
     loss.backward()
     report = []
     for k, p in model.named_parameters():

@@ -300,10 +300,9 @@ def test_frozen_bn_training_step_gives_gradients(det_sd):
 
 @pytest.mark.parametrize("partial", [False, True])
 def test_shared_weight_gradient_scope_matches_immediate_mode(det_sd, partial, monkeypatch):
-    """fn.GraphScope (one weight-gradient buffer per conv and per recorded pass, delivered by the last application
-    to run its backward) must give the gradients of the plain one-tensor-per-application path - also when the loss
-    reaches only some applications (final prediction only: the first iterations' mask head never runs backward and
-    its accumulated share is flushed into .grad at the end of the pass)."""
+    """fn.GraphScope (one weight-gradient buffer per conv and per recorded pass, delivered once per backward pass by
+    the conv's fn.ParamGate node) must give the gradients of the plain one-tensor-per-application path - also when the
+    loss reaches only some applications (final prediction only: the first iterations' mask head never runs backward)."""
     from focusflow_official_amd import FF_RAFT_FUSION, fn
     inp = [t.to(DEV) for t in orc.shifted_pair(1, 128, 128, seed=11)]
     results = []

@@ -38,3 +38,29 @@ def test_two_rank_gloo_harness():
     # rank 1 sleeps 20 ms per step: the reported time is the MAX over ranks
     assert d["ms_per_step"] >= 19.0
     assert abs(d["value"] - 16 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_launches_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE: the parent must start the two ranks itself
+    (the driver's N=1 command with a different --gpus) and relay rank 0's single JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "0",
+           "--harness-selftest"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["shard"] == [0, 8] and d["ms_per_step"] >= 19.0
+
+
+def test_self_launch_propagates_a_rank_failure():
+    """No GPU here: the forward bench must fail in every rank, and the launcher must return non-zero instead of hanging."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode != 0
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
