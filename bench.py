@@ -29,7 +29,8 @@ DTYPES = {"f16x3": "f32 via fp16x3 split operands on the f16 MFMA pipe (f32 accu
           "fp32": "f32", "f16": "f16 operands, f32 accumulate (reduced precision)"}
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense f16/bf16 MFMA, fp32 MFMA
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-LOOKUP_BYTES_PER_QUERY = 2904  # 4*100*4 (windows) + 4*81*4 (output) + 8 (coords)
+# L*(2r+2)^2*s_corr (windows) + L*(2r+1)^2*4 (fp32 output) + 8 (coords); s_corr = 4 (fp32 pyramid) or 2 (fp16)
+LOOKUP_BYTES_PER_QUERY = {"fp32": 4 * 100 * 4 + 4 * 81 * 4 + 8, "fp16": 4 * 100 * 2 + 4 * 81 * 4 + 8}   # 2904 / 2104
 
 
 def cfg():
@@ -69,14 +70,15 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def pmc_traffic(queries):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_lookup_traffic.json:
+def pmc_traffic(queries, pyramid):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_lookup_traffic[_fp16].json:
     TCC_EA0_RDREQ x 128 B + WRITE_SIZE), scaled per query; None if the profile is absent.  PMC passes
     cannot run inside the timed process, so this is the same kernel measured by tools/bench_lookup.py."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_lookup_traffic.json")) as f:
+        name = "r02_lookup_traffic.json" if pyramid == "fp32" else "r02_lookup_traffic_fp16.json"
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
-        return int(d["traffic_bytes_per_launch"] / (d["algorithmic_bytes_per_launch"] / LOOKUP_BYTES_PER_QUERY) * queries)
+        return int(d["traffic_bytes_per_launch"] / d["queries_per_launch"] * queries)
     except (OSError, KeyError, ValueError):
         return None
 
@@ -239,6 +241,12 @@ def train_mode(args, world, rank, local_rank, device):
         dist.destroy_process_group()
 
 
+def TiledPyramidBytes(h8, w8, half):
+    """Bytes of one query's four tiled planes (ops.TiledPyramid / csrc/corr_layout.h)."""
+    from focusflow_official_amd import ops
+    return sum(ops.TiledPyramid.plane_elems(h8, w8, l, half) for l in range(4)) * (2 if half else 4)
+
+
 def ops_precision():
     from focusflow_official_amd import ops
     return ops.conv_precision()
@@ -254,6 +262,9 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pyramid", choices=["fp32", "fp16"], default="fp32",
+                    help="storage type of the correlation pyramid: fp32 = the reference's arithmetic (headline); fp16 = "
+                         "BASELINE configs[4] (540x960 padded to 544x960, iters 32: --height 544 --width 960 --iters 32 --batch 1)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--skip-unused-upsample", action="store_true",
                     help="NOT the default / not the headline number: compute the mask head + convex up-sampling only for "
@@ -289,6 +300,7 @@ def main():
     torch.manual_seed(1234)
     model = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
     model.flow_net.skip_unused_upsample = bool(args.skip_unused_upsample)
+    model.flow_net.corr_pyramid_dtype = args.pyramid
     # weak scaling: every rank owns args.batch independent pairs of the global batch
     lo, hi = shard_units(args.batch * world, world, rank)
     batch = synthetic_batch(hi - lo, args.height, args.width, 1234 + rank, device)
@@ -324,21 +336,24 @@ def main():
             prof = ops.profile_end()
             lookup_ms, vol_ms = prof["lookup"], prof["corr_volume"]
         per_launch_ms = sum(lookup_ms) / max(1, len(lookup_ms))
-        achieved = LOOKUP_BYTES_PER_QUERY * q / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        per_q = LOOKUP_BYTES_PER_QUERY[args.pyramid]
+        achieved = per_q * q / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        c2 = (args.height, args.width, args.iters, args.batch) == (384, 512, 12, 8) and args.pyramid == "fp32"
         line = {
-            "metric": "frame-pairs/sec FF-RAFT 384x512 iters=12", "value": round(pairs / elapsed, 3),
+            "metric": f"frame-pairs/sec FF-RAFT {args.height}x{args.width} iters={args.iters}", "value": round(pairs / elapsed, 3),
             "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPES[ops.conv_precision()], "data": "synthetic",
             "config": {"workload": f"FF-RAFT forward (test_mode), {args.batch} pairs/GPU {args.height}x{args.width}, "
-                                   f"iters={args.iters}, random-init weights, ORB-like masks (BASELINE configs[1])",
-                       "pairs_per_gpu": args.batch, "conv_precision": ops.conv_precision(), "hipgraph": bool(args.graph), "skip_unused_upsample": bool(args.skip_unused_upsample),
+                                   f"iters={args.iters}, {args.pyramid} correlation pyramid, random-init weights, ORB-like masks "
+                                   f"({'BASELINE configs[1]' if c2 else 'BASELINE configs[4]' if args.pyramid == 'fp16' else 'non-headline shape'})",
+                       "pairs_per_gpu": args.batch, "corr_pyramid": args.pyramid, "conv_precision": ops.conv_precision(), "hipgraph": bool(args.graph), "skip_unused_upsample": bool(args.skip_unused_upsample),
                        "parallelism": f"dp{world} (independent shards, no collective)"},
-            "roofline": {"kernel": "lookup_wave_kernel (ff_corr_lookup_fwd)", "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(q),
+            "roofline": {"kernel": f"lookup_tiled_kernel<{'fp16' if args.pyramid == 'fp16' else 'fp32'}> (ff_corr_lookup_tiled_fwd)",
+                         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(q, args.pyramid),
                          "launches": len(lookup_ms), "avg_launch_us": round(per_launch_ms * 1e3, 2),
-                         "algorithmic_bytes_per_launch": LOOKUP_BYTES_PER_QUERY * q},
+                         "algorithmic_bytes_per_query": per_q, "algorithmic_bytes_per_launch": per_q * q},
         }
         # corr-volume build (BASELINE.md "also reported"): dense HWxC x CxHW contraction on the matrix pipe
         q1 = (args.height // 8) * (args.width // 8)
@@ -347,10 +362,14 @@ def main():
         terms = {"f16x3": 3, "f16": 1, "fp32": 1}[ops.conv_precision()]
         peak = MFMA_PEAK_TFLOPS["fp32" if ops.conv_precision() == "fp32" else "f16"]
         issued = vol_flop * terms / (vol_avg_ms * 1e-3) / 1e12 if vol_avg_ms > 0 else 0.0
+        pyr_bytes = (hi - lo) * q1 * TiledPyramidBytes(args.height // 8, args.width // 8, args.pyramid == "fp16")
         line["roofline_corr_build"] = {
-            "kernel": "conv kernel, groups=B (ff_conv2d_fwd via ops.corr_volume)", "bound": "mfma",
+            "kernel": "corr_build_kernel (ff_corr_build: f16x3 volume + 3 pooled levels + tiled store, one launch)" if ops.conv_precision() == "f16x3"
+                      else "conv kernel, groups=B (ff_conv2d_fwd) + pooling pass + retile", "bound": "mfma",
             "achieved": round(issued, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(issued / peak, 4),
-            "note": f"{terms} MFMA term(s) per fp32-accurate product; useful rate {vol_flop / (vol_avg_ms * 1e-3) / 1e12:.1f} TFLOP/s",
+            "note": f"{terms} MFMA term(s) per fp32-accurate product; useful rate {vol_flop / (vol_avg_ms * 1e-3) / 1e12:.1f} TFLOP/s; "
+                    f"the launch also writes the whole pyramid once ({pyr_bytes / 1e6:.1f} MB)",
+            "write_gbs": round(pyr_bytes / (vol_avg_ms * 1e-3) / 1e9, 1) if vol_avg_ms > 0 else 0.0, "write_bytes": pyr_bytes,
             "launches": len(vol_ms), "avg_launch_us": round(vol_avg_ms * 1e3, 1)}
         # all convolutions of one extra (untimed) step, each launch bracketed by HIP events: where 80 % of the step goes
         ops.profile_begin("conv")

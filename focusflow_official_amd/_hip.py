@@ -45,6 +45,12 @@ _SIGS = {
     "ff_prep_input": [_fp, C.c_int, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_corr_pyramid": [_fp, _fp, _fp, _fp, _ll, C.c_int, C.c_int, _fp],
     "ff_corr_lookup_fwd": [C.POINTER(_fp), C.c_int, C.c_int, _fp, _ll, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp],
+    "ff_corr_build": [_fp, _fp, C.POINTER(_fp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_corr_retile": [_fp, _fp, _ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_corr_tile_rows": [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_corr_lookup_tiled_fwd": [C.POINTER(_fp), C.c_int, _fp, _ll, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp],
+    "ff_corr_lookup_tiled_bwd": [C.POINTER(_fp), _fp, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
+    "ff_corr_pyramid_tiled_bwd": [_fp, _fp, _fp, _fp, _ll, C.c_int, C.c_int, _fp],
     "ff_act_copy": [_fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
     "ff_coords_init": [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_coords_step": [_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
@@ -60,8 +66,6 @@ _SIGS = {
     "ff_dilate2": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_norm_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp, _fp,
                     C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
-    "ff_corr_lookup_bwd": [C.POINTER(_fp), _fp, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
-    "ff_corr_pyramid_bwd": [_fp, _fp, _fp, _fp, _ll, C.c_int, C.c_int, _fp],
     "ff_gru_rh_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
     "ff_gru_blend_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
                          _fp, C.c_int, _ll, C.c_int, _fp],
@@ -94,7 +98,7 @@ _SIGS = {
     "ff_scale_add_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int,
                          C.c_int, _fp],
 }
-EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version"])
+EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems"])
 
 _lib = None
 
@@ -121,6 +125,8 @@ def load():
     lib.ff_last_error.argtypes = []
     lib.ff_abi_version.restype = C.c_int
     lib.ff_abi_version.argtypes = []
+    lib.ff_corr_plane_elems.restype = C.c_int
+    lib.ff_corr_plane_elems.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = lib
     return lib
 

@@ -225,145 +225,6 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormBwdArgs a
 }
 
 // ---------------------------------------------------------------------------
-// Lookup backward: dlevel[l][q][y][x] += dout[q][k] * bilinear weight.
-// One wave per query: the 324 output gradients are scattered into an LDS copy of
-// the four 11x16 windows (ds_add_f32), which is then added to the gradient planes
-// with plain read-modify-write — race free, because inside one launch every
-// (query, plane element) belongs to exactly one lane; launches of successive
-// iterations are ordered by the stream.
-// ---------------------------------------------------------------------------
-struct LookupBwdArgs {
-    float* dlvl[4];
-    const float* coords;
-    const float* dout;
-    long long queries;
-    int h0, w0, dout_ld;
-};
-
-__device__ __forceinline__ void tap_1d_b(float c, float inv_scale, int off, int n, int& i0, float& w1) {
-    const float cl = __fmul_rn(c, inv_scale);
-    const float x = __fadd_rn(cl, (float)off);
-    const float nm1 = (float)(n - 1);
-    const float g = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, x), nm1), 1.f);
-    const float u = __fmul_rn(__fmul_rn(__fadd_rn(g, 1.f), 0.5f), nm1);
-    const float f = floorf(u);
-    i0 = (int)f;
-    w1 = __fsub_rn(u, f);
-}
-
-constexpr int BW_ROWS = 11, BW_COLS = 12, BW_N = BW_ROWS * BW_COLS;
-
-__global__ __launch_bounds__(64) void lookup_bwd_kernel(const LookupBwdArgs a) {
-    __shared__ float win[4 * BW_N];
-    __shared__ int tab_i[4][2][9];
-    __shared__ float tab_w[4][2][9];
-    __shared__ int org[4][2];
-    const int lane = threadIdx.x;
-    const int t_lv = min(lane / 9, 3), t_o = lane - (lane / 9) * 9;
-    const float t_inv = 1.f / (float)(1 << t_lv);
-    const int t_h = a.h0 >> t_lv, t_w = a.w0 >> t_lv;
-    for (long long q = blockIdx.x; q < a.queries; q += gridDim.x) {
-        int x0, y0;
-        float wx, wy;
-        tap_1d_b(a.coords[q * 2], t_inv, t_o - 4, t_w, x0, wx);
-        tap_1d_b(a.coords[q * 2 + 1], t_inv, t_o - 4, t_h, y0, wy);
-        const int ox = __shfl(x0, t_lv * 9), oy = __shfl(y0, t_lv * 9);
-        if (lane < 36) {
-            tab_i[t_lv][0][t_o] = min(x0 - ox, BW_COLS - 2);
-            tab_i[t_lv][1][t_o] = min(y0 - oy, BW_ROWS - 2);
-            tab_w[t_lv][0][t_o] = wx;
-            tab_w[t_lv][1][t_o] = wy;
-            if (t_o == 0) {
-                org[t_lv][0] = x0;
-                org[t_lv][1] = y0;
-            }
-        }
-        for (int e = lane; e < 4 * BW_N; e += 64) win[e] = 0.f;
-        __syncthreads();
-        const float* drow = a.dout + q * a.dout_ld;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int k = lane + 64 * j;
-            if (k < 324) {
-                const int lv = k / 81, rem = k - lv * 81;
-                const int ia = rem / 9, ib = rem - ia * 9;
-                const int xi = tab_i[lv][0][ia], yi = tab_i[lv][1][ib];
-                const float fx = tab_w[lv][0][ia], fy = tab_w[lv][1][ib];
-                const float g = drow[k];
-                const float ex = 1.f - fx, sy = 1.f - fy;
-                float* p = &win[lv * BW_N + yi * BW_COLS + xi];
-                atomicAdd(p, g * (sy * ex));
-                atomicAdd(p + 1, g * (sy * fx));
-                atomicAdd(p + BW_COLS, g * (fy * ex));
-                atomicAdd(p + BW_COLS + 1, g * (fy * fx));
-            }
-        }
-        __syncthreads();
-        // read-modify-write of the query's own planes: all twelve loads first (unconditional, lanes with nothing to
-        // add read element 0), then the stores - inside `if (...) pl[i] += v` every element was a dependent round trip
-        constexpr int NE = (BW_N + 63) / 64;
-        float cur[4][NE], add[4][NE];
-        int idx[4][NE];
-#pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-            const int hl = a.h0 >> lv, wl = a.w0 >> lv;
-            const float* pl = a.dlvl[lv] + q * (long long)(hl * wl);
-            const int gx0 = org[lv][0], gy0 = org[lv][1];
-#pragma unroll
-            for (int t = 0; t < NE; ++t) {
-                const int e = min(lane + 64 * t, BW_N - 1);
-                const int r = e / BW_COLS, c = e - r * BW_COLS;
-                const int gy = gy0 + r, gx = gx0 + c;
-                const float v = win[lv * BW_N + e];
-                const bool ok = lane + 64 * t < BW_N && v != 0.f && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl;
-                idx[lv][t] = ok ? gy * wl + gx : -1;
-                add[lv][t] = v;
-                cur[lv][t] = pl[ok ? gy * wl + gx : 0];
-            }
-        }
-#pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-            float* pl = a.dlvl[lv] + q * (long long)((a.h0 >> lv) * (a.w0 >> lv));
-#pragma unroll
-            for (int t = 0; t < NE; ++t)
-                if (idx[lv][t] >= 0) pl[idx[lv][t]] = cur[lv][t] + add[lv][t];
-        }
-        __syncthreads();
-    }
-}
-
-// pooling backward chain: dl2 += up(dl3)/4 ; dl1 += up(dl2)/4 ; dl0 += up(dl1)/4  (in place)
-__global__ __launch_bounds__(256) void pyramid_bwd_kernel(float* __restrict__ d0, float* __restrict__ d1,
-                                                          float* __restrict__ d2, const float* __restrict__ d3, int h0,
-                                                          int w0) {
-    extern __shared__ float sm[];
-    const int h1 = h0 >> 1, w1 = w0 >> 1, h2 = h1 >> 1, w2 = w1 >> 1, h3 = h2 >> 1, w3 = w2 >> 1;
-    float* s2 = sm;               // h2*w2
-    float* s1 = sm + h2 * w2;     // h1*w1
-    const long long plane = blockIdx.x;
-    for (int i = threadIdx.x; i < h2 * w2; i += 256) {
-        const int y = i / w2, x = i - y * w2;
-        float v = d2[plane * h2 * w2 + i];
-        if ((y >> 1) < h3 && (x >> 1) < w3) v += 0.25f * d3[plane * h3 * w3 + (y >> 1) * w3 + (x >> 1)];
-        s2[i] = v;
-        d2[plane * h2 * w2 + i] = v;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < h1 * w1; i += 256) {
-        const int y = i / w1, x = i - y * w1;
-        float v = d1[plane * h1 * w1 + i];
-        if ((y >> 1) < h2 && (x >> 1) < w2) v += 0.25f * s2[(y >> 1) * w2 + (x >> 1)];
-        s1[i] = v;
-        d1[plane * h1 * w1 + i] = v;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < h0 * w0; i += 256) {
-        const int y = i / w0, x = i - y * w0;
-        if ((y >> 1) < h1 && (x >> 1) < w1) d0[plane * h0 * w0 + i] += 0.25f * s1[(y >> 1) * w1 + (x >> 1)];
-    }
-}
-
-// ---------------------------------------------------------------------------
 __global__ void gru_rh_bwd_kernel(const float* __restrict__ drh, int drh_ld, const float* __restrict__ r, int r_ld,
                                   const float* __restrict__ h, int h_ld, float* __restrict__ dr, int dr_ld,
                                   float* __restrict__ dh, int dh_ld, long long npix, int C) {
@@ -522,31 +383,6 @@ extern "C" int ff_norm_bwd(const float* x, int x_ld, const float* dy, int dy_ld,
     if (gx > 1024) gx = 1024;
     norm_bwd_apply_kernel<<<dim3(gx, B), 256, 0, s>>>(a);
     return ff::check_launch("ff_norm_bwd");
-}
-
-extern "C" int ff_corr_lookup_bwd(float* const* dlevels, const float* coords, const float* dout, int dout_ld,
-                                  long long queries, int h0, int w0, void* stream) {
-    FF_REQUIRE(dlevels && coords && dout && queries > 0 && dout_ld >= 324, "ff_corr_lookup_bwd: bad argument");
-    FF_REQUIRE((h0 >> 3) >= 2 && (w0 >> 3) >= 2, "ff_corr_lookup_bwd: level 3 must be at least 2x2");
-    LookupBwdArgs a;
-    for (int i = 0; i < 4; ++i) {
-        FF_REQUIRE(dlevels[i] != nullptr, "ff_corr_lookup_bwd: level %d null", i);
-        a.dlvl[i] = dlevels[i];
-    }
-    a.coords = coords; a.dout = dout; a.queries = queries; a.h0 = h0; a.w0 = w0; a.dout_ld = dout_ld;
-    const long long blocks = queries < 256 * 32 ? queries : 256 * 32;
-    lookup_bwd_kernel<<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
-    return ff::check_launch("ff_corr_lookup_bwd");
-}
-
-extern "C" int ff_corr_pyramid_bwd(float* d0, float* d1, float* d2, const float* d3, long long planes, int h0, int w0,
-                                   void* stream) {
-    FF_REQUIRE(d0 && d1 && d2 && d3 && planes > 0 && planes < (1ll << 31) && h0 >= 8 && w0 >= 8, "ff_corr_pyramid_bwd: bad argument");
-    const int h1 = h0 / 2, w1 = w0 / 2, h2 = h1 / 2, w2 = w1 / 2;
-    const size_t lds = (size_t)(h1 * w1 + h2 * w2) * sizeof(float);
-    FF_REQUIRE(lds <= 64 * 1024, "ff_corr_pyramid_bwd: plane too large");
-    pyramid_bwd_kernel<<<(unsigned)planes, 256, lds, static_cast<hipStream_t>(stream)>>>(d0, d1, d2, d3, h0, w0);
-    return ff::check_launch("ff_corr_pyramid_bwd");
 }
 
 extern "C" int ff_gru_rh_bwd(const float* drh, int drh_ld, const float* r, int r_ld, const float* h, int h_ld, float* dr,

@@ -1,4 +1,6 @@
-// CorrBlock: correlation pyramid + radius-r bilinear window lookup.
+// CorrBlock on ROW-MAJOR planes: pooling pass + generic radius-r bilinear window lookup (one thread per output).
+// The product path is the tiled pyramid (corr_build.hip, corr_lookup_tiled.hip); these entry points serve the exact-fp32
+// and plain-f16 conv precisions (volume by ff_conv2d_fwd, then ff_corr_retile) and the layout-equivalence tests.
 //
 // The lookup replays, op for op in separately rounded fp32 (no FMA contraction),
 // the coordinate arithmetic of the reference: corr.py:41-43 (c = coord/2^i + d),
@@ -111,152 +113,6 @@ __global__ __launch_bounds__(256) void lookup_kernel(const LookupArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// Fast path (4 levels, radius 4): ONE WAVE PER QUERY, software-pipelined.
-//   taps    lanes 0..35 = (level, offset) replay the x- and y- tap chains once
-//           (72 chains per query instead of 648) and publish floor indices
-//           (relative to the staged window) + fractional weights in LDS.
-//   stage   the four source windows go to LDS as [11 rows][16 floats]: rows of
-//           planes whose width is a multiple of 4 are fetched as aligned
-//           16-byte loads (44 lanes x float4 per level), zero padding applied
-//           per load; other widths use dword loads.  11 rows/cols because the
-//           fp32 round trip can move a floor by one.
-//   blend   324 outputs = 4 LDS reads + blend each, stored as coalesced rows.
-// Pipeline: the window loads of query n+1 are issued into registers BEFORE the
-// blend of query n and land in LDS after it; its coords are prefetched one step
-// earlier still.  A block IS one wave, so barriers are wave-local.
-// ---------------------------------------------------------------------------
-constexpr int WROWS = 11, WCOLS = 16, NWIN = WROWS * WCOLS;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// ALLVEC: every level's width is a multiple of 4 (W/8 a multiple of 32): only the 16-byte staging path is compiled.
-// No load sits under a branch: out-of-range lanes read a valid dummy address and the zero padding is applied by a
-// select when the window goes to LDS.  (With the loads inside `if (in range)` the compiler serialised the four
-// levels' loads with s_waitcnt vmcnt(0) between them: four DRAM round trips per query instead of one.)
-template <bool ALLVEC>
-__global__ __launch_bounds__(64) void lookup_wave_kernel(const LookupArgs a) {
-    __shared__ __attribute__((aligned(16))) float win[4 * NWIN];
-    __shared__ int tab_i[2][4][2][9];
-    __shared__ float tab_w[2][4][2][9];
-    __shared__ int org[2][4][2];     // [buf][level][x base (aligned), y base]
-    const int lane = threadIdx.x;
-    const int h0 = a.h[0], w0 = a.w[0];
-
-    const int t_lv = min(lane / 9, 3), t_o = lane - (lane / 9) * 9;   // tap role
-    const float t_inv = 1.f / (float)(1 << t_lv);
-    const int t_h = h0 >> t_lv, t_w = w0 >> t_lv;
-    const bool t_vec = ALLVEC || (t_w & 3) == 0;
-    const int s_r = lane >> 2, s_g = lane & 3;                        // vector staging role (lane < 44)
-    const int d_r0 = lane / 11, d_c0 = lane - d_r0 * 11;              // dword staging role
-    const int d_r1 = (lane + 64) / 11, d_c1 = (lane + 64) - d_r1 * 11;
-
-    auto publish_taps = [&](long long q, float cx, float cy, int buf) {
-        int x0, y0;
-        float wx, wy;
-        tap_1d(cx, t_inv, t_o - 4, t_w, x0, wx);
-        tap_1d(cy, t_inv, t_o - 4, t_h, y0, wy);
-        const int fx0 = __shfl(x0, t_lv * 9), oy = __shfl(y0, t_lv * 9);   // taps of offset -4 = window origin
-        const int ox = t_vec ? (fx0 & ~3) : fx0;                          // aligned down for 16-byte loads
-        if (lane < 36) {
-            tab_i[buf][t_lv][0][t_o] = min(x0 - ox, WCOLS - 2);
-            tab_i[buf][t_lv][1][t_o] = min(y0 - oy, WROWS - 2);
-            tab_w[buf][t_lv][0][t_o] = wx;
-            tab_w[buf][t_lv][1][t_o] = wy;
-            if (t_o == 0) {
-                org[buf][t_lv][0] = ox;
-                org[buf][t_lv][1] = oy;
-            }
-            if (a.taps) {
-                int* t = a.taps + (q * 4 + t_lv) * 18;
-                t[t_o] = x0;
-                t[9 + t_o] = y0;
-            }
-        }
-    };
-
-    f32x4 rv[4];        // vector path: one float4 per level (lanes < 44)
-    float rd[4][2];     // dword path: two floats per level
-    unsigned okm = 0;   // bit lv (vector) / bits 4+2lv, 5+2lv (dword): the load was inside the plane
-    auto issue_loads = [&](long long q, int buf) {
-        okm = 0;
-#pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {   // compile-time level: plane pointer and sizes stay scalar
-            const int hl = h0 >> lv, wl = w0 >> lv;
-            const float* pl = a.lvl[lv] + q * (long long)(hl * wl);
-            const int gx0 = org[buf][lv][0], gy0 = org[buf][lv][1];
-            if (ALLVEC || (wl & 3) == 0) {
-                const int gy = gy0 + s_r, gx = gx0 + 4 * s_g;
-                const bool ok = lane < 44 && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl;
-                // lanes without a load of their own re-read a line of the window (clamped row / column): no extra traffic
-                const int gyc = min(max(gy0 + min(s_r, WROWS - 1), 0), hl - 1), gxc = min(max(gx, 0), wl - 4);
-                rv[lv] = *reinterpret_cast<const f32x4*>(pl + gyc * wl + gxc);
-                okm |= ok ? 1u << lv : 0u;
-            } else {
-                int gy = gy0 + d_r0, gx = gx0 + d_c0;
-                bool ok = (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl;
-                rd[lv][0] = pl[ok ? gy * wl + gx : 0];
-                okm |= ok ? 1u << (4 + 2 * lv) : 0u;
-                gy = gy0 + d_r1, gx = gx0 + d_c1;
-                ok = lane < 121 - 64 && (unsigned)gy < (unsigned)hl && (unsigned)gx < (unsigned)wl;
-                rd[lv][1] = pl[ok ? gy * wl + gx : 0];
-                okm |= ok ? 1u << (5 + 2 * lv) : 0u;
-            }
-        }
-    };
-    auto store_window = [&]() {
-#pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-            if (ALLVEC || ((w0 >> lv) & 3) == 0) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                if (lane < 44) *reinterpret_cast<f32x4*>(&win[lv * NWIN + s_r * WCOLS + 4 * s_g]) = (okm >> lv & 1u) ? rv[lv] : z;
-            } else {
-                win[lv * NWIN + d_r0 * WCOLS + d_c0] = (okm >> (4 + 2 * lv) & 1u) ? rd[lv][0] : 0.f;
-                if (lane < 121 - 64) win[lv * NWIN + d_r1 * WCOLS + d_c1] = (okm >> (5 + 2 * lv) & 1u) ? rd[lv][1] : 0.f;
-            }
-        }
-    };
-
-    long long q = blockIdx.x;
-    if (q >= a.queries) return;
-    int cur = 0;
-    publish_taps(q, a.coords[q * 2], a.coords[q * 2 + 1], 0);
-    __syncthreads();
-    issue_loads(q, 0);
-    for (;;) {
-        const long long qn = q + gridDim.x;
-        const bool has_next = qn < a.queries;
-        const long long qs = has_next ? qn : q;          // the last round re-stages its own query: nothing under a branch
-        const float cxn = a.coords[qs * 2], cyn = a.coords[qs * 2 + 1];
-        store_window();                                  // waits for this query's window loads
-        publish_taps(qs, cxn, cyn, cur ^ 1);
-        __syncthreads();                                 // win + both table sets visible
-        issue_loads(qs, cur ^ 1);                        // in flight during the blend below
-        float* orow = a.out + q * a.out_ld;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int k = lane + 64 * j;
-            if (k < 324) {
-                const int lv = k / 81, rem = k - lv * 81;
-                const int ia = rem / 9, ib = rem - ia * 9;
-                const int xi = tab_i[cur][lv][0][ia], yi = tab_i[cur][lv][1][ib];
-                const float fx = tab_w[cur][lv][0][ia], fy = tab_w[cur][lv][1][ib];
-                const float* p = &win[lv * NWIN + yi * WCOLS + xi];
-                const float v00 = p[0], v01 = p[1], v10 = p[WCOLS], v11 = p[WCOLS + 1];
-                const float ex = __fsub_rn(1.f, fx), sy = __fsub_rn(1.f, fy);
-                float o = __fmul_rn(v00, __fmul_rn(sy, ex));
-                o = __fadd_rn(o, __fmul_rn(v01, __fmul_rn(sy, fx)));
-                o = __fadd_rn(o, __fmul_rn(v10, __fmul_rn(fy, ex)));
-                o = __fadd_rn(o, __fmul_rn(v11, __fmul_rn(fy, fx)));
-                orow[k] = o;
-            }
-        }
-        if (!has_next) break;
-        __syncthreads();                                 // everyone done reading win before it is overwritten
-        q = qn;
-        cur ^= 1;
-    }
-}
-
 }  // namespace
 
 extern "C" int ff_corr_pyramid(const float* l0, float* l1, float* l2, float* l3, long long planes, int h0, int w0,
@@ -298,17 +154,6 @@ extern "C" int ff_corr_lookup_fwd(const float* const* levels, int num_levels, in
     a.out_ld = out_ld;
     a.radius = radius;
     a.num_levels = num_levels;
-    static const int variant = getenv("FF_LOOKUP_GENERIC") ? 0 : 1;   // A/B switch for profiling only
-    if (variant == 1 && num_levels == 4 && radius == 4) {
-        // one wave per block; 78 VGPRs = 6 waves per SIMD = 24 per CU resident: a grid of 256 x 24 runs as ONE round of
-        // waves (4 queries each at B = 8), 256 x 32 as one round plus a third of a second one
-        static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 24;
-        long long blocks = queries < 256ll * wpc ? queries : 256ll * wpc;
-        const bool allvec = ((a.w[0] | a.w[1] | a.w[2] | a.w[3]) & 3) == 0;
-        if (allvec) lookup_wave_kernel<true><<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
-        else lookup_wave_kernel<false><<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
-        return ff::check_launch("ff_corr_lookup_fwd");
-    }
     const long long total = queries * nk;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;

@@ -1,0 +1,444 @@
+// CorrBlock construction (corr.py:12-27, :52-60) as ONE kernel: the all-pairs volume
+//     corr[b][i][j] = <fmap1[b,i,:], fmap2[b,j,:]> / sqrt(C),   C = 256
+// on the f16 matrix pipe with fp16-split operands (3 MFMA terms per fp32-accurate product, ff_common.h), the three
+// avg_pool2d(2, 2) levels from the accumulators, and all four levels written ONCE in the tiled layout of
+// corr_layout.h, as fp32 or as fp16 (BASELINE configs[4]: fp16 correlation pyramid).
+//
+// Block = 128 positions of fmap2 (one 16 x 8 patch: closed under the three 2x2 poolings) x 128 queries, K = 256 in
+// eight 32-channel chunks.  Both operands arrive pre-split (ff_pack_split_f16: one 128-byte row piece per chunk =
+// [x0: 32 halfs | x1: 32 halfs]), so a chunk goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) with no VALU and
+// no staging registers; the 16-byte slots of a row are XOR-swizzled on the SOURCE side (slot ^ ((row >> 1) & 7)) so the
+// ds_read_b128 fragment reads are conflict-free.  Two LDS stages (64 KB): two blocks per CU, one's epilogue beside the
+// other's MFMAs.
+//
+// The matrix rows are the fmap2 positions in tile order (row = yy * 8 + xx inside an 8 x 4 tile), the columns are the
+// queries: a lane then holds, for ITS query, a 4 x 4 spatial block per 32 x 32 accumulator tile (register r -> yy = r >> 2,
+// xx = 4 * (lane >> 5) + (r & 3)), so levels 1 and 2 are plain in-lane adds (ATen's order: ((a + b) + c) + d, then / 4),
+// level 3 needs one exchange between the two half-waves.  Everything is transposed through LDS on the way out so that
+// every global store instruction writes whole 128-byte lines (16 bytes per lane).
+#include "ff_common.h"
+#include "corr_layout.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct BuildArgs {
+    const char* f1s;        // split rows of fmap1 [B*Q][1024 B]
+    const char* f2s;        // split rows of fmap2
+    char* lvl[4];
+    long long plane_bytes[4];
+    int ntx[4], h[4], w[4];
+    int Q, B, npx, npy, mtiles;
+    float scale;            // 1/sqrt(C) / (WSPLIT * WSPLIT)
+};
+
+constexpr int STAGE = 32768;     // J tile 16 KB | I tile 16 KB
+constexpr int NCHUNK = 8;        // C = 256 in chunks of 32 channels
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool HALF>
+__global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // blocks that share an XCD (blockIdx % 8) take a contiguous run of (batch, query tile, patch): the 128 KB query tile
+    // and the sample's fmap2 (3 MB at 48x64) stay in that XCD's L2
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, x = bid & 7;
+        bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (bid >> 3);
+    }
+    const int npatch = a.npx * a.npy;
+    const int patch = bid % npatch, rest = bid / npatch;
+    const int mt = rest % a.mtiles, b = rest / a.mtiles;
+    const int px = patch % a.npx, py = patch / a.npx;
+    const int m0 = mt * 128;
+    const int h0 = a.h[0], w0 = a.w[0];
+    const char* fJ = a.f2s + (size_t)b * a.Q * 1024;
+    const char* fI = a.f1s + (size_t)b * a.Q * 1024;
+
+    // LDS-DMA roles: 32 pieces of 1 KB (8 rows x 128 B) per chunk, 8 per wave; lane -> row (lane >> 3), slot (lane & 7)
+    unsigned off[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int row = (wave + 4 * (g & 3)) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((row >> 1) & 7);
+        if (g < 4) {   // J: fmap2 position of tile-ordered row (t, yy, xx); out-of-plane positions re-read an edge row
+            const int t = row >> 5, yy = (row >> 3) & 3, xx = row & 7;
+            const int gy = min(8 * py + 4 * (t >> 1) + yy, h0 - 1), gx = min(16 * px + 8 * (t & 1) + xx, w0 - 1);
+            off[g] = (unsigned)(gy * w0 + gx) * 1024u + slot * 16;
+        } else {
+            off[g] = (unsigned)min(m0 + row, a.Q - 1) * 1024u + slot * 16;
+        }
+    }
+    auto issue = [&](int c, int buf) {
+        char* dst = sm + buf * STAGE;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const char* src = (g < 4 ? fJ : fI) + off[g] + c * 128;
+            char* d = dst + (g < 4 ? 0 : 16384) + (wave + 4 * (g & 3)) * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)d, 16, 0, 0);
+        }
+    };
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int sw = (li >> 1) & 7;
+    int so[2][2];     // byte offset of the 16-byte slot of (term, k-slice) in this lane's row
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) so[t][s] = ((t * 4 + s * 2 + lh) ^ sw) * 16;
+    const char* jrow = sm + li * 128;
+    const char* irow = sm + 16384 + (wave * 32 + li) * 128;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    issue(0, 0);
+    for (int c = 0; c < NCHUNK; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // chunk c landed for every wave; everybody is done with the other stage
+        if (c + 1 < NCHUNK) issue(c + 1, (c + 1) & 1);
+        const int bo = (c & 1) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f16x8 i0 = *reinterpret_cast<const f16x8*>(irow + bo + so[0][s]);
+            const f16x8 i1 = *reinterpret_cast<const f16x8*>(irow + bo + so[1][s]);
+            f16x8 j0[4], j1[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                j0[t] = *reinterpret_cast<const f16x8*>(jrow + bo + t * 4096 + so[0][s]);
+                j1[t] = *reinterpret_cast<const f16x8*>(jrow + bo + t * 4096 + so[1][s]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(j0[t], i0, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(j0[t], i1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(j1[t], i0, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();      // operands are dead: each wave now owns 16 KB of LDS for its 32 queries
+
+    // ---- epilogue.  acc[t][r]: query = m0 + wave*32 + li ; position in tile t = (ty, tx): yy = r >> 2, xx = 4*lh + (r & 3)
+    char* wreg = sm + wave * 16384;
+    const int qbase = m0 + wave * 32;
+    const size_t plane0 = (size_t)b * a.Q;
+    const float scale = a.scale;
+    float p2[4];
+    // ---- level 0 (and, in registers, levels 1 and 2)
+    //  fp32 image: [32 queries][4 tiles][8 slots of 16 B], slot ^= (query & 7) ; fp16 image: [32][2 tiles (tx)][8 rows][2 x 8 B]
+    float p1[4][2][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ty = t >> 1, tx = t & 1;
+        const int gx0 = 16 * px + 8 * tx + 4 * lh;
+        float v[4][4];
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy) {
+            const bool yok = 8 * py + 4 * ty + yy < h0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = (yok && gx0 + e < w0) ? acc[t][yy * 4 + e] * scale : 0.f;
+                if (HALF) x = (float)(_Float16)x;
+                v[yy][e] = x;
+            }
+            if (HALF) {
+                f16x4 hv = {(_Float16)v[yy][0], (_Float16)v[yy][1], (_Float16)v[yy][2], (_Float16)v[yy][3]};
+                const int slot = tx * 8 + 4 * ty + yy;
+                *reinterpret_cast<f16x4*>(wreg + li * 256 + ((slot ^ (li & 7)) * 16) + lh * 8) = hv;
+            } else {
+                f32x4 fv = {v[yy][0], v[yy][1], v[yy][2], v[yy][3]};
+                const int slot = t * 8 + yy * 2 + lh;
+                *reinterpret_cast<f32x4*>(wreg + li * 512 + ((slot ^ (li & 7)) * 16)) = fv;
+            }
+        }
+        // level 1: 2 x 2 values of this lane ; level 2: one.  ATen avg_pool2d: window summed row-major, then / 4.
+#pragma unroll
+        for (int y1 = 0; y1 < 2; ++y1)
+#pragma unroll
+            for (int x1 = 0; x1 < 2; ++x1) {
+                float s = ((v[2 * y1][2 * x1] + v[2 * y1][2 * x1 + 1]) + v[2 * y1 + 1][2 * x1]) + v[2 * y1 + 1][2 * x1 + 1];
+                s *= 0.25f;
+                const bool ok = 4 * py + 2 * ty + y1 < a.h[1] && 8 * px + 4 * tx + 2 * lh + x1 < a.w[1];
+                s = ok ? s : 0.f;
+                if (HALF) s = (float)(_Float16)s;
+                p1[t][y1][x1] = s;
+            }
+        {
+            float s = ((p1[t][0][0] + p1[t][0][1]) + p1[t][1][0]) + p1[t][1][1];
+            s *= 0.25f;
+            const bool ok = 2 * py + ty < a.h[2] && 4 * px + 2 * tx + lh < a.w[2];
+            s = ok ? s : 0.f;
+            if (HALF) s = (float)(_Float16)s;
+            p2[t] = s;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // level-0 read-back: every instruction stores whole 128-byte lines
+    if (HALF) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int p = it * 64 + lane, ql = p >> 4, slot = p & 15;      // 16 slots of 16 B per query: 2 tiles
+            const f32x4 d = *reinterpret_cast<const f32x4*>(wreg + ql * 256 + ((slot ^ (ql & 7)) * 16));
+            const int q = qbase + ql;
+            if (q < a.Q) {
+                char* dst = a.lvl[0] + (plane0 + q) * a.plane_bytes[0] + (size_t)((py * a.ntx[0] + 2 * px + (slot >> 3)) * 128 + (slot & 7) * 16);
+                *reinterpret_cast<f32x4*>(dst) = d;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int p = it * 64 + lane, ql = p >> 5, slot = p & 31;      // 32 slots per query: 4 tiles
+            const f32x4 d = *reinterpret_cast<const f32x4*>(wreg + ql * 512 + ((slot ^ (ql & 7)) * 16));
+            const int q = qbase + ql, t = slot >> 3;
+            if (q < a.Q) {
+                char* dst = a.lvl[0] + (plane0 + q) * a.plane_bytes[0] +
+                            (size_t)(((2 * py + (t >> 1)) * a.ntx[0] + 2 * px + (t & 1)) * 128 + (slot & 7) * 16);
+                *reinterpret_cast<f32x4*>(dst) = d;
+            }
+        }
+    }
+    // level 3: the two half-waves hold the left / right level-2 value of each tile
+    float p3[2];
+#pragma unroll
+    for (int tx = 0; tx < 2; ++tx) {
+        const float a0 = p2[tx], b0 = p2[2 + tx];
+        const float a1 = __shfl(a0, lane + 32), b1 = __shfl(b0, lane + 32);     // lh = 1 partner (only lanes < 32 use it)
+        float s = ((a0 + a1) + b0) + b1;
+        s *= 0.25f;
+        const bool ok = py < a.h[3] && 2 * px + tx < a.w[3];
+        s = ok ? s : 0.f;
+        if (HALF) s = (float)(_Float16)s;
+        p3[tx] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();       // the level-0 image has been read: reuse the region for the pooled levels
+    // images (per wave):  L1 at +0, L2 at +4096, L3 at +5120
+    char* im1 = wreg;
+    char* im2 = wreg + 4096;
+    char* im3 = wreg + 5120;
+    if (HALF) {
+        // L1: [32 q][16 words of 2 halfs], word ^= (q & 15) ; patch = 8 x 4 halfs = rows (4py & 7).. of tile (py >> 1, px)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int y1 = 0; y1 < 2; ++y1) {
+                const int word = (2 * (t >> 1) + y1) * 4 + 2 * (t & 1) + lh;
+                f16x2 hv = {(_Float16)p1[t][y1][0], (_Float16)p1[t][y1][1]};
+                *reinterpret_cast<f16x2*>(im1 + li * 64 + ((word ^ (li & 15)) * 4)) = hv;
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)      // L2: [32 q][8 halfs]: (ty, 2 tx + lh)
+            *reinterpret_cast<_Float16*>(im2 + li * 16 + ((t >> 1) * 4 + 2 * (t & 1) + lh) * 2) = (_Float16)p2[t];
+        if (lh == 0) {
+            f16x2 hv = {(_Float16)p3[0], (_Float16)p3[1]};
+            *reinterpret_cast<f16x2*>(im3 + li * 4) = hv;
+        }
+    } else {
+        // L1: [32 q][16 slots of 8 B], slot ^= (q & 15) ; the patch is exactly tile (py, px) of level 1
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int y1 = 0; y1 < 2; ++y1) {
+                const int s8 = (2 * (t >> 1) + y1) * 4 + 2 * (t & 1) + lh;
+                f32x2 fv = {p1[t][y1][0], p1[t][y1][1]};
+                *reinterpret_cast<f32x2*>(im1 + li * 128 + ((s8 ^ (li & 15)) * 8)) = fv;
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)      // L2: [32 q][8 floats]
+            *reinterpret_cast<float*>(im2 + li * 32 + ((t >> 1) * 4 + 2 * (t & 1) + lh) * 4) = p2[t];
+        if (lh == 0) {
+            f32x2 fv = {p3[0], p3[1]};
+            *reinterpret_cast<f32x2*>(im3 + li * 8) = fv;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (HALF) {
+        // level 1: 64 B per query = 4 pieces of 16 B (rows (4py & 7) + 0..3 of the 8 x 8 tile)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int p = it * 64 + lane, ql = p >> 2, piece = p & 3;
+            unsigned wds[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wds[e] = *reinterpret_cast<const unsigned*>(im1 + ql * 64 + (((piece * 4 + e) ^ (ql & 15)) * 4));
+            const int q = qbase + ql;
+            if (q < a.Q) {
+                char* dst = a.lvl[1] + (plane0 + q) * a.plane_bytes[1] +
+                            (size_t)(((py >> 1) * a.ntx[1] + px) * 128 + (((4 * py) & 7) + piece) * 16);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 d = {wds[0], wds[1], wds[2], wds[3]};
+                *reinterpret_cast<u32x4*>(dst) = d;
+            }
+        }
+        {   // level 2: 2 rows x 4 halfs (8 B each): lane -> (query, row)
+            const int ql = lane >> 1, row = lane & 1, q = qbase + ql;
+            const f32x2 d = *reinterpret_cast<const f32x2*>(im2 + ql * 16 + row * 8);
+            const int y2 = 2 * py + row, x2 = 4 * px;
+            if (q < a.Q)
+                *reinterpret_cast<f32x2*>(a.lvl[2] + (plane0 + q) * a.plane_bytes[2] +
+                                          (size_t)(((y2 >> 3) * a.ntx[2] + (x2 >> 3)) * 128 + (y2 & 7) * 16 + (x2 & 7) * 2)) = d;
+        }
+        if (lane < 32) {   // level 3: 2 halfs
+            const int q = qbase + lane;
+            const unsigned d = *reinterpret_cast<const unsigned*>(im3 + lane * 4);
+            const int y3 = py, x3 = 2 * px;
+            if (q < a.Q)
+                *reinterpret_cast<unsigned*>(a.lvl[3] + (plane0 + q) * a.plane_bytes[3] +
+                                             (size_t)(((y3 >> 3) * a.ntx[3] + (x3 >> 3)) * 128 + (y3 & 7) * 16 + (x3 & 7) * 2)) = d;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {   // level 1: one whole tile (128 B) per query
+            const int p = it * 64 + lane, ql = p >> 3, s16 = p & 7;
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(im1 + ql * 128 + (((2 * s16) ^ (ql & 15)) * 8));
+            const f32x2 hi = *reinterpret_cast<const f32x2*>(im1 + ql * 128 + (((2 * s16 + 1) ^ (ql & 15)) * 8));
+            const int q = qbase + ql;
+            if (q < a.Q) {
+                f32x4 d = {lo[0], lo[1], hi[0], hi[1]};
+                *reinterpret_cast<f32x4*>(a.lvl[1] + (plane0 + q) * a.plane_bytes[1] + (size_t)((py * a.ntx[1] + px) * 128 + s16 * 16)) = d;
+            }
+        }
+        {   // level 2: 2 rows x 4 floats
+            const int ql = lane >> 1, row = lane & 1, q = qbase + ql;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(im2 + ql * 32 + row * 16);
+            const int y2 = 2 * py + row, x2 = 4 * px;
+            if (q < a.Q)
+                *reinterpret_cast<f32x4*>(a.lvl[2] + (plane0 + q) * a.plane_bytes[2] +
+                                          (size_t)(((y2 >> 2) * a.ntx[2] + (x2 >> 3)) * 128 + (y2 & 3) * 32 + (x2 & 7) * 4)) = d;
+        }
+        if (lane < 32) {   // level 3: 2 floats
+            const int q = qbase + lane;
+            const f32x2 d = *reinterpret_cast<const f32x2*>(im3 + lane * 8);
+            const int y3 = py, x3 = 2 * px;
+            if (q < a.Q)
+                *reinterpret_cast<f32x2*>(a.lvl[3] + (plane0 + q) * a.plane_bytes[3] +
+                                          (size_t)(((y3 >> 2) * a.ntx[3] + (x3 >> 3)) * 128 + (y3 & 3) * 32 + (x3 & 7) * 4)) = d;
+        }
+    }
+}
+
+// ---- row-major fp32 planes <-> tiled planes (fp32 or fp16): layout conversion only -----------------------------
+template <bool HALF, bool TO_TILED>
+__global__ void retile_kernel(float* __restrict__ rm, void* __restrict__ tl, long long planes, int h, int w, int ntx,
+                              int plane_elems) {
+    constexpr int TH = HALF ? 8 : 4;
+    const long long total = planes * h * w;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pl = i / (h * w);
+        const int e = (int)(i - pl * (h * w)), y = e / w, x = e - y * w;
+        const long long o = pl * plane_elems + ff::tiled_offset<TH>(y, x, ntx);
+        if (TO_TILED) {
+            if (HALF) static_cast<_Float16*>(tl)[o] = (_Float16)rm[i];
+            else static_cast<float*>(tl)[o] = rm[i];
+        } else {
+            rm[i] = HALF ? (float)static_cast<const _Float16*>(tl)[o] : static_cast<const float*>(tl)[o];
+        }
+    }
+}
+
+// feature rows [B][Q][C] <-> rows in the tile order of level 0 [B][P][C] (P = plane elements; pad rows zero)
+template <bool TO_TILED>
+__global__ void tile_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int h, int w, int ntx,
+                                 int P, int C) {
+    const int cg = C >> 2;
+    const long long total = (long long)B * (TO_TILED ? P : h * w) * cg;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % cg);
+        const long long r = i / cg;
+        if (TO_TILED) {
+            const int p = (int)(r % P), b = (int)(r / P);
+            const int tile = p >> 5, yy = (p >> 3) & 3, xx = p & 7;
+            const int y = (tile / ntx) * 4 + yy, x = (tile % ntx) * 8 + xx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y < h && x < w) v = *reinterpret_cast<const f32x4*>(src + ((long long)b * h * w + y * w + x) * C + g * 4);
+            *reinterpret_cast<f32x4*>(dst + r * C + g * 4) = v;
+        } else {
+            const int e = (int)(r % (h * w)), b = (int)(r / (h * w));
+            const int y = e / w, x = e - y * w;
+            *reinterpret_cast<f32x4*>(dst + r * C + g * 4) =
+                *reinterpret_cast<const f32x4*>(src + ((long long)b * P + ff::tiled_offset<4>(y, x, ntx)) * C + g * 4);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ff_corr_plane_elems(int h0, int w0, int level, int half) {
+    if (h0 < 1 || w0 < 1 || level < 0 || level > 3) return -1;
+    return ff::corr_layout(h0, w0, half != 0).plane[level];
+}
+
+extern "C" int ff_corr_build(const void* f1_split, const void* f2_split, void* const* levels, int B, int h0, int w0, int C,
+                             int half, void* stream) {
+    FF_REQUIRE(f1_split && f2_split && levels, "ff_corr_build: null pointer");
+    FF_REQUIRE(C == 256, "ff_corr_build: C = %d (the kernel is built for 256 feature channels)", C);
+    FF_REQUIRE(B >= 1 && h0 >= 16 && w0 >= 16, "ff_corr_build: plane %dx%d too small (need >= 16x16: level 3 must be 2x2)", h0, w0);
+    FF_REQUIRE((long long)h0 * w0 * 1024 < (1ll << 32), "ff_corr_build: plane too large");
+    const ff::CorrLayout L = ff::corr_layout(h0, w0, half != 0);
+    BuildArgs a;
+    a.f1s = static_cast<const char*>(f1_split);
+    a.f2s = static_cast<const char*>(f2_split);
+    const int esz = half ? 2 : 4;
+    for (int l = 0; l < 4; ++l) {
+        FF_REQUIRE(levels[l] != nullptr && ff::aligned16(levels[l]), "ff_corr_build: level %d null or not 16-byte aligned", l);
+        a.lvl[l] = static_cast<char*>(levels[l]);
+        a.plane_bytes[l] = (long long)L.plane[l] * esz;
+        a.ntx[l] = L.ntx[l];
+        a.h[l] = L.h[l];
+        a.w[l] = L.w[l];
+    }
+    a.Q = h0 * w0;
+    a.B = B;
+    a.npx = L.npx;
+    a.npy = L.npy;
+    a.mtiles = (a.Q + 127) / 128;
+    a.scale = 1.f / sqrtf((float)C) / (ff::WSPLIT * ff::WSPLIT);
+    const long long nblk = (long long)B * a.mtiles * L.npx * L.npy;
+    FF_REQUIRE(nblk < (1ll << 31), "ff_corr_build: grid too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (half) corr_build_kernel<true><<<(unsigned)nblk, 256, 2 * STAGE, s>>>(a);
+    else corr_build_kernel<false><<<(unsigned)nblk, 256, 2 * STAGE, s>>>(a);
+    return ff::check_launch("ff_corr_build");
+}
+
+extern "C" int ff_corr_retile(float* rowmajor, void* tiled, long long planes, int h0, int w0, int level, int half,
+                              int to_tiled, void* stream) {
+    FF_REQUIRE(rowmajor && tiled && planes > 0 && level >= 0 && level < 4 && h0 >= 1 && w0 >= 1, "ff_corr_retile: bad argument");
+    const ff::CorrLayout L = ff::corr_layout(h0, w0, half != 0);
+    const int h = L.h[level], w = L.w[level];
+    FF_REQUIRE(h >= 1 && w >= 1, "ff_corr_retile: level %d is empty", level);
+    const long long total = planes * h * w;
+    const unsigned g = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (half && to_tiled) retile_kernel<true, true><<<g, 256, 0, s>>>(rowmajor, tiled, planes, h, w, L.ntx[level], L.plane[level]);
+    else if (half) retile_kernel<true, false><<<g, 256, 0, s>>>(rowmajor, tiled, planes, h, w, L.ntx[level], L.plane[level]);
+    else if (to_tiled) retile_kernel<false, true><<<g, 256, 0, s>>>(rowmajor, tiled, planes, h, w, L.ntx[level], L.plane[level]);
+    else retile_kernel<false, false><<<g, 256, 0, s>>>(rowmajor, tiled, planes, h, w, L.ntx[level], L.plane[level]);
+    return ff::check_launch("ff_corr_retile");
+}
+
+extern "C" int ff_corr_tile_rows(const float* src, float* dst, int B, int h0, int w0, int C, int to_tiled, void* stream) {
+    FF_REQUIRE(src && dst && B >= 1 && h0 >= 1 && w0 >= 1 && C >= 4 && (C & 3) == 0, "ff_corr_tile_rows: bad argument");
+    const ff::CorrLayout L = ff::corr_layout(h0, w0, false);
+    const long long total = (long long)B * (to_tiled ? L.plane[0] : h0 * w0) * (C >> 2);
+    const unsigned g = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (to_tiled) tile_rows_kernel<true><<<g, 256, 0, s>>>(src, dst, B, h0, w0, L.ntx[0], L.plane[0], C);
+    else tile_rows_kernel<false><<<g, 256, 0, s>>>(src, dst, B, h0, w0, L.ntx[0], L.plane[0], C);
+    return ff::check_launch("ff_corr_tile_rows");
+}

@@ -269,39 +269,32 @@ class UpsampleFn(torch.autograd.Function):
 
 
 # ---- CorrBlock -------------------------------------------------------------
-class CorrVolumeFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, f1, f2):
-        ctx.save_for_backward(f1, f2)
-        return ops.corr_volume(f1, f2)
+class CorrBuildFn(torch.autograd.Function):
+    """(fmap1, fmap2) -> token.  The tiled pyramid lives on `block` (block.pyr); lookups accumulate their gradients
+    into block.grad_pyr (tiled fp32 planes - no per-iteration volume-sized autograd buffers), and this node - which
+    autograd runs after every LookupFn because of the token edge - folds them down the pooling chain to d(volume) and
+    contracts that with the feature maps (BmmBackward of corr.py:58).  fp16 pyramid storage is a straight-through
+    rounding for the gradient, as a cast under autocast would be."""
 
     @staticmethod
-    def backward(ctx, dvol):
-        f1, f2 = ctx.saved_tensors
-        return ops.corr_volume_bwd(dvol, f1, f2)
-
-
-class PyramidFn(torch.autograd.Function):
-    """vol -> token.  The pooled levels live on `block`; lookups accumulate their gradients into
-    block.grad_levels (no per-iteration volume-sized autograd buffers), and this node — which autograd
-    runs after every LookupFn because of the token edge — folds them down to d(vol)."""
-
-    @staticmethod
-    def forward(ctx, vol, block, h, w):
-        block.corr_pyramid = ops.corr_pyramid(vol, h, w)
-        block.grad_levels = None
+    def forward(ctx, f1, f2, block, half):
+        block.pyr = ops.corr_build(f1, f2, half)
+        block.grad_pyr = None
         ctx.block = block
-        ctx.shape = vol.shape
-        return torch.zeros(1, device=vol.device)
+        ctx.save_for_backward(f1, f2)
+        return torch.zeros(1, device=f1.device)
 
     @staticmethod
     def backward(ctx, dtoken):
-        gl = ctx.block.grad_levels
-        if gl is None:
-            return torch.zeros(ctx.shape, device=dtoken.device), None, None, None
-        ops.corr_pyramid_bwd(gl)
-        ctx.block.grad_levels = None
-        return gl[0].view(ctx.shape), None, None, None
+        f1, f2 = ctx.saved_tensors
+        gp = ctx.block.grad_pyr
+        if gp is None:
+            return torch.zeros_like(f1), torch.zeros_like(f2), None, None
+        ops.corr_pyramid_tiled_bwd(gp)
+        ctx.block.grad_pyr = None
+        b, h, w, _ = f1.shape
+        df1, df2 = ops.corr_volume_bwd(gp.levels[0].view(b, h * w, -1), f1, f2, tiled=True)
+        return df1, df2, None, None
 
 
 class LookupFn(torch.autograd.Function):
@@ -309,15 +302,16 @@ class LookupFn(torch.autograd.Function):
     def forward(ctx, token, block, coords):
         ctx.block = block
         ctx.save_for_backward(coords)
-        return ops.corr_lookup(block.corr_pyramid, coords, block.radius)
+        return ops.corr_lookup_tiled(block.pyr, coords)
 
     @staticmethod
     def backward(ctx, dout):
         (coords,) = ctx.saved_tensors
         blk = ctx.block
-        if blk.grad_levels is None:
-            blk.grad_levels = [torch.zeros_like(lv) for lv in blk.corr_pyramid]
-        ops.corr_lookup_bwd(blk.grad_levels, coords, _dense(dout))
+        if blk.grad_pyr is None:
+            pyr = blk.pyr
+            blk.grad_pyr = ops.TiledPyramid.empty(pyr.levels[0].shape[0], pyr.h0, pyr.w0, False, dout.device, zero=True)
+        ops.corr_lookup_tiled_bwd(blk.grad_pyr, coords, _dense(dout))
         return torch.zeros(1, device=dout.device), None, None
 
 

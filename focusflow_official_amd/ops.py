@@ -185,6 +185,88 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     return out
 
 
+class TiledPyramid:
+    """The 4-level correlation pyramid in the tiled HBM layout of csrc/corr_layout.h.
+
+    levels[l]: (B*Q, plane_l) tensor, float32 or float16; a plane is a grid of 128-byte tiles (8 x 4 floats or
+    8 x 8 halfs) over the level's h_l x w_l values.  `rowmajor(l)` converts a level back to (B*Q, h_l, w_l) fp32
+    (tests / debugging only)."""
+
+    def __init__(self, levels: List[Tensor], h0: int, w0: int, half: bool):
+        self.levels, self.h0, self.w0, self.half = levels, h0, w0, half
+
+    @staticmethod
+    def plane_elems(h0: int, w0: int, level: int, half: bool) -> int:
+        n = _hip.load().ff_corr_plane_elems(h0, w0, level, int(half))
+        if n <= 0:
+            raise _hip.FocusFlowHipError(f"ff_corr_plane_elems({h0}, {w0}, {level}) failed")
+        return n
+
+    @classmethod
+    def empty(cls, planes: int, h0: int, w0: int, half: bool, device, zero: bool = False) -> "TiledPyramid":
+        dt = torch.float16 if half else torch.float32
+        mk = torch.zeros if zero else torch.empty
+        return cls([mk((planes, cls.plane_elems(h0, w0, l, half)), dtype=dt, device=device) for l in range(4)], h0, w0, half)
+
+    def ptrs(self):
+        return (C.c_void_p * 4)(*[lv.data_ptr() for lv in self.levels])
+
+    def rowmajor(self, level: int) -> Tensor:
+        n = self.levels[level].shape[0]
+        out = torch.empty((n, self.h0 >> level, self.w0 >> level), dtype=torch.float32, device=self.levels[level].device)
+        _hip.call("ff_corr_retile", _p(out), _p(self.levels[level]), n, self.h0, self.w0, level, int(self.half), 0, _stream())
+        return out
+
+    @classmethod
+    def from_rowmajor(cls, levels: List[Tensor], half: bool = False) -> "TiledPyramid":
+        """(B*Q, h_l, w_l) fp32 planes -> tiled storage (fp16: rounded to nearest even); pads are zero."""
+        n, h0, w0 = levels[0].shape
+        pyr = cls.empty(n, h0, w0, half, levels[0].device, zero=True)
+        for l, lv in enumerate(levels):
+            assert lv.shape == (n, h0 >> l, w0 >> l) and lv.is_contiguous() and lv.dtype == torch.float32
+            _hip.call("ff_corr_retile", _p(lv), _p(pyr.levels[l]), n, h0, w0, l, int(half), 1, _stream())
+        return pyr
+
+
+def corr_build(fmap1: Tensor, fmap2: Tensor, half: bool = False) -> TiledPyramid:
+    """CorrBlock.__init__ (corr.py:12-27, :52-60) in one launch: all-pairs volume / sqrt(C) on the f16 matrix pipe with
+    fp16-split operands, the three 2x2 average-pooling levels from the accumulators, everything written once in the
+    tiled layout (fp32, or fp16 storage = BASELINE configs[4]).  Other conv precisions (exact fp32 MFMA, plain f16) go
+    through the grouped-conv volume + pooling pass and are re-tiled."""
+    b, h, w, c = fmap1.shape
+    q = h * w
+    assert fmap1.is_contiguous() and fmap2.is_contiguous() and fmap2.shape == fmap1.shape
+    _require_gpu(fmap1)
+    if w_format() != _hip.W_F16X3 or c != 256:
+        return TiledPyramid.from_rowmajor(corr_pyramid(corr_volume(fmap1, fmap2), h, w), half)
+    esz = fmap1.element_size()
+    if fmap2.data_ptr() == fmap1.data_ptr() + b * q * c * esz and fmap1.untyped_storage().data_ptr() == fmap2.untyped_storage().data_ptr():
+        # both frames went through fnet as one batch: split them with one launch
+        both = torch.empty((2 * b * q, c * 4), dtype=torch.uint8, device=fmap1.device)
+        _hip.call("ff_pack_split_f16", _p(fmap1), _p(both), 2 * b * q, c, _stream())
+        f1s, f2s = both[:b * q], both[b * q:]
+    else:
+        f1s, f2s = pack_split(fmap1.view(b * q, c)), pack_split(fmap2.view(b * q, c))
+    pyr = TiledPyramid.empty(b * q, h, w, half, fmap1.device)
+    _timed_call("corr_volume", "ff_corr_build", _p(f1s), _p(f2s), pyr.ptrs(), b, h, w, c, int(half), _stream())
+    return pyr
+
+
+def corr_lookup_tiled(pyr: TiledPyramid, coords: Tensor, want_taps: bool = False, out: Optional[Tensor] = None):
+    """CorrBlock.__call__ (corr.py:29-50) on a TiledPyramid.  coords: (B, H, W, 2) [x, y].  Returns (B, H, W, 324)
+    (+ int32 taps (B*H*W, 4, 2, 9)).  `out`: a (B,H,W,324) view of a wider buffer."""
+    _require_gpu(coords)
+    b, h, w, _ = coords.shape
+    assert coords.is_contiguous() and pyr.levels[0].shape[0] == b * h * w
+    if out is None:
+        out = empty_nhwc(b, h, w, 324, coords)
+    assert out.shape == (b, h, w, 324)
+    taps = torch.empty((b * h * w, 4, 2, 9), dtype=torch.int32, device=coords.device) if want_taps else None
+    _timed_call("lookup", "ff_corr_lookup_tiled_fwd", pyr.ptrs(), int(pyr.half), _p(coords), b * h * w, pyr.h0, pyr.w0,
+                _p(out), _ld(out), _p(taps), _stream())
+    return (out, taps) if want_taps else out
+
+
 def corr_volume(fmap1: Tensor, fmap2: Tensor) -> Tensor:
     """corr.py:52-60: vol[b][i][j] = <f1[b,i,:], f2[b,j,:]> / sqrt(C) as a grouped 1x1 conv
     whose per-sample weights are fmap2.  Returns (B, Q, Q) planes [B*Q][H8][W8]."""
@@ -573,16 +655,27 @@ def norm_bwd(x, dy, y, fstats, per_sample, fixed_stats, eps, gamma, beta, relu, 
     return dx, dres, bstats
 
 
-def corr_lookup_bwd(dlevels: List[Tensor], coords: Tensor, dout: Tensor):
+def corr_lookup_tiled_bwd(dpyr: TiledPyramid, coords: Tensor, dout: Tensor):
+    """Scatter d(lookup output) into the tiled fp32 gradient planes (accumulates)."""
     b, h, w, _ = coords.shape
-    arr = (C.c_void_p * 4)(*[lv.data_ptr() for lv in dlevels])
-    h0, w0 = dlevels[0].shape[-2:]
-    _hip.call("ff_corr_lookup_bwd", arr, _p(coords), _p(dout), _ld(dout), b * h * w, h0, w0, _stream())
+    assert not dpyr.half
+    _hip.call("ff_corr_lookup_tiled_bwd", dpyr.ptrs(), _p(coords), _p(dout), _ld(dout), b * h * w, dpyr.h0, dpyr.w0, _stream())
 
 
-def corr_pyramid_bwd(dlevels: List[Tensor]):
-    n, h0, w0 = dlevels[0].shape
-    _hip.call("ff_corr_pyramid_bwd", _p(dlevels[0]), _p(dlevels[1]), _p(dlevels[2]), _p(dlevels[3]), n, h0, w0, _stream())
+def corr_pyramid_tiled_bwd(dpyr: TiledPyramid):
+    """avg_pool2d backward chain, in place: afterwards dpyr.levels[0] is d(volume) in tile order."""
+    lv = dpyr.levels
+    _hip.call("ff_corr_pyramid_tiled_bwd", _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), lv[0].shape[0], dpyr.h0, dpyr.w0, _stream())
+
+
+def corr_tile_rows(x: Tensor, h: int, w: int, to_tiled: bool) -> Tensor:
+    """(B, Q, C) feature rows <-> (B, P, C) rows in the tile order of a level-0 plane (pad rows zero)."""
+    b, n, c = x.shape
+    p = TiledPyramid.plane_elems(h, w, 0, False)
+    assert x.is_contiguous() and n == (h * w if to_tiled else p)
+    out = torch.empty((b, p if to_tiled else h * w, c), dtype=torch.float32, device=x.device)
+    _hip.call("ff_corr_tile_rows", _p(x), _p(out), b, h, w, c, int(to_tiled), _stream())
+    return out
 
 
 def grouped_1x1(x: Tensor, wt: Tensor, out_scale: float) -> Tensor:
@@ -603,28 +696,40 @@ def grouped_1x1(x: Tensor, wt: Tensor, out_scale: float) -> Tensor:
     return y
 
 
-def corr_volume_bwd(dvol: Tensor, f1: Tensor, f2: Tensor):
-    """BmmBackward of corr.py:58: df1 = dvol @ f2 / sqrt(C), df2 = dvol^T @ f1 / sqrt(C)."""
+def corr_volume_bwd(dvol: Tensor, f1: Tensor, f2: Tensor, tiled: bool = False):
+    """BmmBackward of corr.py:58: df1 = dvol @ f2 / sqrt(C), df2 = dvol^T @ f1 / sqrt(C).
+    tiled: dvol is (B, Q, P) with the fmap2 index j in the tile order of a level-0 plane (pad columns zero): the
+    contraction over j runs over fmap2's rows gathered into the same order, and df2's rows are un-permuted at the end."""
     b, h, w, c = f1.shape
     q = h * w
     s = 1.0 / math.sqrt(c)
-    dvol = dvol.contiguous().view(b, q, q)
-    qp = (q + 3) // 4 * 4
-    if qp != q:      # odd plane sizes: the kernels read the contraction index in 16-byte groups -> zero-pad its rows
-        dvol = torch.nn.functional.pad(dvol, (0, qp - q))
+    if tiled:
+        qn = dvol.shape[-1]
+        dvol = dvol.contiguous().view(b, q, qn)
+        f2r = corr_tile_rows(f2.contiguous().view(b, q, c), h, w, True)        # (B, P, C), pad rows zero
+        qp = qn
+    else:
+        qn = q
+        dvol = dvol.contiguous().view(b, q, q)
+        qp = (q + 3) // 4 * 4
+        if qp != q:      # odd plane sizes: the kernels read the contraction index in 16-byte groups -> zero-pad its rows
+            dvol = torch.nn.functional.pad(dvol, (0, qp - q))
+        f2r = f2.contiguous().view(b, q, c)
     f2t = torch.zeros((b, c, qp), dtype=torch.float32, device=f1.device)      # [c][j] = f2[j][c]
     for i in range(b):
-        _hip.call("ff_pack_conv_weight_dgrad", _p(f2[i]), q, c, 1, 1, _p(f2t[i]), qp, 0, _stream())
+        _hip.call("ff_pack_conv_weight_dgrad", _p(f2r[i]), qn, c, 1, 1, _p(f2t[i]), qp, 0, _stream())
     df1 = grouped_1x1(dvol, f2t, s).view(b, h, w, c)
-    df2 = torch.zeros((b, q, c), dtype=torch.float32, device=f1.device)
+    df2 = torch.zeros((b, qn, c), dtype=torch.float32, device=f1.device)
     p = FFConvParams()
     p.x[0], p.x_ld[0], p.x_c[0], p.x_gstride[0] = f1.data_ptr(), c, c, q * c
     p.groups, p.B, p.H, p.W = b, 1, 1, q
-    p.Ho, p.Wo, p.Cout = 1, q, q
+    p.Ho, p.Wo, p.Cout = 1, q, qn
     p.KH = p.KW = p.stride = 1
     p.out_scale = s
     p.y, p.y_ld, p.y_gstride = dvol.data_ptr(), qp, q * qp
-    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(df2), q * c, None, _stream())
+    _hip.call("ff_conv2d_wgrad", C.byref(p), _p(df2), qn * c, None, _stream())
+    if tiled:
+        df2 = corr_tile_rows(df2, h, w, False)
     return df1, df2.view(b, h, w, c)
 
 

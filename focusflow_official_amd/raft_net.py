@@ -26,9 +26,16 @@ class RAFT(nn.Module):
         self.context_dim = cdim = 128
         self.corr_levels, self.corr_radius = 4, 4
         self.dropout = dropout
-        # ALT_CORR selects an on-the-fly correlation in the reference (extension not
-        # vendored there); here the flag is accepted and the materialised pyramid is used.
+        # ALT_CORR selects an on-the-fly correlation in the reference (its alt_cuda_corr extension is not vendored
+        # there, corr.py:5-9); here the materialised pyramid is always used - say so, the caller may have set the flag to
+        # bound memory (B * Q^2 * 5.3 bytes in fp32, half that with corr_pyramid_dtype = "fp16")
         self.alternate_corr = alternate_corr
+        if alternate_corr:
+            import warnings
+            warnings.warn("alternate_corr=True: the HIP path has no on-the-fly correlation; the materialised all-pairs "
+                          "pyramid is used (O((H*W/64)^2) memory per pair; corr_pyramid_dtype='fp16' halves it)")
+        # storage type of the correlation pyramid: None = $FF_CORR_PYRAMID or "fp32"; "fp16" = BASELINE configs[4]
+        self.corr_pyramid_dtype = None
         mc = cfg.TRAIN.MASK_CHANNEL
         self.fnet = BasicParallelFusionLayer(3, mc, output_dim=256, norm_fn="instance", dropout=dropout, cfg=cfg)
         self.cnet = BasicParallelFusionLayer(3, mc, output_dim=hdim + cdim, norm_fn="batch", dropout=dropout, cfg=cfg)
@@ -80,7 +87,7 @@ class RAFT(nn.Module):
         f12 = self.fnet(torch.cat([image1, image2], 0), torch.cat([mask1, mask2], 0))
         fmap1, fmap2 = f12[:b], f12[b:]
         self.fmap = fmap1
-        corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius)
+        corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
         cnet = self.cnet(image1, mask1)
         taped = fn.recording(cnet)
         if taped:

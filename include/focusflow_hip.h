@@ -142,7 +142,8 @@ int ff_prep_input(const float* src_nchw, int src_c, float fill_value, float* dst
                   int B, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------
- * CorrBlock (corr.py:12-60).  The volume itself is ff_conv2d_fwd with
+ * CorrBlock (corr.py:12-60), row-major planes (any radius / level count; the exact-fp32 and plain-f16 conv precisions
+ * and the tests use it - the product path is the tiled set below).  The volume itself is ff_conv2d_fwd with
  * groups = B (fmap2 as per-sample 1x1 weights, out_scale = 1/sqrt(C)).
  *   ff_corr_pyramid    : levels 1..3 by 2x2 average pooling (corr.py:24-27),
  *                        planes are [B*Q][h_l][w_l] row-major, floor on odd sizes.
@@ -158,6 +159,40 @@ int ff_corr_lookup_fwd(const float* const* levels /* HOST array of 4 device ptrs
                        int num_levels, int radius, const float* coords /* [B*Q][2] x,y */,
                        long long queries, int h0, int w0, float* out, int out_ld,
                        int* taps_dbg, void* stream);
+
+/* ------------------------------------------------------------------------
+ * CorrBlock on a TILED pyramid - the product path (corr.py:12-60, utils.py:57-71).
+ * Level l of query i (h_l x w_l values, h_l = h0 >> l) is a grid of 128-byte 2-D tiles:
+ *     fp32 storage: tile = 8 wide x 4 high floats ; fp16 storage: tile = 8 wide x 8 high halfs ;
+ *     element (y, x) at ((y / TH) * ntx + x / 8) * (8 * TH) + (y % TH) * 8 + (x % 8),
+ *     ntx = ceil((ceil16(w0) >> l) / 8), nty = ceil((ceil8(h0) >> l) / TH); pad elements are undefined.
+ *   ff_corr_plane_elems       elements per plane of `level` (the only non-status return value besides ff_abi_version)
+ *   ff_corr_build             CorrBlock.__init__ (corr.py:12-27) + CorrBlock.corr (:52-60) in ONE launch: volume
+ *                             <fmap1[i], fmap2[j]> / sqrt(C) on the f16 matrix pipe from operands pre-split by
+ *                             ff_pack_split_f16 ([B*Q][C] fp32 rows -> [B*Q][4 C bytes]), the three avg_pool2d(2,2) levels
+ *                             (ATen's summation order) from the accumulators, all four levels stored once.  half != 0:
+ *                             every level is rounded to fp16 (RNE) and the next one is pooled from the ROUNDED values
+ *                             in fp32, as torch autocast does.  C must be 256; levels = HOST array of 4 device pointers.
+ *   ff_corr_retile            layout conversion of one level: row-major fp32 planes <-> tiled (fp32 / fp16) planes
+ *   ff_corr_tile_rows         feature rows [B][Q][C] <-> rows in the tile order of a level-0 fp32 plane [B][P][C]
+ *   ff_corr_lookup_tiled_fwd  CorrBlock.__call__ (corr.py:29-50), 4 levels, radius 4: out NHWC [B*Q][out_ld], channel
+ *                             k = level*81 + a*9 + b with a = x-offset index; taps_dbg as in ff_corr_lookup_fwd
+ *   ff_corr_lookup_tiled_bwd  d(out) scattered into tiled fp32 gradient planes (accumulates; pads stay zero)
+ *   ff_corr_pyramid_tiled_bwd pooling backward chain in place on tiled fp32 planes; afterwards d0 = d(volume)
+ * ---------------------------------------------------------------------- */
+int ff_corr_plane_elems(int h0, int w0, int level, int half);
+int ff_corr_build(const void* fmap1_split, const void* fmap2_split, void* const* levels /* HOST array */,
+                  int B, int h0, int w0, int C, int half, void* stream);
+int ff_corr_retile(float* rowmajor, void* tiled, long long planes, int h0, int w0, int level, int half,
+                   int to_tiled, void* stream);
+int ff_corr_tile_rows(const float* src, float* dst, int B, int h0, int w0, int C, int to_tiled, void* stream);
+int ff_corr_lookup_tiled_fwd(const void* const* levels /* HOST array of 4 device ptrs */, int half,
+                             const float* coords /* [B*Q][2] x,y */, long long queries, int h0, int w0,
+                             float* out, int out_ld, int* taps_dbg, void* stream);
+int ff_corr_lookup_tiled_bwd(float* const* dlevels /* HOST array */, const float* coords, const float* dout,
+                             int dout_ld, long long queries, int h0, int w0, void* stream);
+int ff_corr_pyramid_tiled_bwd(float* d0, float* d1, float* d2, const float* d3, long long planes, int h0, int w0,
+                              void* stream);
 
 /* ------------------------------------------------------------------------
  * Update-block glue (raft.py:205-231, update.py:45-60).
@@ -217,13 +252,8 @@ int ff_norm_bwd(const float* x, int x_ld, const float* dy, int dy_ld, const floa
                 const double* fstats, double* bstats, int per_sample, int fixed_stats, float eps,
                 const float* gamma, const float* beta, int relu, float* dx, int dx_ld,
                 float* dres, int dres_ld, int B, int HW, int C, void* stream);
-/* GridSampler2DBackward (w.r.t. the pyramid only: coords are detached, raft.py:216):
- * dlevels[l] += scatter(dout); 4 levels, radius 4. */
-int ff_corr_lookup_bwd(float* const* dlevels /* HOST array of 4 device ptrs */, const float* coords,
-                       const float* dout, int dout_ld, long long queries, int h0, int w0, void* stream);
-/* AvgPool2DBackward chain, in place: d2 += up(d3)/4 ; d1 += up(d2)/4 ; d0 += up(d1)/4 */
-int ff_corr_pyramid_bwd(float* d0, float* d1, float* d2, const float* d3, long long planes,
-                        int h0, int w0, void* stream);
+/* GridSampler2DBackward (w.r.t. the pyramid only: coords are detached, raft.py:216) and the AvgPool2DBackward chain:
+ * ff_corr_lookup_tiled_bwd / ff_corr_pyramid_tiled_bwd above (gradient planes share the tiled fp32 layout). */
 int ff_gru_rh_bwd(const float* drh, int drh_ld, const float* r, int r_ld, const float* h, int h_ld,
                   float* dr, int dr_ld, float* dh, int dh_ld, long long npix, int C, void* stream);
 int ff_gru_blend_bwd(const float* dhn, int dhn_ld, const float* z, int z_ld, const float* q, int q_ld,

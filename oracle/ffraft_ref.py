@@ -135,13 +135,22 @@ def corr_volume(fmap1: Tensor, fmap2: Tensor) -> Tensor:
     return (vol / torch.sqrt(torch.tensor(c).float()).to(vol.dtype)).view(b, h * w, h, w)
 
 
-def corr_pyramid(vol: Tensor, num_levels=4) -> List[Tensor]:
-    """corr.py:21-27 → list of (B*Q, 1, h_l, w_l)."""
+def corr_pyramid(vol: Tensor, num_levels=4, half: bool = False) -> List[Tensor]:
+    """corr.py:21-27 → list of (B*Q, 1, h_l, w_l).
+
+    half=True is the fp16 correlation pyramid of BASELINE configs[4] (the storage torch autocast would give CorrBlock:
+    the matmul result and every avg_pool2d output are rounded to fp16, each pooling reads the ROUNDED level below and
+    sums in fp32; grid_sample is on autocast's fp32 list, so the lookup interpolates in fp32 on the fp16 values).
+    Returned as fp32 tensors that hold fp16-representable values."""
     b, q, h, w = vol.shape
     lvl = vol.reshape(b * q, 1, h, w)
+    if half:
+        lvl = lvl.half().float()
     out = [lvl]
     for _ in range(num_levels - 1):
         lvl = F.avg_pool2d(lvl, 2, stride=2)
+        if half:
+            lvl = lvl.half().float()
         out.append(lvl)
     return out
 
@@ -281,17 +290,18 @@ def prepare_inputs(image1, image2, mask1, mask2, mask_channel=3):
 
 def raft_forward(sd: Dict[str, Tensor], image1, image2, mask1, mask2, iters=12,
                  flow_init: Optional[Tensor] = None, test_mode=False, training=False,
-                 fusion_type="1x1conv", prefix="", taps: Optional[dict] = None):
+                 fusion_type="1x1conv", prefix="", taps: Optional[dict] = None, corr_half: bool = False):
     """raft.py:173-236 on already-normalised inputs.
 
     ``taps`` (optional dict) receives intermediates for per-op parity tests.
+    ``corr_half``: fp16 storage of the correlation pyramid (see corr_pyramid).
     """
     p = prefix
     fmap1 = cce_encoder(sd, p + "fnet", image1, mask1, "instance", training, fusion_type)
     fmap2 = cce_encoder(sd, p + "fnet", image2, mask2, "instance", training, fusion_type)
     if fmap1.dtype != torch.float64:  # raft.py:191-193; fp64 is kept for noise studies
         fmap1, fmap2 = fmap1.float(), fmap2.float()
-    pyramid = corr_pyramid(corr_volume(fmap1, fmap2))
+    pyramid = corr_pyramid(corr_volume(fmap1, fmap2), half=corr_half)
     cnet = cce_encoder(sd, p + "cnet", image1, mask1, "batch", training, fusion_type)
     net, inp = torch.split(cnet, [128, 128], dim=1)
     net, inp = torch.tanh(net), torch.relu(inp)
@@ -322,11 +332,11 @@ def raft_forward(sd: Dict[str, Tensor], image1, image2, mask1, mask2, iters=12,
 
 def ffraft_forward(sd, image1, image2, mask1, mask2=None, raft_iters=12, flow_init=None,
                    test_mode=False, training=False, mask_channel=3, fusion_type="1x1conv",
-                   taps=None):
+                   taps=None, corr_half=False):
     """ff_raft.py:134-160 for use_fusion='parallel'; keys carry 'flow_net.'."""
     i1, i2, m1, m2 = prepare_inputs(image1, image2, mask1, mask2, mask_channel)
     return raft_forward(sd, i1, i2, m1, m2, raft_iters, flow_init, test_mode, training,
-                        fusion_type, prefix="flow_net.", taps=taps)
+                        fusion_type, prefix="flow_net.", taps=taps, corr_half=corr_half)
 
 
 # ----------------------------------------------------------------------------
