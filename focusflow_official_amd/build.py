@@ -37,7 +37,13 @@ def build_hip(force=False, verbose=True):
         src = os.path.join(CSRC, name)
         obj = os.path.join(objdir, name[:-4] + ".o")
         if force or _newer([src] + hdrs, obj):
-            cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+            extra = []
+            with open(src) as f:
+                # files that replay the reference's separately rounded fp32 chains (sampler coordinates, bilinear blend)
+                # say so with a pragma; hipcc does not honour it inside templates / lambdas, so they also get the flag
+                if "#pragma clang fp contract(off)" in f.read():
+                    extra = ["-ffp-contract=off"]
+            cmd = [HIPCC, *FLAGS, *extra, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -1,8 +1,6 @@
 // Backward kernels of the FF-RAFT hot path other than the convolution GEMMs
-// (SURVEY §3.3): activation masks, Instance/BatchNorm backward, lookup backward
-// (bilinear scatter into the pyramid gradient), pooling backward, GRU gates,
-// convex-upsampling backward.  All HBM-bound.
-#pragma clang fp contract(off)
+// (SURVEY §3.3): activation masks, Instance/BatchNorm backward, GRU gates,
+// convex-upsampling backward.  All HBM-bound.  (Lookup / pooling backward: corr_lookup_tiled.hip.)
 #include "ff_common.h"
 
 namespace {

@@ -16,6 +16,7 @@
 // xx = 4 * (lane >> 5) + (r & 3)), so levels 1 and 2 are plain in-lane adds (ATen's order: ((a + b) + c) + d, then / 4),
 // level 3 needs one exchange between the two half-waves.  Everything is transposed through LDS on the way out so that
 // every global store instruction writes whole 128-byte lines (16 bytes per lane).
+#include <cstdlib>
 #include "ff_common.h"
 #include "corr_layout.h"
 
@@ -36,6 +37,8 @@ struct BuildArgs {
     int ntx[4], h[4], w[4];
     int Q, B, npx, npy, mtiles;
     float scale;            // 1/sqrt(C) / (WSPLIT * WSPLIT)
+    int ablate;             // timing experiments only (FF_CORR_BUILD_ABLATE): 1 = no epilogue, 2 = operands loaded once
+    int stagger;            // second resident block of every CU starts this many x 4 us late (see ff_corr_build)
 };
 
 constexpr int STAGE = 32768;     // J tile 16 KB | I tile 16 KB
@@ -105,11 +108,16 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // Two blocks share a CU and would otherwise move in lock-step (both in their MFMA loop, then both in their store
+    // epilogue).  The blocks of the second dispatch round (one per CU: ids 256..511) start late, which puts the two
+    // residents of a CU - and every pair of blocks that replaces them - in opposite phases.
+    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     issue(0, 0);
     for (int c = 0; c < NCHUNK; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // chunk c landed for every wave; everybody is done with the other stage
-        if (c + 1 < NCHUNK) issue(c + 1, (c + 1) & 1);
+        if (c + 1 < NCHUNK && !(a.ablate & 2)) issue(c + 1, (c + 1) & 1);
         const int bo = (c & 1) * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -130,6 +138,10 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
         }
     }
     __syncthreads();      // operands are dead: each wave now owns 16 KB of LDS for its 32 queries
+    if (a.ablate & 1) {   // timing only: keep the accumulators alive, store nothing
+        if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 12345.f) a.lvl[0][0] = 1;
+        return;
+    }
 
     // ---- epilogue.  acc[t][r]: query = m0 + wave*32 + li ; position in tile t = (ty, tx): yy = r >> 2, xx = 4*lh + (r & 3)
     char* wreg = sm + wave * 16384;
@@ -408,9 +420,24 @@ extern "C" int ff_corr_build(const void* f1_split, const void* f2_split, void* c
     a.npy = L.npy;
     a.mtiles = (a.Q + 127) / 128;
     a.scale = 1.f / sqrtf((float)C) / (ff::WSPLIT * ff::WSPLIT);
+    static const int ablate = getenv("FF_CORR_BUILD_ABLATE") ? atoi(getenv("FF_CORR_BUILD_ABLATE")) : 0;
+    a.ablate = ablate;
+    static const int stagger = getenv("FF_CORR_BUILD_STAGGER") ? atoi(getenv("FF_CORR_BUILD_STAGGER")) : 0;
+    a.stagger = stagger;
     const long long nblk = (long long)B * a.mtiles * L.npx * L.npy;
     FF_REQUIRE(nblk < (1ll << 31), "ff_corr_build: grid too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // The kernel writes every element its 16 x 8 patches cover (zeros beyond the plane).  Where the tile grid of a deeper
+    // level is larger than that cover (tile rounding), the remainder is cleared here, so that EVERY pad element of a
+    // tiled plane is zero - the lookup relies on it instead of masking elements.
+    const int th = half ? 8 : 4;
+    for (int l = 1; l < 4; ++l) {
+        const int wp = (L.npx * 16) >> l, hp = (L.npy * 8) >> l;
+        if (L.ntx[l] * 8 > wp || L.nty[l] * th > hp) {
+            hipError_t e = hipMemsetAsync(levels[l], 0, (size_t)B * a.Q * a.plane_bytes[l], s);
+            if (e != hipSuccess) return ff::fail(FF_EHIP, "ff_corr_build: memset: %s", hipGetErrorString(e));
+        }
+    }
     if (half) corr_build_kernel<true><<<(unsigned)nblk, 256, 2 * STAGE, s>>>(a);
     else corr_build_kernel<false><<<(unsigned)nblk, 256, 2 * STAGE, s>>>(a);
     return ff::check_launch("ff_corr_build");

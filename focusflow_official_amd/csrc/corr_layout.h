@@ -5,8 +5,9 @@
 //     fp32 storage: tile = 8 wide x 4 high floats        fp16 storage: tile = 8 wide x 8 high halfs
 //     element (y, x)  ->  ((y / TH) * ntx + (x / 8)) * (8 * TH) + (y % TH) * 8 + (x % 8)
 // The tile grid covers the plane padded to the build kernel's 16 x 8 patch of level-0 positions (wp0 = ceil16(w0),
-// hp0 = ceil8(h0), level l: wp0 >> l by hp0 >> l), rounded up to whole tiles.  Pad elements are NOT guaranteed to be
-// zero (some are never written): readers mask by coordinates.
+// hp0 = ceil8(h0), level l: wp0 >> l by hp0 >> l), rounded up to whole tiles.  Pad elements are ZERO by contract
+// (ff_corr_build clears what its patches do not cover; ff_corr_retile fills zero-initialised storage; the backward
+// kernels mask their updates), so the lookup needs no per-element masks.
 #pragma once
 
 namespace ff {

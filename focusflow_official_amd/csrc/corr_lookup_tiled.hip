@@ -5,10 +5,10 @@
 // Forward: ONE WAVE PER QUERY, software-pipelined as the row-major kernel was (taps -> window loads in flight during the
 // previous query's blend -> LDS -> blend), but a window is fetched as whole 128-byte tiles: the 11 x 11 values a level
 // needs lie in 2-3 x 3-4 tiles (fp32, 8 x 4) or 2-3 x 2-3 tiles (fp16, 8 x 8) instead of 11-15 row pieces of 128-byte
-// lines.  8 lanes fetch one tile (16 bytes each); the tile range is computed from the taps actually needed (offset -4 ..
+// lines.  4 lanes fetch one tile (32 bytes each); the tile range is computed from the taps actually needed (offset -4 ..
 // offset +4, +1), tiles outside the plane are zeros (grid_sample's zero padding), elements of an edge tile beyond the
-// plane are masked by coordinates (the pad of a tiled plane is not defined).  The coordinate arithmetic is the
-// separately rounded fp32 replay of corr.hip (tap indices bit-identical to the reference).
+// plane are zero in memory (the builders guarantee it).  The coordinate arithmetic is the separately rounded fp32 replay
+// of corr.hip (tap indices bit-identical to the reference).
 #pragma clang fp contract(off)
 #include <cstdlib>
 #include "ff_common.h"
@@ -42,28 +42,49 @@ __device__ __forceinline__ void tap_1d(float c, float inv_scale, int off, int n,
     w1 = __fsub_rn(u, f);
 }
 
-constexpr int LTILES = 12;                 // LDS image of one level: 4 tile rows x 3 tile columns of 128 B
-constexpr int LVL_BYTES = LTILES * 128;
+// LDS window of one level, row-major: fp32 16 rows x 32 columns at a 144-byte pitch, fp16 32 rows x 32 columns at an
+// 80-byte pitch.  The pitch is what keeps the blend's reads conflict-free: 32 lanes read a block of ~9 rows x 4 columns,
+// and with 36 (20) dwords per row consecutive rows start 4 banks apart (at the natural 32 / 16 dwords every row would start
+// on the same bank: a 9-way conflict that cost more than all the arithmetic of the kernel).
+constexpr int LVL_BYTES = 2560;
 
-// The window of one level as tile coordinates: first tile (tx0, ty0), ntc x ntr tiles.
-struct WinGeom {
-    int tx0, ty0, ntc, ntr;
+
+struct __attribute__((aligned(16))) TapEntry {
+    int off;        // byte offset of tap 0 in the level window (x: column part, y: level base + row part)
+    float w1, w0;   // fractional weight of tap 1 and 1 - w1 (ATen: separately rounded subtraction)
+    int pad;
 };
 
+// Instruction count is what bounds this kernel (one wave per query, ~24 queries per SIMD at B = 8), next to the number
+// of cache lines a load instruction touches (a version whose lanes each fetched a whole tile - 64 lines per
+// instruction - ran slower than one with twice the instructions).  So:
+//   taps     lanes 0..35 = (level, offset) replay the x- and y- tap chains and publish, per axis, ONE 16-byte table
+//            entry (window offset of tap 0, weight, 1 - weight); tap 1 is the next element of the row-major window.
+//   staging  a level's window is at most 3 x 4 (fp32) / 3 x 3 (fp16) tiles inside a fixed 4 x 4 slot grid anchored at
+//            the tile of tap (-4, -4).  Eight lanes fetch one tile (16 bytes each), one load instruction = 8 whole
+//            128-byte lines = two tile rows of one level, 8 instructions per query.  The level is fixed per instruction,
+//            so the window geometry sits in scalar registers.  Slots past the window re-read the window's edge tile (no
+//            extra traffic), tiles outside the plane's tile grid become zeros (grid_sample's zero padding).  Elements
+//            of an edge tile beyond the plane are zero in memory (ff_corr_build / ff_corr_retile guarantee it).  The
+//            tiles are written to LDS UN-tiled (row-major window), so the blend needs one address per output.
+//   blend    324 outputs = 2 table reads + 2 two-element LDS reads + 11 separately rounded fp32 ops each.
 template <bool HALF>
 __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
     constexpr int TSH = HALF ? 3 : 2;      // log2(tile height)
     constexpr int ESZ = HALF ? 2 : 4;
     constexpr int MAXR = HALF ? 3 : 4;     // tile rows a window can span
+    constexpr int PITCH = HALF ? 80 : 144; // window row pitch in bytes (4 tile columns x 8 elements + padding, see LVL_BYTES)
     __shared__ __attribute__((aligned(16))) char win[4 * LVL_BYTES];
-    __shared__ int tab_o[2][4][2][2][9];   // [buf][level][axis][tap 0/1][offset]: byte offset of the tap in the level image
-    __shared__ float tab_w[2][4][2][9];
-    __shared__ int geo[2][4][4];           // [buf][level]{tx0, ty0, ntc, ntr}
+    __shared__ TapEntry tab[2][2][4][9];   // [buf][axis][level][offset]
+    __shared__ __attribute__((aligned(16))) int geo[2][4][4];           // [buf][level]{tx0, ty0, ntc, ntr}
     const int lane = threadIdx.x;
     const int t_lv = min(lane / 9, 3), t_o = lane - (lane / 9) * 9;   // tap role (lanes < 36)
     const float t_inv = 1.f / (float)(1 << t_lv);
     const int t_h = a.h[0] >> t_lv, t_w = a.w[0] >> t_lv;
-    const int k8 = lane >> 3, piece = lane & 7;                       // staging role: tile k8 (+8), 16-byte piece
+    // staging role: 16-byte piece s_p of tile column s_tc, tile row s_trh (+ 2 for the odd instruction of a level)
+    const int s_p = lane & 7, s_tc = (lane >> 3) & 3, s_trh = lane >> 5;
+    // LDS position of the piece (row-major window): fp32 piece = tile row p >> 1, half p & 1 ; fp16 piece = tile row p
+    const int s_dst = (s_trh << TSH) * PITCH + s_tc * 8 * ESZ + (HALF ? s_p * PITCH : (s_p >> 1) * PITCH + (s_p & 1) * 16);
 
     auto publish_taps = [&](long long q, float cx, float cy, int buf) {
         int x0, y0;
@@ -73,22 +94,23 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
         const int xlo = __shfl(x0, t_lv * 9), ylo = __shfl(y0, t_lv * 9);            // taps of offset -4
         const int xhi = __shfl(x0, t_lv * 9 + 8) + 1, yhi = __shfl(y0, t_lv * 9 + 8) + 1;   // last tap read: offset +4, +1
         const int tx0 = xlo >> 3, ty0 = ylo >> TSH;
-        const int ntc = min(max((xhi >> 3) - tx0 + 1, 1), 3), ntr = min(max((yhi >> TSH) - ty0 + 1, 1), MAXR);
         if (lane < 36) {
-            // byte offset in the level image [tile row][3 tile columns][128 B]; clamped so a wild coordinate stays inside
-            const int tc0 = min(max((x0 >> 3) - tx0, 0), 2), tc1 = min(max(((x0 + 1) >> 3) - tx0, 0), 2);
-            const int tr0 = min(max((y0 >> TSH) - ty0, 0), MAXR - 1), tr1 = min(max(((y0 + 1) >> TSH) - ty0, 0), MAXR - 1);
-            tab_o[buf][t_lv][0][0][t_o] = tc0 * 128 + (x0 & 7) * ESZ;
-            tab_o[buf][t_lv][0][1][t_o] = tc1 * 128 + ((x0 + 1) & 7) * ESZ;
-            tab_o[buf][t_lv][1][0][t_o] = tr0 * 384 + (y0 & ((1 << TSH) - 1)) * 8 * ESZ;
-            tab_o[buf][t_lv][1][1][t_o] = tr1 * 384 + ((y0 + 1) & ((1 << TSH) - 1)) * 8 * ESZ;
-            tab_w[buf][t_lv][0][t_o] = wx;
-            tab_w[buf][t_lv][1][t_o] = wy;
+            // window coordinates of tap 0, clamped so that a wild coordinate (and its +1 neighbour) stays inside the window
+            const int wxc = min(max(x0 - tx0 * 8, 0), 30), wyc = min(max(y0 - (ty0 << TSH), 0), (4 << TSH) - 2);
+            TapEntry ex, ey;
+            ex.off = wxc * ESZ;
+            ex.w1 = wx;
+            ex.w0 = __fsub_rn(1.f, wx);
+            ex.pad = 0;
+            ey.off = t_lv * LVL_BYTES + wyc * PITCH;
+            ey.w1 = wy;
+            ey.w0 = __fsub_rn(1.f, wy);
+            ey.pad = 0;
+            tab[buf][0][t_lv][t_o] = ex;
+            tab[buf][1][t_lv][t_o] = ey;
             if (t_o == 0) {
-                geo[buf][t_lv][0] = tx0;
-                geo[buf][t_lv][1] = ty0;
-                geo[buf][t_lv][2] = ntc;
-                geo[buf][t_lv][3] = ntr;
+                int4 g4 = make_int4(tx0, ty0, min(max((xhi >> 3) - tx0 + 1, 1), 3), min(max((yhi >> TSH) - ty0 + 1, 1), MAXR));
+                *reinterpret_cast<int4*>(&geo[buf][t_lv][0]) = g4;
             }
             if (a.taps) {
                 int* t = a.taps + (q * 4 + t_lv) * 18;
@@ -98,111 +120,96 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
         }
     };
 
-    u32x4 rv[4][2];      // per level: two rounds of 8 tiles
-    unsigned okm = 0;    // bit (2 lv + round): this lane's tile is inside the plane's tile grid (else: zeros = padding)
-    unsigned wrm = 0;    // bit (2 lv + round): this lane's tile index lies inside the window (else: nothing to stage)
-    int slot_lds[4][2];  // byte offset of this lane's piece in the level image
-    unsigned emask[4][2];// per 16-byte piece: bit e set = element e (fp32: 4, fp16: 8) lies inside the plane
+    u32x4 rv[8];         // instruction i = level i >> 1, tile rows (i & 1) * 2 + {0, 1}
+    // Buffer loads over ONE plane (resource = the query's plane of the level, range-checked): a tile outside the plane's
+    // tile grid gets an out-of-range offset and the hardware returns zeros - grid_sample's zero padding without a select.
     auto issue_loads = [&](long long q, int buf) {
-        okm = 0;
-        wrm = 0;
 #pragma unroll
         for (int lv = 0; lv < 4; ++lv) {
-            const int tx0 = geo[buf][lv][0], ty0 = geo[buf][lv][1], ntc = geo[buf][lv][2], ntr = geo[buf][lv][3];
+            const int4 g4 = *reinterpret_cast<const int4*>(&geo[buf][lv][0]);
+            const int tx0 = __builtin_amdgcn_readfirstlane(g4.x), ty0 = __builtin_amdgcn_readfirstlane(g4.y);
+            const int ntc = __builtin_amdgcn_readfirstlane(g4.z), ntr = __builtin_amdgcn_readfirstlane(g4.w);
             const int ntx = a.ntx[lv], nty = a.nty[lv];
-            const char* pl = a.lvl[lv] + q * a.plane_bytes[lv];
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(a.lvl[lv] + q * a.plane_bytes[lv]), 0, (int)a.plane_bytes[lv], 0x00020000);
+            const int gtx = tx0 + min(s_tc, ntc - 1);                                    // slots past the window re-read its edge
+            const bool inx = (unsigned)gtx < (unsigned)ntx;
 #pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-                const int nt = ntc * ntr;
-                const int k = min(k8 + 8 * rd, nt - 1);                   // lanes beyond the window re-read its last tile
-                const int tr = (k * (ntc == 3 ? 43 : (ntc == 2 ? 64 : 128))) >> 7, tc = k - tr * ntc;   // k / ntc, k < 12
-                const int gtx = tx0 + tc, gty = ty0 + tr;
-                const bool wr = k8 + 8 * rd < nt;
-                const bool in = (unsigned)gtx < (unsigned)ntx && (unsigned)gty < (unsigned)nty && wr;
-                const int ctx = min(max(gtx, 0), ntx - 1), cty = min(max(gty, 0), nty - 1);
-                rv[lv][rd] = *reinterpret_cast<const u32x4*>(pl + (size_t)((cty * ntx + ctx) * 128 + piece * 16));
-                okm |= in ? 1u << (2 * lv + rd) : 0u;
-                wrm |= wr ? 1u << (2 * lv + rd) : 0u;
-                slot_lds[lv][rd] = (tr * 3 + tc) * 128 + piece * 16;
-                // elements of the piece inside the plane: fp32 piece = row (piece >> 1), x = (piece & 1) * 4 .. +3 ;
-                // fp16 piece = row piece, x = 0 .. 7
-                const int ey = (gty << TSH) + (HALF ? piece : piece >> 1);
-                const int ex = gtx * 8 + (HALF ? 0 : (piece & 1) * 4);
-                const int nv = min(max((a.w[0] >> lv) - ex, 0), HALF ? 8 : 4);
-                emask[lv][rd] = ((unsigned)ey < (unsigned)(a.h[0] >> lv)) ? (1u << nv) - 1u : 0u;
+            for (int hf = 0; hf < 2; ++hf) {
+                const int gty = ty0 + min(hf * 2 + s_trh, ntr - 1);
+                const bool in = inx && (unsigned)gty < (unsigned)nty;
+                const int off = in ? (gty * ntx + gtx) * 128 + s_p * 16 : 0x7ffffff0;
+                rv[lv * 2 + hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             }
         }
     };
     auto store_window = [&]() {
 #pragma unroll
-        for (int lv = 0; lv < 4; ++lv)
-#pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-                const unsigned m = (okm >> (2 * lv + rd) & 1u) ? emask[lv][rd] : 0u;
-                u32x4 v = rv[lv][rd];
-                if (HALF) {
-#pragma unroll
-                    for (int d = 0; d < 4; ++d)
-                        v[d] &= ((m >> (2 * d) & 1u) ? 0x0000ffffu : 0u) | ((m >> (2 * d + 1) & 1u) ? 0xffff0000u : 0u);
-                } else {
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) v[d] = (m >> d & 1u) ? v[d] : 0u;
-                }
-                // lanes whose tile index is past the window stage nothing (their slot aliases the window's last tile)
-                if (wrm >> (2 * lv + rd) & 1u) *reinterpret_cast<u32x4*>(&win[lv * LVL_BYTES + slot_lds[lv][rd]]) = v;
-            }
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<u32x4*>(&win[(i >> 1) * LVL_BYTES + (i & 1) * (2 << TSH) * PITCH + s_dst]) = rv[i];
     };
+
+    // blend roles: output k = lane + 64 j -> (level, ia, ib): loop-invariant table entries
+    int bx[6], by[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int k = min(lane + 64 * j, 323);
+        const int lv = k / 81, rem = k - lv * 81;
+        const int ia = rem / 9, ib = rem - ia * 9;
+        bx[j] = lv * 9 + ia;
+        by[j] = lv * 9 + ib;
+    }
 
     long long q = blockIdx.x;
     if (q >= a.queries) return;
     int cur = 0;
-    publish_taps(q, a.coords[q * 2], a.coords[q * 2 + 1], 0);
+    const float2* cptr = reinterpret_cast<const float2*>(a.coords);
+    publish_taps(q, cptr[q].x, cptr[q].y, 0);
     __syncthreads();
     issue_loads(q, 0);
+    // coordinates travel two queries ahead of the blend (their load latency would otherwise sit in front of every tap chain)
+    long long qn = q + gridDim.x;
+    float2 cn = cptr[qn < a.queries ? qn : q];
     for (;;) {
-        const long long qn = q + gridDim.x;
         const bool has_next = qn < a.queries;
         const long long qs = has_next ? qn : q;          // the last round re-stages its own query: nothing under a branch
-        const float cxn = a.coords[qs * 2], cyn = a.coords[qs * 2 + 1];
+        const long long qnn = qn + gridDim.x;
+        const float2 cnn = cptr[qnn < a.queries ? qnn : qs];   // past the end: the query that is re-staged then
         store_window();                                  // waits for this query's window loads
-        publish_taps(qs, cxn, cyn, cur ^ 1);
+        publish_taps(qs, cn.x, cn.y, cur ^ 1);
         __syncthreads();                                 // win + both table sets visible
         issue_loads(qs, cur ^ 1);                        // in flight during the blend below
         float* orow = a.out + q * a.out_ld;
+        const TapEntry* tx = &tab[cur][0][0][0];
+        const TapEntry* ty = &tab[cur][1][0][0];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int k = lane + 64 * j;
-            if (k < 324) {
-                const int lv = k / 81, rem = k - lv * 81;
-                const int ia = rem / 9, ib = rem - ia * 9;
-                const int xo0 = tab_o[cur][lv][0][0][ia], xo1 = tab_o[cur][lv][0][1][ia];
-                const int yo0 = tab_o[cur][lv][1][0][ib], yo1 = tab_o[cur][lv][1][1][ib];
-                const float fx = tab_w[cur][lv][0][ia], fy = tab_w[cur][lv][1][ib];
-                const char* p = &win[lv * LVL_BYTES];
-                float v00, v01, v10, v11;
-                if (HALF) {
-                    v00 = (float)*reinterpret_cast<const _Float16*>(p + yo0 + xo0);
-                    v01 = (float)*reinterpret_cast<const _Float16*>(p + yo0 + xo1);
-                    v10 = (float)*reinterpret_cast<const _Float16*>(p + yo1 + xo0);
-                    v11 = (float)*reinterpret_cast<const _Float16*>(p + yo1 + xo1);
-                } else {
-                    v00 = *reinterpret_cast<const float*>(p + yo0 + xo0);
-                    v01 = *reinterpret_cast<const float*>(p + yo0 + xo1);
-                    v10 = *reinterpret_cast<const float*>(p + yo1 + xo0);
-                    v11 = *reinterpret_cast<const float*>(p + yo1 + xo1);
-                }
-                const float ex = __fsub_rn(1.f, fx), sy = __fsub_rn(1.f, fy);
-                // nw*s*e + ne*s*w + sw*n*e + se*n*w  (ATen's weight naming)
-                float o = __fmul_rn(v00, __fmul_rn(sy, ex));
-                o = __fadd_rn(o, __fmul_rn(v01, __fmul_rn(sy, fx)));
-                o = __fadd_rn(o, __fmul_rn(v10, __fmul_rn(fy, ex)));
-                o = __fadd_rn(o, __fmul_rn(v11, __fmul_rn(fy, fx)));
-                orow[k] = o;
+            const TapEntry ex = tx[bx[j]], ey = ty[by[j]];
+            const char* p = &win[ey.off + ex.off];
+            float v00, v01, v10, v11;
+            if (HALF) {
+                v00 = (float)*reinterpret_cast<const _Float16*>(p);
+                v01 = (float)*reinterpret_cast<const _Float16*>(p + 2);
+                v10 = (float)*reinterpret_cast<const _Float16*>(p + PITCH);
+                v11 = (float)*reinterpret_cast<const _Float16*>(p + PITCH + 2);
+            } else {
+                v00 = *reinterpret_cast<const float*>(p);
+                v01 = *reinterpret_cast<const float*>(p + 4);
+                v10 = *reinterpret_cast<const float*>(p + PITCH);
+                v11 = *reinterpret_cast<const float*>(p + PITCH + 4);
             }
+            // nw*s*e + ne*s*w + sw*n*e + se*n*w  (ATen's weight naming): s = 1 - wy, e = 1 - wx
+            float o = __fmul_rn(v00, __fmul_rn(ey.w0, ex.w0));
+            o = __fadd_rn(o, __fmul_rn(v01, __fmul_rn(ey.w0, ex.w1)));
+            o = __fadd_rn(o, __fmul_rn(v10, __fmul_rn(ey.w1, ex.w0)));
+            o = __fadd_rn(o, __fmul_rn(v11, __fmul_rn(ey.w1, ex.w1)));
+            if (j < 5 || lane < 4) orow[lane + 64 * j] = o;
         }
         if (!has_next) break;
         __syncthreads();                                 // everyone done reading win before it is overwritten
         q = qn;
+        qn = qnn;
+        cn = cnn;
         cur ^= 1;
     }
 }
@@ -225,8 +232,10 @@ struct TLookupBwdArgs {
     int dout_ld;
 };
 
+constexpr int BTILES = 12;     // backward: 4 tile rows x 3 tile columns per level
+
 __global__ __launch_bounds__(64) void lookup_tiled_bwd_kernel(const TLookupBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float win[4 * LTILES * 32];
+    __shared__ __attribute__((aligned(16))) float win[4 * BTILES * 32];
     __shared__ int tab_o[4][2][2][9];
     __shared__ float tab_w[4][2][9];
     __shared__ int geo[4][4];
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_bwd_kernel(const TLookupBwdAr
                 geo[t_lv][3] = min(max((yhi >> 2) - ty0 + 1, 1), 4);
             }
         }
-        for (int e = lane; e < 4 * LTILES * 32; e += 64) win[e] = 0.f;
+        for (int e = lane; e < 4 * BTILES * 32; e += 64) win[e] = 0.f;
         __syncthreads();
         const float* drow = a.dout + q * a.dout_ld;
 #pragma unroll
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_bwd_kernel(const TLookupBwdAr
                 const float fx = tab_w[lv][0][ia], fy = tab_w[lv][1][ib];
                 const float g = drow[k];
                 const float ex = 1.f - fx, sy = 1.f - fy;
-                float* p = &win[lv * LTILES * 32];
+                float* p = &win[lv * BTILES * 32];
                 atomicAdd(p + yo0 + xo0, g * (sy * ex));
                 atomicAdd(p + yo0 + xo1, g * (sy * fx));
                 atomicAdd(p + yo1 + xo0, g * (fy * ex));
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_bwd_kernel(const TLookupBwdAr
                 const int ctx = min(max(gtx, 0), ntx - 1), cty = min(max(gty, 0), nty - 1);
                 const long long o = (long long)(cty * ntx + ctx) * 32 + piece * 4;
                 cur[lv][rd] = *reinterpret_cast<const f32x4*>(pl + o);
-                f32x4 v = *reinterpret_cast<const f32x4*>(&win[lv * LTILES * 32 + (tr * 3 + tc) * 32 + piece * 4]);
+                f32x4 v = *reinterpret_cast<const f32x4*>(&win[lv * BTILES * 32 + (tr * 3 + tc) * 32 + piece * 4]);
                 const int ey = gty * 4 + (piece >> 1), ex = gtx * 8 + (piece & 1) * 4;
                 const int nv = ((unsigned)ey < (unsigned)(a.h[0] >> lv)) ? min(max((a.w[0] >> lv) - ex, 0), 4) : 0;
 #pragma unroll
@@ -395,8 +404,8 @@ extern "C" int ff_corr_lookup_tiled_fwd(const void* const* levels, int half, con
     a.taps = taps_dbg;
     a.queries = queries;
     a.out_ld = out_ld;
-    // one wave per block, 7.7 KB of LDS each: 20 blocks fit a CU; a grid of 256 x 16 runs as one resident round
-    static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 16;
+    // one wave per block, 12.7 KB of LDS each: 12 blocks fit a CU
+    static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 12;
     const long long blocks = queries < 256ll * wpc ? queries : 256ll * wpc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (half) lookup_tiled_kernel<true><<<(unsigned)blocks, 64, 0, s>>>(a);

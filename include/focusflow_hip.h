@@ -165,7 +165,9 @@ int ff_corr_lookup_fwd(const float* const* levels /* HOST array of 4 device ptrs
  * Level l of query i (h_l x w_l values, h_l = h0 >> l) is a grid of 128-byte 2-D tiles:
  *     fp32 storage: tile = 8 wide x 4 high floats ; fp16 storage: tile = 8 wide x 8 high halfs ;
  *     element (y, x) at ((y / TH) * ntx + x / 8) * (8 * TH) + (y % TH) * 8 + (x % 8),
- *     ntx = ceil((ceil16(w0) >> l) / 8), nty = ceil((ceil8(h0) >> l) / TH); pad elements are undefined.
+ *     ntx = ceil((ceil16(w0) >> l) / 8), nty = ceil((ceil8(h0) >> l) / TH).  Pad elements (inside the tile grid, beyond
+ *     the plane) MUST BE ZERO: ff_corr_build and ff_corr_retile (into zero-initialised storage) guarantee it, the lookup
+ *     relies on it (grid_sample's zero padding), the backward kernels keep it.
  *   ff_corr_plane_elems       elements per plane of `level` (the only non-status return value besides ff_abi_version)
  *   ff_corr_build             CorrBlock.__init__ (corr.py:12-27) + CorrBlock.corr (:52-60) in ONE launch: volume
  *                             <fmap1[i], fmap2[j]> / sqrt(C) on the f16 matrix pipe from operands pre-split by

@@ -159,8 +159,11 @@ def test_corr_block_backward(mods, h, w, half):
     lossd = sum((blk(nhwc(cd)) * nhwc(gy)).sum() for cd, gy in zip(coords, gys))
     close(lossd.item(), loss.item(), rtol=(1e-3 if half else 1e-5), atol_rel=(1e-3 if half else 1e-5), what="loss")
     lossd.backward()
-    close(nchw(f1d.grad), f1.grad, rtol=1e-4, atol_rel=1e-4, what="dfmap1")
-    close(nchw(f2d.grad), f2.grad, rtol=1e-4, atol_rel=1e-4, what="dfmap2")
+    # fp16 storage: the ORACLE's gradient passes through .half() (autograd rounds it to fp16 there); the HIP path keeps the
+    # straight-through gradient in fp32, so the two differ by fp16 rounding of the oracle's side
+    tol = 2e-3 if half else 1e-4
+    close(nchw(f1d.grad), f1.grad, rtol=tol, atol_rel=tol, what="dfmap1")
+    close(nchw(f2d.grad), f2.grad, rtol=tol, atol_rel=tol, what="dfmap2")
 
 
 def test_gru_and_upsample_backward(mods):

@@ -543,9 +543,10 @@ def test_full_size_lookup_properties(ops, half):
     # (not bit-equal: at W=64 the sampler's fp32 normalise/un-normalise round trip moves some
     #  integer coordinates by an ulp, exactly as in the reference — SURVEY §7 "hard parts")
     close(out.view(b, h * w, 324)[..., 40].cpu(), diag.cpu(), rtol=0, atol=(2e-2 if half else 1e-3), what="centre tap")
-    # linearity of the volume in fmap1 (a power of two: exact in every format)
+    # linearity of the volume in fmap1 (not bit-exact: the fp16 residual of a split operand is a subnormal half for
+    # small values, so doubling the operand changes its last bits)
     vol2 = ops.corr_build(f1 * 2, f2, half).rowmajor(0).view(b, h * w, h * w)
-    assert torch.equal(vol2, vol * 2), "volume is not linear in fmap1"
+    close(vol2.cpu(), (vol * 2).cpu(), rtol=(1e-3 if half else 1e-6), atol=(2e-3 if half else 1e-5), what="linearity")
     # pyramid means are preserved level to level (48x64 divides evenly)
     for lo, hi in zip(lv[:-1], lv[1:]):
         close(hi.mean(dim=(1, 2)).cpu(), lo.mean(dim=(1, 2)).cpu(), rtol=1e-4, atol=(2e-3 if half else 1e-4), what="pool mean")

@@ -45,3 +45,8 @@ for name, spoil in (("cache-warm (back-to-back)", False), ("cache-cold (512 MB w
         flop = 2.0 * b * (h * w) ** 2 * 256
         print(f"build (incl. operand split) {name}: median {us:.1f} us  min {mn:.1f} us -> {3 * flop / us / 1e6:.0f} TFLOP/s f16 issued, "
               f"{vol_bytes / us / 1e3:.0f} GB/s written")
+if only in ("", "build"):
+    both = torch.empty((2 * b * h * w, 1024), dtype=torch.uint8, device="cuda")
+    from focusflow_official_amd import _hip
+    us, mn = timeit(lambda: _hip.call("ff_pack_split_f16", ops._p(f12), ops._p(both), 2 * b * h * w, 256, ops._stream()), False, n=15)
+    print(f"operand split alone ({2 * b * h * w} rows): median {us:.1f} us")
