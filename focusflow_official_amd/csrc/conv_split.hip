@@ -397,20 +397,39 @@ int dispatch(const KernArgs& a, hipStream_t s) {
 }
 
 // fp32 rows [rows][K] -> split rows [rows][ceil(K/32)][x0: 32 fp16 | x1: 32 fp16], zero padded
+// One thread = 8 consecutive k of one row chunk: two 16-byte loads (when the row allows), two 16-byte stores (x0 part
+// and x1 part of the 128-byte chunk row).  Same arithmetic as one element at a time: h0 = f16(s v), h1 = f16(s v - h0).
 __global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long rows, int K,
-                                  int nchunks) {
-    const long long total = rows * nchunks * 32;
+                                  int nchunks, int vec) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const long long total = rows * nchunks * 4;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int kk = (int)(i % 32);
-        const long long rc = i / 32;
+        const int oct = (int)(i & 3);
+        const long long rc = i >> 2;
         const int c = (int)(rc % nchunks);
         const long long r = rc / nchunks;
-        const int k = c * 32 + kk;
-        const float v = k < K ? src[r * K + k] : 0.f;
-        const float sv = v * ff::WSPLIT;
-        const _Float16 h0 = (_Float16)sv;
-        dst[rc * 64 + kk] = h0;
-        dst[rc * 64 + 32 + kk] = (_Float16)(sv - (float)h0);
+        const int k0 = c * 32 + oct * 8;
+        float v[8];
+        if (vec && k0 + 8 <= K) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + r * K + k0), b = *reinterpret_cast<const f32x4*>(src + r * K + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = a[e];
+                v[4 + e] = b[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = k0 + e < K ? src[r * K + k0 + e] : 0.f;
+        }
+        h8 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sv = v[e] * ff::WSPLIT;
+            h0[e] = (_Float16)sv;
+            h1[e] = (_Float16)(sv - (float)h0[e]);
+        }
+        *reinterpret_cast<h8*>(dst + rc * 64 + oct * 8) = h0;
+        *reinterpret_cast<h8*>(dst + rc * 64 + 32 + oct * 8) = h1;
     }
 }
 
@@ -439,9 +458,10 @@ extern "C" int ff_pack_split_f16(const float* src, void* dst, long long rows, in
     FF_REQUIRE(src && dst && rows > 0 && K > 0, "ff_pack_split_f16: bad argument");
     FF_REQUIRE(ff::aligned16(dst), "ff_pack_split_f16: dst not 16-byte aligned");
     const int nchunks = (K + 31) / 32;
-    const long long total = rows * nchunks * 32;
+    const long long total = rows * nchunks * 4;
     long long g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
-    pack_split_kernel<<<(unsigned)g, 256, 0, static_cast<hipStream_t>(stream)>>>(src, static_cast<_Float16*>(dst), rows, K, nchunks);
+    if (g > 8192) g = 8192;
+    const int vec = (K & 3) == 0 && ff::aligned16(src);
+    pack_split_kernel<<<(unsigned)g, 256, 0, static_cast<hipStream_t>(stream)>>>(src, static_cast<_Float16*>(dst), rows, K, nchunks, vec);
     return ff::check_launch("ff_pack_split_f16");
 }

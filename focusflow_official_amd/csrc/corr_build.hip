@@ -38,7 +38,6 @@ struct BuildArgs {
     int Q, B, npx, npy, mtiles;
     float scale;            // 1/sqrt(C) / (WSPLIT * WSPLIT)
     int ablate;             // timing experiments only (FF_CORR_BUILD_ABLATE): 1 = no epilogue, 2 = operands loaded once
-    int stagger;            // second resident block of every CU starts this many x 4 us late (see ff_corr_build)
 };
 
 constexpr int STAGE = 32768;     // J tile 16 KB | I tile 16 KB
@@ -59,9 +58,14 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
         const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, x = bid & 7;
         bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (bid >> 3);
     }
+    // Inside a sample, blocks walk 8 x 8 super-tiles of (query tile, patch): the ~64 blocks an XCD has in flight then
+    // share 8 query tiles and 8 patches (2 MB) instead of 3 query tiles and every patch of the sample.
     const int npatch = a.npx * a.npy;
-    const int patch = bid % npatch, rest = bid / npatch;
-    const int mt = rest % a.mtiles, b = rest / a.mtiles;
+    const int sgm = (a.mtiles + 7) >> 3, sgp = (npatch + 7) >> 3, per_b = sgm * sgp * 64;
+    const int b = bid / per_b, rb = bid - b * per_b;
+    const int sb = rb >> 6, wi = rb & 63;
+    const int mt = (sb / sgp) * 8 + (wi >> 3), patch = (sb % sgp) * 8 + (wi & 7);
+    if (b >= a.B || mt >= a.mtiles || patch >= npatch) return;
     const int px = patch % a.npx, py = patch / a.npx;
     const int m0 = mt * 128;
     const int h0 = a.h[0], w0 = a.w[0];
@@ -108,11 +112,6 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // Two blocks share a CU and would otherwise move in lock-step (both in their MFMA loop, then both in their store
-    // epilogue).  The blocks of the second dispatch round (one per CU: ids 256..511) start late, which puts the two
-    // residents of a CU - and every pair of blocks that replaces them - in opposite phases.
-    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     issue(0, 0);
     for (int c = 0; c < NCHUNK; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -422,9 +421,7 @@ extern "C" int ff_corr_build(const void* f1_split, const void* f2_split, void* c
     a.scale = 1.f / sqrtf((float)C) / (ff::WSPLIT * ff::WSPLIT);
     static const int ablate = getenv("FF_CORR_BUILD_ABLATE") ? atoi(getenv("FF_CORR_BUILD_ABLATE")) : 0;
     a.ablate = ablate;
-    static const int stagger = getenv("FF_CORR_BUILD_STAGGER") ? atoi(getenv("FF_CORR_BUILD_STAGGER")) : 0;
-    a.stagger = stagger;
-    const long long nblk = (long long)B * a.mtiles * L.npx * L.npy;
+    const long long nblk = (long long)B * ((a.mtiles + 7) / 8) * ((L.npx * L.npy + 7) / 8) * 64;   // 8 x 8 super-tiles, ragged ones exit
     FF_REQUIRE(nblk < (1ll << 31), "ff_corr_build: grid too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // The kernel writes every element its 16 x 8 patches cover (zeros beyond the plane).  Where the tile grid of a deeper

@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden
+from conftest import golden_spec, load_golden
 from oracle import ffraft_ref as orc
 
 pytestmark = pytest.mark.gpu
