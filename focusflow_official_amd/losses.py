@@ -47,7 +47,7 @@ class _SequenceLossFn(torch.autograd.Function):
             grads.append(g)
         ctx.grads = grads
         ctx.vmap = vmap
-        return loss.float().squeeze(0)
+        return loss.sum().float()     # a fresh 0-dim tensor, not a view: train.py:313-314 multiplies the loss IN PLACE (`loss *= world_size`)
 
     @staticmethod
     def backward(ctx, gout):

@@ -28,7 +28,7 @@ class _ScaleLoss(torch.autograd.Function):
                   int(zero_if_empty), int(over_batch), int(l1q), float(eps), float(q), _p(grad), _p(loss), b, target.shape[2], target.shape[3],
                   h, w, _stream())
         ctx.save_for_backward(grad)
-        return loss.float().squeeze(0)
+        return loss.sum().float()     # a fresh 0-dim tensor, not a view: train.py:313-314 multiplies the loss IN PLACE (`loss *= world_size`)
 
     @staticmethod
     def backward(ctx, g):

@@ -39,7 +39,7 @@ def close(a, b, rtol=2e-5, atol=None, what=""):
     assert err.max() <= atol, f"{what}: max violation {err.max():.3e} (atol {atol:.3e}), max|ref| {np.abs(b).max():.3e}"
 
 
-C5_FP16_VS_ORACLE = 2e-3   # px: same definition on both sides; differences come from fp16 roundings that flip on 1e-6 volume noise
+C5_FP16_VS_ORACLE = 2e-3   # px at 1/8 resolution: same definition on both sides; differences come from fp16 roundings that flip on 1e-6 volume noise
 C5_FP16_VS_FP32 = 2e-2     # px on flow_low: effect of the fp16 storage itself on the 32-iteration flow (5.5e-3 measured on the oracle)
 
 
@@ -594,7 +594,7 @@ def test_baseline_config5_544x960_it32_fp16_pyramid():
         fl, fu = m(*[t.to(DEV) for t in inp], raft_iters=32, test_mode=True)
         rl, ru = orc.ffraft_forward(sd, *inp, raft_iters=32, test_mode=True, corr_half=True)
     close(fl.cpu(), rl, rtol=0, atol=C5_FP16_VS_ORACLE, what="C5 it32 fp16 pyramid: flow_low vs oracle (fp16 pyramid)")
-    close(fu.cpu(), ru, rtol=0, atol=C5_FP16_VS_ORACLE, what="C5 it32 fp16 pyramid: flow_up vs oracle (fp16 pyramid)")
+    close(fu.cpu(), ru, rtol=0, atol=8 * C5_FP16_VS_ORACLE, what="C5 it32 fp16 pyramid: flow_up vs oracle (fp16 pyramid)")   # flow_up = 8 x flow
     close(fl.cpu(), g["flow_low_fp32"], rtol=0, atol=C5_FP16_VS_FP32, what="C5 it32 fp16 pyramid vs reference fp32")
 
 
