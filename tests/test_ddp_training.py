@@ -79,4 +79,7 @@ def test_ddp_two_ranks_match_full_batch(tmp_path, partial):
             continue
         report.append((((ddp_grads[k] - ref).abs().max() / scale).item(), k, scale))
     report.sort(reverse=True)
-    assert report[0][0] < 1e-2, report[:8]
+    # both sides are the HIP path: what differs is the order of the atomic weight-gradient adds and the per-rank batch
+    # of 1 instead of 2 (other tiles, other split scales of the gradients)
+    print(report[:4])
+    assert report[0][0] < 1e-4, report[:8]      # measured: 1e-5 (it was asserted at 1e-2)

@@ -139,6 +139,87 @@ def test_norm_backward(mods, kind, relu, use_res):
         close(bd.grad.cpu(), beta.grad, rtol=1e-4, atol_rel=1e-4, what="dbeta")
 
 
+def _model_for_blocks(det_sd):
+    from focusflow_official_amd import FF_RAFT_FUSION
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg())
+    m.load_state_dict(det_sd, strict=True)
+    return m.to(DEV).train()
+
+
+@pytest.mark.parametrize("blkname,c_in,c,hw,stride", [("layer2.1", 96, 96, 32, 1), ("layer1.0", 64, 64, 64, 1), ("layer2.0", 64, 96, 64, 2)])
+@pytest.mark.parametrize("kind", ["smooth", "noise", "tiny+outliers"])
+def test_residual_block_backward_against_fp64(det_sd, blkname, c_in, c, hw, stride, kind):
+    """One residual block of fnet (conv-InstanceNorm-ReLU twice, optional stride-2 downsample branch, residual add) on
+    the HIP path, forward AND backward, against the oracle in DOUBLE - at 1e-5 of each tensor's maximum.  A single
+    block is well conditioned, so this is where a wrong-by-0.5 % gradient would show; the whole-network gradient
+    tests below cannot be this tight (see there).  Upstream gradients: smooth fields, white noise, and white noise at
+    1e-7 with a few 3e4 x outliers (the power-of-two scaling of the f16 gradient operands must cope)."""
+    m = _model_for_blocks(det_sd)
+    enc = m.flow_net.fnet
+    blk = dict(enc.named_modules())[blkname]
+    pre = "flow_net.fnet." + blkname
+    g = torch.Generator().manual_seed(7)
+    ho = hw // stride
+    if kind == "smooth":
+        x = F.interpolate(torch.randn(1, c_in, hw // 4, hw // 4, generator=g), size=(hw, hw), mode="bilinear").relu() \
+            + 0.01 * torch.randn(1, c_in, hw, hw, generator=g).abs()
+        G = F.interpolate(torch.randn(1, c, ho // 8, ho // 8, generator=g), size=(ho, ho), mode="bilinear")
+    else:
+        x = torch.randn(1, c_in, hw, hw, generator=g).relu()
+        G = torch.randn(1, c, ho, ho, generator=g)
+        if kind == "tiny+outliers":
+            G = G * 1e-7
+            G.view(-1)[torch.randint(0, G.numel(), (20,), generator=g)] *= 3e4
+    s2 = {k: v.double().clone().requires_grad_(True) for k, v in det_sd.items() if k.startswith(pre + ".") and v.is_floating_point()}
+    xx = x.double().requires_grad_(True)
+    y = orc._resblock(s2, pre, xx, "instance", stride, False)
+    (y * G.double()).sum().backward()
+    xd = nhwc(x).requires_grad_(True)
+    yd = enc._block(blk, xd)
+    (yd * nhwc(G)).sum().backward()
+    close(nchw(yd), y.detach(), rtol=0, atol_rel=5e-6, what="block output")
+    close(nchw(xd.grad), xx.grad, rtol=0, atol_rel=1e-5, what="dx")
+    # (the biases sit in front of an InstanceNorm: their true gradient is exactly zero)
+    names = ["conv1.weight", "conv2.weight"] + (["downsample.0.weight"] if stride != 1 else [])
+    params = dict(blk.named_parameters())
+    for n in names:
+        close(params[n].grad.cpu(), s2[pre + "." + n].grad, rtol=0, atol_rel=1e-5, what=n)
+
+
+def test_update_block_step_backward_against_fp64(det_sd):
+    """One application of the update block (motion encoder, both SepConvGRU passes, flow head, mask head: update.py:126-135)
+    forward and backward against the oracle in double, 2e-5 (gradients: 5e-5) of each tensor's maximum."""
+    m = _model_for_blocks(det_sd)
+    ub = m.flow_net.update_block
+    pre = "flow_net.update_block"
+    g = torch.Generator().manual_seed(3)
+    b, h, w = 1, 16, 24
+    net = torch.tanh(torch.randn(b, 128, h, w, generator=g))
+    inp = torch.randn(b, 128, h, w, generator=g).relu()
+    corr = torch.randn(b, 324, h, w, generator=g) * 3
+    flow = torch.randn(b, 2, h, w, generator=g) * 2
+    gn, gm, gd = torch.randn(b, 128, h, w, generator=g), torch.randn(b, 576, h, w, generator=g), torch.randn(b, 2, h, w, generator=g)
+    s2 = {k: v.double().clone().requires_grad_(True) for k, v in det_sd.items() if k.startswith(pre + ".")}
+    ins64 = [t.double().requires_grad_(True) for t in (net, inp, corr)]
+    n64, m64, d64 = orc.update_block(s2, pre, ins64[0], ins64[1], ins64[2], flow.double())
+    ((n64 * gn).sum() + (m64 * gm).sum() + (d64 * gd).sum()).backward()
+    insd = [nhwc(t).requires_grad_(True) for t in (net, inp, corr)]
+    flow4 = F.pad(nhwc(flow), (0, 2))
+    fill = lambda motion: motion[..., 126:].copy_(flow4[..., :2])  # noqa: E731  (test plumbing: torch.cat([out, flow]))
+    nd, md, dd = ub.run(insd[0], insd[1], insd[2], flow4, fill)
+    ((nd * nhwc(gn)).sum() + (md * nhwc(gm)).sum() + (dd[..., :2] * nhwc(gd)).sum()).backward()
+    close(nchw(nd), n64.detach(), rtol=0, atol_rel=2e-5, what="net")
+    close(nchw(md), m64.detach(), rtol=0, atol_rel=2e-5, what="up_mask")
+    close(nchw(dd[..., :2]), d64.detach(), rtol=0, atol_rel=2e-5, what="delta_flow")
+    for name, a, r in zip(("dnet", "dinp", "dcorr"), insd, ins64):
+        close(nchw(a.grad), r.grad, rtol=0, atol_rel=5e-5, what=name)
+    params = dict(ub.named_parameters())
+    for n in ["encoder.convc1.weight", "encoder.convc2.weight", "encoder.convf1.weight", "encoder.convf2.bias", "encoder.conv.weight",
+              "gru.convz1.weight", "gru.convr1.weight", "gru.convq1.weight", "gru.convz2.bias", "gru.convr2.weight", "gru.convq2.weight",
+              "flow_head.conv1.weight", "flow_head.conv2.weight", "mask.0.bias", "mask.2.weight"]:
+        close(params[n].grad.cpu(), s2[pre + "." + n].grad, rtol=0, atol_rel=5e-5, what=n)
+
+
 @pytest.mark.parametrize("h,w,half", [(16, 24, False), (17, 19, False), (20, 16, True)], ids=["16x24", "17x19-odd", "20x16-fp16"])
 def test_corr_block_backward(mods, h, w, half):
     """d(loss)/d(fmap1, fmap2) through volume -> pyramid -> 3 lookups at different coords (tiled gradient planes:
@@ -229,6 +310,50 @@ def _cfg():
                      MODEL=Namespace(FUSION_TYPE="1x1conv", LOAD_MODULE_TO_BRANCH=False))
 
 
+def _oracle_grads(det_sd, inp, iters, loss_fn, dtype):
+    """Autograd through the oracle in `dtype` (frozen BatchNorm): {name: grad}, last prediction."""
+    sd = {k: ((v.to(dtype).clone().requires_grad_(True) if "running_" not in k else v.to(dtype).clone()) if v.is_floating_point() else v.clone())
+          for k, v in det_sd.items()}
+    ref = orc.ffraft_forward(sd, *[t.to(dtype) for t in inp], raft_iters=iters, training=False)
+    loss_fn(ref).backward()
+    return {k: v.grad for k, v in sd.items() if getattr(v, "grad", None) is not None}, ref[-1].detach()
+
+
+# Whole-network gradients cannot be compared tightly: between two fp32 evaluations (and between fp32 and fp64) a ReLU
+# plane of a constant mask image, an L1 sign or a window corner flips here and there, and the flip lands in one channel of
+# one layer.  Measured on one frozen-BatchNorm step at 128x128 over all 216 parameter tensors, error = |g - g_fp64| / max|g_fp64|:
+#   CPU oracle in fp32      median 5.7e-4   90 % < 8.7e-4   max 1.7e-3
+#   HIP, exact-fp32 convs   median 4.3e-4   90 % < 2.8e-3   max 4.9e-2  (fnet.layer2.0.conv2.weight, one output channel)
+#   HIP, f16x3 convs        median 1.0e-3   90 % < 2.7e-3   max 2.9e-2  (fnet.layer2.1.conv2.weight, one output channel)
+# and with noise images in 'frame' mask mode the CPU's own maximum is 2.2e-2 while HIP stays below 5.3e-3
+# (tests/diagnostics/grad_spread.py).  So the sharp checks are the single-block tests above (1e-5 against fp64); the
+# whole-network tests bound each sampled tensor by 8 x the oracle's own fp32-vs-fp64 spread (at least 5e-3 of its max)
+# and, over ALL parameters, the median and the 90th percentile.
+def _check_grad_spread(hip, ref32, ref64, name):
+    want = ref64.double().numpy()
+    scale = float(np.abs(want).max())
+    ref_spread = float(np.abs(ref32.double().numpy() - want).max())
+    hip_spread = float(np.abs(hip.double().numpy() - want).max())
+    assert hip_spread <= max(8 * ref_spread, 5e-3 * scale), \
+        f"{name}: |hip - fp64| = {hip_spread / scale:.2e} of max, the oracle's own fp32 run: {ref_spread / scale:.2e}"
+
+
+def _check_grad_population(params, g32, g64):
+    """Over every parameter tensor with a non-trivial gradient: distribution of |hip - fp64| / max against the CPU's."""
+    hip, cpu = [], []
+    for k, p in params.items():
+        if p.grad is None or k not in g64 or float(g64[k].abs().max()) < 1e-7:
+            continue
+        s = float(g64[k].abs().max())
+        hip.append(float((p.grad.cpu().double() - g64[k]).abs().max()) / s)
+        cpu.append(float((g32[k].double() - g64[k]).abs().max()) / s)
+    hip, cpu = np.array(hip), np.array(cpu)
+    assert len(hip) > 200
+    assert np.median(hip) <= max(4 * np.median(cpu), 3e-3), (np.median(hip), np.median(cpu))
+    assert np.percentile(hip, 90) <= max(6 * np.percentile(cpu, 90), 1e-2), (np.percentile(hip, 90), np.percentile(cpu, 90))
+    assert hip.max() <= 0.1, hip.max()
+
+
 def test_train_step_matches_reference(det_sd):
     """Train-mode forward (BatchNorm batch statistics) + sequence L1 + backward, against the
     fixture produced by the reference (loss, 14 sampled parameter gradients and their norms,
@@ -261,15 +386,22 @@ def test_train_step_matches_reference(det_sd):
         rel = float(np.abs(got - g[key]).max() / max(1e-12, np.abs(g[key]).max()))
         report.append(f"{name}: |grad| {gk.norm().item():.6g} vs {gn:.6g}, max rel err {rel:.2e}")
     print("\n".join(report))
+    g64 = load_golden("train_shift_128x128_b2_it3_fp64")     # the same step evaluated in double (make_golden_train64.py)
     for key in [k for k in g if k.startswith("grad:")]:
         name = "flow_net." + key[5:]
         gk = params[name].grad
-        got = gk.flatten()[:: max(1, gk.numel() // 512)].cpu().numpy()
+        got = gk.flatten()[:: max(1, gk.numel() // 512)].cpu().numpy().astype(np.float64)
         gn = float(g["gnorm:" + key[5:]][0])
         assert abs(gk.norm().item() - gn) < 2e-3 * max(gn, 1e-3), "\n".join(report)
-        # element tolerance = 1e-2 of the tensor's max: the reference's own fp32-vs-fp64 spread on this
-        # step is 2.7e-3 of max for fnet (instance norms over near-constant mask planes), 5e-4 elsewhere
-        np.testing.assert_allclose(got, g[key], rtol=0, atol=1e-2 * float(np.abs(g[key]).max()), err_msg=name)
+        # Element bound (see the note above _check_grad_spread): 8 x the REFERENCE's own fp32-vs-fp64 spread on this
+        # tensor, at least 5e-3 of its maximum; the heads, whose gradients do not pass through any flip-prone layer,
+        # must agree to 1e-4.
+        want64 = g64["grad64:" + key[5:]]
+        scale = float(np.abs(want64).max())
+        ref_spread = float(np.abs(g[key].astype(np.float64) - want64).max())
+        hip_spread = float(np.abs(got - want64).max())
+        bound = 1e-4 * scale if ("flow_head.conv2" in name or "mask.2" in name) else max(8 * ref_spread, 5e-3 * scale)
+        assert hip_spread <= bound, f"{name}: |hip - fp64| {hip_spread / scale:.2e} of max vs reference spread {ref_spread / scale:.2e}\n" + "\n".join(report)
     total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())).item()
     assert abs(total - g["grad_total_norm"][0]) < 2e-3 * g["grad_total_norm"][0]
     sd = m.state_dict()
@@ -288,19 +420,16 @@ def test_frozen_bn_training_step_gives_gradients(det_sd):
     inp = orc.shifted_pair(1, 128, 128, seed=9)
     preds = m(*[t.to(DEV) for t in inp], raft_iters=2)
     preds[-1].abs().mean().backward()
-    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
-          for k, v in det_sd.items()}
-    # oracle: instance norm always per-sample; batch norm in eval mode = training False
-    ref = orc.ffraft_forward(sd, *inp, raft_iters=2, training=False)
-    ref[-1].abs().mean().backward()
-    close(preds[-1].detach().cpu(), ref[-1].detach(), rtol=0, atol_rel=2e-4, what="pred")
+    # oracle: instance norm always per-sample; batch norm in eval mode = training False; once in fp32, once in fp64
+    loss_fn = lambda ref: ref[-1].abs().mean()  # noqa: E731
+    g32, last32 = _oracle_grads(det_sd, inp, 2, loss_fn, torch.float32)
+    g64, _ = _oracle_grads(det_sd, inp, 2, loss_fn, torch.float64)
+    close(preds[-1].detach().cpu(), last32, rtol=0, atol_rel=2e-4, what="pred")
     params = dict(m.named_parameters(remove_duplicate=False))
     for name in ["flow_net.cnet.norm1.weight", "flow_net.cnet.layer2.0.downsample.1.bias", "flow_net.cnet.conv1.weight",
                  "flow_net.update_block.gru.convq1.weight", "flow_net.fnet.fusion3.img2mask.conv.weight"]:
-        ref_g = sd[name].grad
-        # 1e-2: at this size the step sits next to a discrete event (a ReLU / window-corner flip between the CPU and the
-        # GPU forward): the exact-fp32 conv mode differs from the CPU oracle by the same 0.5 % (tests/diagnostics/frozen_bn_grads.py)
-        close(params[name].grad.cpu(), ref_g, rtol=1e-2, atol_rel=1e-2, what=name)
+        _check_grad_spread(params[name].grad.cpu(), g32[name], g64[name], name)
+    _check_grad_population(params, g32, g64)
 
 
 @pytest.mark.parametrize("partial", [False, True])
@@ -341,18 +470,15 @@ def test_odd_plane_sizes_forward_and_backward(det_sd):
     inp = orc.shifted_pair(1, 136, 152, seed=13)
     preds = m(*[t.to(DEV) for t in inp], raft_iters=2)
     sum(p.abs().mean() for p in preds).backward()
-    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
-          for k, v in det_sd.items()}
-    ref = orc.ffraft_forward(sd, *inp, raft_iters=2, training=False)
-    sum(p.abs().mean() for p in ref).backward()
-    close(preds[-1].detach().cpu(), ref[-1].detach(), rtol=0, atol_rel=2e-4, what="pred")
+    loss_fn = lambda ref: sum(p.abs().mean() for p in ref)  # noqa: E731
+    g32, last32 = _oracle_grads(det_sd, inp, 2, loss_fn, torch.float32)
+    g64, _ = _oracle_grads(det_sd, inp, 2, loss_fn, torch.float64)
+    close(preds[-1].detach().cpu(), last32, rtol=0, atol_rel=2e-4, what="pred")
     params = dict(m.named_parameters(remove_duplicate=False))
     for name in ["flow_net.fnet.layer3.1.conv2.weight", "flow_net.cnet.conv1.weight", "flow_net.update_block.gru.convz2.weight",
                  "flow_net.update_block.encoder.convc1.weight", "flow_net.update_block.mask.2.weight",
                  "flow_net.fnet.fusion2.mask2img.conv.weight"]:
-        # 1e-2 of the tensor's max, as in the train-step fixture test: the reference's own fp32-vs-fp64 spread on
-        # gradients that travel the whole network (encoder stems) is a few 1e-3
-        close(params[name].grad.cpu(), sd[name].grad, rtol=1e-2, atol_rel=1e-2, what=name)
+        _check_grad_spread(params[name].grad.cpu(), g32[name], g64[name], name)
 
 
 def test_overfitting_a_fixed_batch_reduces_the_loss(det_sd):
