@@ -88,6 +88,9 @@ _SIGS = {
     "ff_pwc_loss_scale": [_fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp, C.c_int,
                           C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_pwc_epe_mean": [_fp, _fp, C.c_int, C.c_float, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_pwc_loss_scale_sparse": [_fp, _fp, _fp, _fp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_pwc_epe_mean_sparse": [_fp, _fp, C.c_int, C.c_float, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_resize_to_nhwc4": [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_mask_prepare": [C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_chan_stats_fwd": [_fp, C.c_int, C.c_int, _ll, _fp, C.c_int, _fp, _fp],

@@ -6,6 +6,9 @@
 //   context   : m = (conv2d(mask/255, E, pad k/2) > 0) * image                          (:24-30)
 // G = get_kernel(KERNEL_SIZE, KERNEL_SIGMA) (:13-21), E = cv.getStructuringElement(MORPH_ELLIPSE, (k,k)) —
 // both tables are built on the host and passed in.
+// FF-PWC's init_mask (core/models/ff-pwcnet/PWCNet_Core/ff_pwcnet.py:61-110) is the same arithmetic on inputs that stay
+// in [0,255]: mode bit 2 (FF_MASK_RAW) leaves the [0,255] -> [-1,1] scaling out, mode bit 3 (FF_MASK_IMAGE_NHWC4) reads
+// the context image from an NHWC4 tensor (FF_PWCNET has already resized / repacked it).
 #pragma clang fp contract(off)
 #include "ff_common.h"
 
@@ -44,22 +47,32 @@ __global__ void mask_conv_kernel(const float* __restrict__ mask, const float* __
 
 // phase 2: write the NHWC4 scaled tensor
 __global__ void mask_finish_kernel(const float* __restrict__ tmp, const unsigned int* __restrict__ gmax,
-                                   const float* __restrict__ image, int mode, float* __restrict__ dst, int B, int HW) {
+                                   const float* __restrict__ image, int mode, int raw, int image_nhwc4, float* __restrict__ dst,
+                                   int B, int HW) {
     const long long total = (long long)B * HW;
     const float mx = __uint_as_float(*gmax);
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long b = i / HW, p = i - b * HW;
         f32x4 o;
         if (mode == 0) {                       // neighborG: m*255/max
-            const float v = scale255(__fdiv_rn(__fmul_rn(tmp[i], 255.f), mx));
+            const float m = __fdiv_rn(__fmul_rn(tmp[i], 255.f), mx);
+            const float v = raw ? m : scale255(m);
             o = (f32x4){v, v, v, 0.f};
         } else if (mode == 1) {                // neighborE: (dil > 0) * 255
-            const float v = scale255(tmp[i] > 0.f ? 255.f : 0.f);
+            const float m = tmp[i] > 0.f ? 255.f : 0.f;
+            const float v = raw ? m : scale255(m);
             o = (f32x4){v, v, v, 0.f};
         } else {                               // context: (dil > 0) * image
             const float k = tmp[i] > 0.f ? 1.f : 0.f;
-            const float* s = image + b * 3 * HW + p;
-            o = (f32x4){scale255(k * s[0]), scale255(k * s[HW]), scale255(k * s[2ll * HW]), 0.f};
+            float s0, s1, s2;
+            if (image_nhwc4) {
+                const f32x4 s = *reinterpret_cast<const f32x4*>(image + i * 4);
+                s0 = s[0], s1 = s[1], s2 = s[2];
+            } else {
+                const float* s = image + b * 3 * HW + p;
+                s0 = s[0], s1 = s[HW], s2 = s[2ll * HW];
+            }
+            o = raw ? (f32x4){k * s0, k * s1, k * s2, 0.f} : (f32x4){scale255(k * s0), scale255(k * s1), scale255(k * s2), 0.f};
         }
         *reinterpret_cast<f32x4*>(dst + i * 4) = o;
     }
@@ -69,7 +82,9 @@ __global__ void mask_finish_kernel(const float* __restrict__ tmp, const unsigned
 
 extern "C" int ff_mask_prepare(int mode, const float* mask, const float* image, const float* table, int ks, float* tmp,
                                unsigned int* gmax, float* dst_nhwc4, int B, int H, int W, void* stream) {
-    FF_REQUIRE(mode >= 0 && mode <= 2, "ff_mask_prepare: mode must be 0 (neighborG), 1 (neighborE) or 2 (context)");
+    const int raw = (mode >> 2) & 1, image_nhwc4 = (mode >> 3) & 1;
+    mode &= 3;
+    FF_REQUIRE(mode >= 0 && mode <= 2, "ff_mask_prepare: mode must be 0 (neighborG), 1 (neighborE) or 2 (context) [+ 4 raw, + 8 NHWC4 image]");
     FF_REQUIRE(mask && table && tmp && gmax && dst_nhwc4 && B > 0 && H > 0 && W > 0 && ks >= 1 && ks % 2 == 1,
                "ff_mask_prepare: bad argument (odd kernel size required)");
     FF_REQUIRE(mode != 2 || image, "ff_mask_prepare: context mode needs the image");
@@ -79,6 +94,6 @@ extern "C" int ff_mask_prepare(int mode, const float* mask, const float* image, 
     int g = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     (void)hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
     mask_conv_kernel<<<g, 256, 0, s>>>(mask, table, ks, mode == 0 ? 1.f : 255.f, tmp, gmax, B, H, W);
-    mask_finish_kernel<<<g, 256, 0, s>>>(tmp, gmax, image, mode, dst_nhwc4, B, H * W);
+    mask_finish_kernel<<<g, 256, 0, s>>>(tmp, gmax, image, mode, raw, image_nhwc4, dst_nhwc4, B, H * W);
     return ff::check_launch("ff_mask_prepare");
 }

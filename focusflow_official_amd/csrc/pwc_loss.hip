@@ -69,6 +69,11 @@ __device__ __forceinline__ float epe_value(float dx, float dy, int l1q, float ep
     return e;
 }
 
+// SPARSE (KITTI stage, losses.py:28-41, :58-67, :186-214): the target is down-sampled by sparse_max_pool (max of the
+// positive values minus max of the negated negative ones over the adaptive window), pixels whose pooled target is
+// exactly (0, 0) are invalid; `mask_over_batch` then means "the plain term counts valid pixels only" (EPELoss; MixLoss
+// sums the plain term over every pixel and only the key-point term over valid ones).
+template <bool SPARSE>
 __global__ void pwc_loss_scale_kernel(const float* __restrict__ out, const float* __restrict__ target, const float* __restrict__ gmask,
                                       const double* __restrict__ msum, float w_plain, float w_mask_num, int zero_if_empty,
                                       int mask_over_batch, int l1q, float eps, float q, float* __restrict__ grad, double* __restrict__ loss, int B, int H, int W, int h,
@@ -88,19 +93,36 @@ __global__ void pwc_loss_scale_kernel(const float* __restrict__ out, const float
         const int xs = (int)(((long long)x * W) / w), xe = (int)((((long long)x + 1) * W + w - 1) / w);
         float tx = 0.f, ty = 0.f;
         const float* t0 = target + b * 2 * H * W;
-        for (int yy = ys; yy < ye; ++yy)
-            for (int xx = xs; xx < xe; ++xx) {
-                tx += t0[(long long)yy * W + xx];
-                ty += t0[(long long)H * W + (long long)yy * W + xx];
-            }
-        const float inv = 1.f / (float)((ye - ys) * (xe - xs));
-        tx *= inv;
-        ty *= inv;
+        if (SPARSE) {
+            float px = 0.f, nx = 0.f, py = 0.f, ny = 0.f;      // max(t * (t > 0)), max(-t * (t < 0)): both >= 0
+            for (int yy = ys; yy < ye; ++yy)
+                for (int xx = xs; xx < xe; ++xx) {
+                    const float a = t0[(long long)yy * W + xx], c = t0[(long long)H * W + (long long)yy * W + xx];
+                    px = fmaxf(px, a);
+                    nx = fmaxf(nx, -a);
+                    py = fmaxf(py, c);
+                    ny = fmaxf(ny, -c);
+                }
+            tx = px - nx;
+            ty = py - ny;
+        } else {
+            for (int yy = ys; yy < ye; ++yy)
+                for (int xx = xs; xx < xe; ++xx) {
+                    tx += t0[(long long)yy * W + xx];
+                    ty += t0[(long long)H * W + (long long)yy * W + xx];
+                }
+            const float inv = 1.f / (float)((ye - ys) * (xe - xs));
+            tx *= inv;
+            ty *= inv;
+        }
+        const bool valid = !SPARSE || !(tx == 0.f && ty == 0.f);
         const long long o0 = (b * 2 * h + y) * w + x, o1 = o0 + (long long)h * w;
         float gx, gy;
         const float e = epe_value(tx - out[o0], ty - out[o1], l1q, eps, q, gx, gy);
         float gm = 0.f;
-        if (gmask) {
+        if (gmask && SPARSE) {
+            gm = valid ? gmask[i] : 0.f;
+        } else if (gmask) {
             if (mask_over_batch) {          // CPCL multiplies a (B,h,w) error map by a (B,1,h,w) mask (:114): broadcasting
                 const long long pix = i - b * (long long)h * w;            // pairs every sample with every sample's mask
                 for (int bb = 0; bb < B; ++bb) gm += gmask[(long long)bb * h * w + pix];
@@ -108,7 +130,7 @@ __global__ void pwc_loss_scale_kernel(const float* __restrict__ out, const float
                 gm = gmask[i];
             }
         }
-        const float wp = w_plain + w_mask * gm;
+        const float wp = ((SPARSE && mask_over_batch && !valid) ? 0.f : w_plain) + w_mask * gm;
         local += (double)(wp * e);
         if (grad) {           // d/d(out) = -d/d(d)
             grad[o0] = -wp * gx;
@@ -120,20 +142,28 @@ __global__ void pwc_loss_scale_kernel(const float* __restrict__ out, const float
     if ((threadIdx.x & 63) == 0) atomicAdd(loss, local);
 }
 
+// sparse != 0: only pixels whose target is not exactly (0, 0) count (realEPE with sparse=True, losses.py:33-37)
 __global__ void pwc_epe_mean_kernel(const float* __restrict__ pred, const float* __restrict__ target, int l1q, float eps, float q,
-                                    double* __restrict__ out2, int B, int H, int W) {
+                                    double* __restrict__ out2, int B, int H, int W, int sparse) {
     const long long hw = (long long)H * W, total = B * hw;
-    double local = 0.0;
+    double local = 0.0, cnt = 0.0;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long b = i / hw, p = i - b * hw;
+        const float tx = target[b * 2 * hw + p], ty = target[b * 2 * hw + hw + p];
+        if (sparse && tx == 0.f && ty == 0.f) continue;
         float gx, gy;
-        local += epe_value(target[b * 2 * hw + p] - pred[b * 2 * hw + p], target[b * 2 * hw + hw + p] - pred[b * 2 * hw + hw + p], l1q, eps, q,
-                           gx, gy);
+        local += epe_value(tx - pred[b * 2 * hw + p], ty - pred[b * 2 * hw + hw + p], l1q, eps, q, gx, gy);
+        cnt += 1.0;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out2, local);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out2 + 1, (double)total);
+    for (int o = 32; o > 0; o >>= 1) {
+        local += __shfl_xor(local, o);
+        cnt += __shfl_xor(cnt, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out2, local);
+        atomicAdd(out2 + 1, cnt);
+    }
 }
 
 inline unsigned grid_for(long long total) {
@@ -154,14 +184,30 @@ extern "C" int ff_pwc_loss_scale(const float* out, const float* target, const fl
                                  float w_mask_num, int zero_if_empty, int mask_over_batch, int l1q, float eps, float q, float* grad,
                                  double* loss, int B, int H, int W, int h, int w, void* stream) {
     FF_REQUIRE(out && target && loss && (!gmask || msum) && B > 0 && H >= h && W >= w && h > 0 && w > 0, "ff_pwc_loss_scale: bad argument");
-    pwc_loss_scale_kernel<<<grid_for((long long)B * h * w), 256, 0, static_cast<hipStream_t>(stream)>>>(out, target, gmask, msum, w_plain, w_mask_num,
-                                                                                                    zero_if_empty, mask_over_batch, l1q, eps, q, grad, loss, B, H, W, h, w);
+    pwc_loss_scale_kernel<false><<<grid_for((long long)B * h * w), 256, 0, static_cast<hipStream_t>(stream)>>>(out, target, gmask, msum, w_plain, w_mask_num,
+                                                                                                           zero_if_empty, mask_over_batch, l1q, eps, q, grad, loss, B, H, W, h, w);
     return ff::check_launch("ff_pwc_loss_scale");
+}
+
+extern "C" int ff_pwc_loss_scale_sparse(const float* out, const float* target, const float* gmask, const double* msum, float w_plain,
+                                        float w_mask_num, int zero_if_empty, int plain_valid_only, int l1q, float eps, float q, float* grad,
+                                        double* loss, int B, int H, int W, int h, int w, void* stream) {
+    FF_REQUIRE(out && target && loss && (!gmask || msum) && B > 0 && H >= h && W >= w && h > 0 && w > 0, "ff_pwc_loss_scale_sparse: bad argument");
+    pwc_loss_scale_kernel<true><<<grid_for((long long)B * h * w), 256, 0, static_cast<hipStream_t>(stream)>>>(out, target, gmask, msum, w_plain, w_mask_num,
+                                                                                                          zero_if_empty, plain_valid_only, l1q, eps, q, grad, loss, B, H, W, h, w);
+    return ff::check_launch("ff_pwc_loss_scale_sparse");
 }
 
 extern "C" int ff_pwc_epe_mean(const float* pred, const float* target, int l1q, float eps, float q, double* out2, int B, int H, int W,
                                void* stream) {
     FF_REQUIRE(pred && target && out2 && B > 0 && H > 0 && W > 0, "ff_pwc_epe_mean: bad argument");
-    pwc_epe_mean_kernel<<<grid_for((long long)B * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(pred, target, l1q, eps, q, out2, B, H, W);
+    pwc_epe_mean_kernel<<<grid_for((long long)B * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(pred, target, l1q, eps, q, out2, B, H, W, 0);
     return ff::check_launch("ff_pwc_epe_mean");
+}
+
+extern "C" int ff_pwc_epe_mean_sparse(const float* pred, const float* target, int l1q, float eps, float q, double* out2, int B, int H, int W,
+                                      void* stream) {
+    FF_REQUIRE(pred && target && out2 && B > 0 && H > 0 && W > 0, "ff_pwc_epe_mean_sparse: bad argument");
+    pwc_epe_mean_kernel<<<grid_for((long long)B * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(pred, target, l1q, eps, q, out2, B, H, W, 1);
+    return ff::check_launch("ff_pwc_epe_mean_sparse");
 }

@@ -408,15 +408,16 @@ def prep_input(src_nchw: Optional[Tensor], b, h, w, like: Tensor, fill: float = 
     return dst
 
 
-def mask_prepare(mode: int, mask_nchw: Tensor, image_nchw: Tensor, table: Tensor) -> Tensor:
-    """init_mask modes neighborG(0)/neighborE(1)/context(2) + scaling -> NHWC4."""
+def mask_prepare(mode: int, mask_nchw: Tensor, image: Tensor, table: Tensor, raw: bool = False, image_nhwc4: bool = False) -> Tensor:
+    """init_mask modes neighborG(0)/neighborE(1)/context(2) -> NHWC4; scaled to [-1,1] (FF-RAFT) or raw [0,255] (FF-PWC);
+    the context image is NCHW (B,3,H,W) or, with image_nhwc4, an NHWC4 tensor."""
     _require_gpu(mask_nchw)
     b, _, h, w = mask_nchw.shape
     dst = empty_nhwc(b, h, w, 4, mask_nchw)
     tmp = torch.empty((b, h, w), dtype=torch.float32, device=mask_nchw.device)
     gmax = torch.empty(1, dtype=torch.int32, device=mask_nchw.device)
-    _hip.call("ff_mask_prepare", mode, _p(mask_nchw.contiguous()), _p(image_nchw.contiguous()), _p(table), table.shape[0],
-              _p(tmp), _p(gmax), _p(dst), b, h, w, _stream())
+    _hip.call("ff_mask_prepare", mode | (4 if raw else 0) | (8 if image_nhwc4 else 0), _p(mask_nchw.contiguous()), _p(image.contiguous()),
+              _p(table), table.shape[0], _p(tmp), _p(gmax), _p(dst), b, h, w, _stream())
     return dst
 
 

@@ -19,12 +19,12 @@ class _ScaleLoss(torch.autograd.Function):
     """loss contribution of one pyramid level; the kernel returns value and gradient together."""
 
     @staticmethod
-    def forward(ctx, out, target, gmask, msum, w_plain, w_mask_num, zero_if_empty, over_batch, l1q, eps, q):
+    def forward(ctx, out, target, gmask, msum, w_plain, w_mask_num, zero_if_empty, over_batch, l1q, eps, q, sparse=False):
         b, _, h, w = out.shape
         oc = out.contiguous()
         grad = torch.empty_like(oc)
         loss = torch.zeros(1, dtype=torch.float64, device=out.device)
-        _hip.call("ff_pwc_loss_scale", _p(oc), _p(target), _p(gmask), _p(msum), float(w_plain), float(w_mask_num),
+        _hip.call("ff_pwc_loss_scale_sparse" if sparse else "ff_pwc_loss_scale", _p(oc), _p(target), _p(gmask), _p(msum), float(w_plain), float(w_mask_num),
                   int(zero_if_empty), int(over_batch), int(l1q), float(eps), float(q), _p(grad), _p(loss), b, target.shape[2], target.shape[3],
                   h, w, _stream())
         ctx.save_for_backward(grad)
@@ -33,7 +33,7 @@ class _ScaleLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return (grad * g,) + (None,) * 10
+        return (grad * g,) + (None,) * 11
 
 
 class EPELoss(nn.Module):
@@ -69,9 +69,8 @@ class EPELoss(nn.Module):
         return gmask, msum
 
     def realEPE(self, output, target, sparse=False):
-        """Mean error of the finest flow bilinearly resized to the target's size (:78-81, :121-138, :216-233)."""
-        if sparse:
-            raise NotImplementedError("sparse ground truth (KITTI stage) is not built on the HIP path")
+        """Mean error of the finest flow bilinearly resized to the target's size (:78-81, :121-138, :216-233); sparse: over
+        the pixels whose target is not exactly (0, 0) (:33-37)."""
         b, _, h, w = target.shape
         src = output.detach().permute(0, 2, 3, 1)                       # NHWC view (contiguous when it comes from FF_PWCNET)
         src = src if src.is_contiguous() or src.stride(3) == 1 else src.contiguous()
@@ -79,12 +78,18 @@ class EPELoss(nn.Module):
         _hip.call("ff_resize_bilinear", _p(src), ops._ld(src), 2, src.shape[1], src.shape[2], _p(up), b, h, w, 1.0, 1.0, _stream())
         out2 = torch.zeros(2, dtype=torch.float64, device=target.device)
         l1q, eps, q = self._mode()
-        _hip.call("ff_pwc_epe_mean", _p(up), _p(target.contiguous()), l1q, eps, q, _p(out2), b, h, w, _stream())
+        _hip.call("ff_pwc_epe_mean_sparse" if sparse else "ff_pwc_epe_mean", _p(up), _p(target.contiguous()), l1q, eps, q, _p(out2), b, h, w,
+                  _stream())
         return (out2[0] / out2[1]).float()
 
+    # sparse ground truth: the plain term counts valid pixels only (EPELoss, :33-41); MixLoss overrides (:186-214)
+    sparse_plain_valid_only = True
+
     def multiscaleEPE(self, network_output, target_flow, mask=None, sparse=False):
-        if sparse:
-            raise NotImplementedError("sparse ground truth (KITTI stage) is not built on the HIP path")
+        if sparse and self.mask_over_batch:
+            # CPCL with sparse=True indexes a (B,h,w) error map with the validity mask (1-D result) and then multiplies it
+            # by a convolution of that same boolean mask (losses.py:100-114): the reference itself raises there
+            raise NotImplementedError("CPCL with sparse ground truth fails in the reference too (losses.py:100-114)")
         if not isinstance(network_output, (tuple, list)):
             network_output = [network_output]
         assert len(self.weights) == len(network_output)
@@ -98,7 +103,8 @@ class EPELoss(nn.Module):
             if self.uses_mask:
                 gmask, msum = self._mask_map(mask, h, w)
             wp, wm, zero = self._level_weights(weight, b, h, w)
-            loss = loss + _ScaleLoss.apply(output, target_flow, gmask, msum, wp, wm, zero, self.mask_over_batch, l1q, eps, q)
+            flag = self.sparse_plain_valid_only if sparse else self.mask_over_batch
+            loss = loss + _ScaleLoss.apply(output, target_flow, gmask, msum, wp, wm, zero, flag, l1q, eps, q, bool(sparse))
         return loss
 
     def forward(self, output, target, *args, sparse=False):
@@ -131,6 +137,7 @@ class CPCL(EPELoss):
 class MixLoss(EPELoss):
     """losses.py:167-258: plain error sum + lamda * key-point-weighted term."""
     uses_mask = True
+    sparse_plain_valid_only = False      # :204-214: EPE_map.sum() runs over every pixel, only the masked term drops invalid ones
 
     def __init__(self, cfg):
         super().__init__(cfg)

@@ -351,8 +351,10 @@ class FF_PWCNET(nn.Module):
         _hip.load()
         if cfg.MODEL.FUSION != "parallel":
             raise NotImplementedError(f"FF_PWCNET only support parallel fusion, but got {cfg.MODEL.FUSION}")
-        if getattr(cfg.TRAIN, "MASK_MODAL", "point") != "point":
-            raise NotImplementedError("FF_PWCNET on HIP: only MASK_MODAL='point' is built")
+        self.mask_modal = getattr(cfg.TRAIN, "MASK_MODAL", "point")
+        if self.mask_modal not in ("point", "frame", "neighborG", "neighborE", "context"):
+            raise ValueError(f"MASK_MODAL={self.mask_modal!r} is not one of point/frame/neighborG/neighborE/context")
+        self._table = None
         self.fusion_type = cfg.MODEL.FUSION_TYPE
         self.cfg = cfg
         self.netExtractor = Extractor(self.fusion_type)
@@ -382,12 +384,30 @@ class FF_PWCNET(nn.Module):
         # preprocess (ff_pwcnet.py:391-403): bilinear resize to the next multiples of 64, a no-op when they already are
         h, w = (h0 + 63) // 64 * 64, (w0 + 63) // 64 * 64
         self.origin_H, self.origin_W, self.new_H, self.new_W = h0, w0, h, w
-        if (h, w) == (h0, w0):
+        resized = (h, w) != (h0, w0)
+        if not resized:
             i1, i2 = self._nhwc4(tenOne, b, h, w, tenOne), self._nhwc4(tenTwo, b, h, w, tenOne)
-            m1 = self._nhwc4(mask1, b, h, w, tenOne)                  # 'point': repeat to 3 channels
         else:
-            i1, i2, m1 = self._resized4(tenOne, b, h, w), self._resized4(tenTwo, b, h, w), self._resized4(mask1, b, h, w)
-        m2 = self._nhwc4(None, b, h, w, tenOne, fill=255.0)           # ones_like(mask1) * 255
+            i1, i2 = self._resized4(tenOne, b, h, w), self._resized4(tenTwo, b, h, w)
+        # init_mask (ff_pwcnet.py:61-110) on the PRE-PROCESSED inputs (:406-408); values stay in [0,255]
+        modal = self.mask_modal
+        if modal == "point":                                          # repeat to 3 channels; mask2 = 255
+            m1 = self._resized4(mask1, b, h, w) if resized else self._nhwc4(mask1, b, h, w, tenOne)
+            m2 = self._nhwc4(None, b, h, w, tenOne, fill=255.0)
+        elif modal == "frame":                                        # :107-109: the masks are the frames
+            m1, m2 = i1, i2
+        else:
+            from .model import MASK_MODES, ellipse_table, gaussian_table
+            if self._table is None or self._table.device != tenOne.device:
+                t = self.cfg.TRAIN
+                tab = gaussian_table(t.KERNEL_SIZE, t.KERNEL_SIGMA) if modal == "neighborG" else ellipse_table(t.MASK_DILATE)
+                self._table = tab.to(tenOne.device)
+            mk = mask1.contiguous()
+            if resized:                                               # (B,1,H,W) NCHW is NHWC with one channel
+                mk = torch.empty((b, 1, h, w), dtype=torch.float32, device=tenOne.device)
+                _hip.call("ff_resize_bilinear", _p(mask1.contiguous()), 1, 1, h0, w0, _p(mk), b, h, w, 1.0, 1.0, _stream())
+            m1 = ops.mask_prepare(MASK_MODES[modal], mk, i1, self._table, raw=True, image_nhwc4=True)
+            m2 = i2 if modal == "context" else self._nhwc4(None, b, h, w, tenOne, fill=255.0)
         decoders = ((6, self.netSix), (5, self.netFiv), (4, self.netFou), (3, self.netThr), (2, self.netTwo))
         est = None
         flows = []

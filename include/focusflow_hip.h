@@ -321,11 +321,22 @@ int ff_pwc_loss_scale(const float* out, const float* target, const float* gmask,
                       double* loss, int B, int H, int W, int h, int w, void* stream);
 int ff_pwc_epe_mean(const float* pred, const float* target, int l1q, float eps, float q, double* out2, int B, int H, int W,
                     void* stream);
+/* Sparse ground truth (KITTI stage, ff-pwcnet/train.py:287-312 passes sparse=True; losses.py:28-41, :58-67, :186-214):
+ *   ff_pwc_loss_scale_sparse  as ff_pwc_loss_scale with the target down-sampled by sparse_max_pool (:44-57) and pixels
+ *                             whose pooled target is exactly (0, 0) invalid: the key-point term counts valid pixels only;
+ *                             plain_valid_only != 0: so does the plain term (EPELoss; MixLoss keeps it over every pixel)
+ *   ff_pwc_epe_mean_sparse    out2 += { sum of E over pixels whose target is not exactly (0, 0), their count } */
+int ff_pwc_loss_scale_sparse(const float* out, const float* target, const float* gmask, const double* msum, float w_plain,
+                             float w_mask_num, int zero_if_empty, int plain_valid_only, int l1q, float eps, float q, float* grad,
+                             double* loss, int B, int H, int W, int h, int w, void* stream);
+int ff_pwc_epe_mean_sparse(const float* pred, const float* target, int l1q, float eps, float q, double* out2, int B, int H, int W,
+                           void* stream);
 
 /* init_mask modes neighborG (0) / neighborE (1) / context (2), ff_raft.py:23-72, fused with the
  * [0,255] -> [-1,1] scaling: mask (B,1,H,W) [+ image (B,3,H,W)] -> NHWC4.  `table` = host-built k x k
  * Gaussian (get_kernel, :13-21) or ellipse structuring element; tmp (B*H*W floats) and gmax (1 word)
- * are caller-provided scratch. */
+ * are caller-provided scratch.  mode: 0 neighborG, 1 neighborE, 2 context; + 4: leave the values in [0,255] (FF-PWC's
+ * init_mask, core/models/ff-pwcnet/PWCNet_Core/ff_pwcnet.py:61-110, does not normalise); + 8: `image` is NHWC4. */
 int ff_mask_prepare(int mode, const float* mask, const float* image, const float* table, int ks, float* tmp,
                     unsigned int* gmax, float* dst_nhwc4, int B, int H, int W, void* stream);
 

@@ -117,14 +117,17 @@ def pwc_refiner(sd, p, feat):
     return x
 
 
-def ffpwc_forward(sd, image1, image2, mask1, mask2=None, test_mode=False, mask_channel=3, fusion_type="1x1conv"):
-    """ff_pwcnet.py:405-433 with 'point' masks, including preprocess (:391-403): sizes that are not multiples of 64
-    are bilinearly resized first.  Inputs stay in [0,255] (FF-PWC does not normalise)."""
+def ffpwc_forward(sd, image1, image2, mask1, mask2=None, test_mode=False, mask_channel=3, fusion_type="1x1conv",
+                  mask_modal="point", dilate=31, kernel_size=31, kernel_sigma=5):
+    """ff_pwcnet.py:405-433, including preprocess (:391-403): sizes that are not multiples of 64 are bilinearly resized
+    first; then init_mask (:61-110) on the resized inputs - the same five modes as FF-RAFT's (ffraft_ref.init_mask
+    restates both: the two functions differ only in names).  Inputs stay in [0,255] (FF-PWC does not normalise)."""
+    from .ffraft_ref import init_mask
     b, _, h0, w0 = image1.shape
     h, w = -(-h0 // 64) * 64, -(-w0 // 64) * 64
     image1, image2, mask1 = (F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False) for t in (image1, image2, mask1))
-    m1 = mask1.repeat(1, mask_channel, 1, 1)
-    m2 = torch.ones_like(m1) * 255
+    m1, m2 = init_mask(image1, image2, mask1, mask_modal, mask_channel, dilate, kernel_size, kernel_sigma)
+    m1, m2 = m1.to(image1.dtype), m2.to(image1.dtype)
     f1 = pwc_extractor(sd, "netExtractor", image1, m1, fusion_type)
     f2 = pwc_extractor(sd, "netExtractor", image2, m2, fusion_type)
     est = None

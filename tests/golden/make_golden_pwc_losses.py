@@ -46,6 +46,29 @@ def main():
                 for i, p in enumerate(ps):
                     out[f"{tag}_grad{i}"] = p.grad.numpy()
                 print(tag, loss.item(), float(res["epe"]))
+    # sparse ground truth (KITTI stage: train.py:287-312 calls the loss with sparse=True): EPELoss and MixLoss (CPCL raises
+    # in the reference itself).  About a third of the target pixels are "invalid" = exactly (0, 0).
+    drop = torch.rand(B, 1, H, W, generator=g) < 0.35
+    starget = torch.where(drop, torch.zeros_like(target), target)
+    out["sparse_target"] = starget.numpy()
+    for lt in ("EPELoss", "MixLoss"):
+        for mode in ("pretrain", "finetune"):
+            ks, sigma = (1, 0.01) if lt == "EPELoss" else (5, 1.7)
+            crit = build_losses(cfg(lt, mode, ks, sigma))
+            ps = [p.clone().requires_grad_(True) for p in preds]
+            loss, res = crit(ps, starget, True) if lt == "EPELoss" else crit(ps, starget, mask, True)
+            loss.backward()
+            tag = f"sparse_{lt}_{mode}_k{ks}"
+            out[tag + "_loss"] = np.array([loss.item(), float(res["epe"])], dtype=np.float64)
+            for i, p in enumerate(ps):
+                out[f"{tag}_grad{i}"] = p.grad.numpy()
+            print(tag, loss.item(), float(res["epe"]))
+    try:
+        build_losses(cfg("CPCL", "pretrain", 5, 1.7))([p.clone() for p in preds], starget, mask, True)
+        out["sparse_CPCL_raises"] = np.array([0])
+    except Exception as e:  # noqa: BLE001
+        print("CPCL sparse in the reference raises:", type(e).__name__, str(e)[:80])
+        out["sparse_CPCL_raises"] = np.array([1])
     np.savez_compressed(os.path.join(HERE, "pwc_losses.npz"), **out)
 
 

@@ -75,5 +75,35 @@ def test_pwc_multiscale_losses_match_reference(tag):
     for i, p in enumerate(preds):
         want = g[f"{tag}_grad{i}"]
         np.testing.assert_allclose(p.grad.cpu().numpy(), want, rtol=2e-4, atol=2e-6 * float(np.abs(want).max()), err_msg=f"level {i}")
-    with pytest.raises(NotImplementedError):
-        crit(preds, target, True) if lt == "EPELoss" else crit(preds, target, mask, True)
+    if lt == "CPCL":      # sparse ground truth: the reference's CPCL raises (losses.py:100-114), so does this one
+        assert int(g["sparse_CPCL_raises"][0]) == 1
+        with pytest.raises(NotImplementedError):
+            crit(preds, target, mask, True)
+
+
+@pytest.mark.parametrize("tag", ["sparse_EPELoss_pretrain_k1", "sparse_EPELoss_finetune_k1", "sparse_MixLoss_pretrain_k5",
+                                 "sparse_MixLoss_finetune_k5"])
+def test_pwc_sparse_losses_match_reference(tag):
+    """Sparse ground truth (KITTI stage, ff-pwcnet/train.py:287-312): sparse_max_pool of the target, pixels whose pooled
+    target is exactly (0, 0) are invalid (losses.py:28-41, :44-57, :186-214) - loss, 'epe' and every gradient vs the
+    reference's own classes called with sparse=True."""
+    from argparse import Namespace
+    from conftest import load_golden
+    from focusflow_official_amd import pwc_losses
+    g = load_golden("pwc_losses")
+    _, lt, mode, k = tag.split("_")
+    ks, sigma = (1, 0.01) if k == "k1" else (5, 1.7)
+    cfg = Namespace(TRAIN=Namespace(LOSS_TYPE=lt, LOSS_MODE=mode, LOSS_WEIGHTS=[0.005, 0.01, 0.02, 0.08, 0.32], LOSS_Q=0.4,
+                                    LOSS_EPSILON=0.01, LOSS_KERNEL_SIZE=ks, LOSS_SIGMA=sigma, LOSS_LAMDA=0.7))
+    crit = pwc_losses.build_losses(cfg)
+    target = torch.from_numpy(g["sparse_target"]).to(DEV)
+    mask = torch.from_numpy(g["mask"]).to(DEV)
+    preds = [torch.from_numpy(g[f"pred{i}"]).to(DEV).requires_grad_(True) for i in range(5)]
+    loss, res = crit(preds, target, True) if lt == "EPELoss" else crit(preds, target, mask, True)
+    loss.backward()
+    want_loss, want_epe = g[tag + "_loss"]
+    assert abs(loss.item() - want_loss) < 2e-5 * abs(want_loss), (loss.item(), want_loss)
+    assert abs(float(res["epe"]) - want_epe) < 2e-5 * abs(want_epe)
+    for i, p in enumerate(preds):
+        want = g[f"{tag}_grad{i}"]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want, rtol=2e-4, atol=2e-6 * float(np.abs(want).max()), err_msg=f"level {i}")

@@ -236,3 +236,40 @@ def test_ffpwcnet_training_step_gradients_match_oracle():
         err = float((got.cpu().double() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
         assert err < 5e-3, f"{n}: relative error {err:.3e}"
     assert all(p.grad is not None for p in m.parameters())
+
+
+@pytest.mark.parametrize("modal", ["frame", "neighborG", "neighborE", "context"])
+def test_ffpwcnet_mask_modes(modal):
+    """FF-PWC's init_mask modes other than 'point' (ff_pwcnet.py:61-110), applied to the pre-processed (resized) inputs,
+    values left in [0,255].  'frame' and 'neighborG' against the REFERENCE's own FF_PWCNET (tests/golden/
+    make_golden_pwc_masks.py); all four against the oracle ('neighborE' / 'context' use OpenCV's ellipse element, which is
+    restated from its published algorithm: unpinned)."""
+    from argparse import Namespace
+    from conftest import load_golden
+    from focusflow_official_amd.pwcnet import FF_PWCNET
+    cfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL=modal, KERNEL_SIZE=9, KERNEL_SIGMA=1.5, MASK_DILATE=7),
+                    MODEL=Namespace(FUSION="parallel", FUSION_TYPE="1x1conv"))
+    sd = _pwc_weights()
+    m = FF_PWCNET(cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    g = load_golden("pwc_mask_modes") if modal in ("frame", "neighborG") else None
+    for tag, (b, h, w), seed in (("128x192", (1, 128, 192), 14), ("100x180", (1, 100, 180), 15)):
+        gen = torch.Generator().manual_seed(seed)                      # = make_golden_pwc.inputs(b, h, w, seed)
+        base = torch.rand(b, 3, h // 4 + 4, w // 4 + 4, generator=gen)
+        i1 = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear", align_corners=False) * 255
+        i2 = torch.roll(i1, shifts=(2, -3), dims=(2, 3))
+        m1 = (torch.rand(b, 1, h, w, generator=gen) < 0.02).float() * 255
+        with torch.no_grad():
+            got = m(i1.to(DEV), i2.to(DEV), m1.to(DEV), torch.zeros_like(m1).to(DEV))
+            got_full = m(i1.to(DEV), i2.to(DEV), m1.to(DEV), torch.zeros_like(m1).to(DEV), test_mode=True)
+            ref = pwc_ref.ffpwc_forward(sd, i1, i2, m1, mask_modal=modal, dilate=7, kernel_size=9, kernel_sigma=1.5)
+            ref_full = pwc_ref.ffpwc_forward(sd, i1, i2, m1, test_mode=True, mask_modal=modal, dilate=7, kernel_size=9, kernel_sigma=1.5)
+        close(got[0].cpu(), ref[0], tol=2e-4, what=f"{modal} {tag} finest flow vs oracle")
+        close(got_full.cpu(), ref_full, tol=2e-4, what=f"{modal} {tag} test_mode flow vs oracle")
+        if g is not None:
+            import zlib
+            crc = lambda t: zlib.crc32(t.contiguous().numpy().tobytes())  # noqa: E731
+            assert [crc(i1), crc(i2), crc(m1)] == g[f"{modal}_{tag}_in_crc"].tolist(), "synthetic inputs drifted"
+            close(got[0].cpu(), g[f"{modal}_{tag}_flow2"], tol=2e-4, what=f"{modal} {tag} finest flow vs reference")
+            close(got_full.cpu(), g[f"{modal}_{tag}_full"], tol=2e-4, what=f"{modal} {tag} test_mode flow vs reference")

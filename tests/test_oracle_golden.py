@@ -303,3 +303,27 @@ def test_config5_544x960_it32_matches_reference_and_fp16_pyramid_definition():
         assert torch.equal(hi, torch.nn.functional.avg_pool2d(lo, 2, stride=2).half().float())
     full = orc.corr_pyramid(vol)
     assert torch.equal(pyr[0], full[0].half().float()) and (pyr[1] - full[1]).abs().max() <= 2.0 ** -10 * full[1].abs().max()
+
+
+@pytest.mark.parametrize("modal", ["frame", "neighborG"])
+def test_pwc_oracle_mask_modes_match_reference(modal):
+    """oracle/pwc_ref.py with FF-PWC's non-'point' init_mask modes against the reference's own FF_PWCNET
+    (tests/golden/make_golden_pwc_masks.py; cost volume = the oracle's, as in every FF-PWC fixture)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import pwc_ref
+    from test_hip_pwc import _pwc_weights
+    g = load_golden("pwc_mask_modes")
+    sd = _pwc_weights()
+    for tag, (b, h, w), seed in (("128x192", (1, 128, 192), 14), ("100x180", (1, 100, 180), 15)):
+        gen = torch.Generator().manual_seed(seed)
+        base = torch.rand(b, 3, h // 4 + 4, w // 4 + 4, generator=gen)
+        i1 = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear", align_corners=False) * 255
+        i2 = torch.roll(i1, shifts=(2, -3), dims=(2, 3))
+        m1 = (torch.rand(b, 1, h, w, generator=gen) < 0.02).float() * 255
+        assert [crc(i1), crc(i2), crc(m1)] == g[f"{modal}_{tag}_in_crc"].tolist()
+        with torch.no_grad():
+            full = pwc_ref.ffpwc_forward(sd, i1, i2, m1, test_mode=True, mask_modal=modal, dilate=7, kernel_size=9, kernel_sigma=1.5)
+            flows = pwc_ref.ffpwc_forward(sd, i1, i2, m1, mask_modal=modal, dilate=7, kernel_size=9, kernel_sigma=1.5)
+        np.testing.assert_allclose(full.numpy(), g[f"{modal}_{tag}_full"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(flows[0].numpy(), g[f"{modal}_{tag}_flow2"], rtol=0, atol=2e-6)
