@@ -92,6 +92,7 @@ _SIGS = {
                                  C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_pwc_epe_mean_sparse": [_fp, _fp, C.c_int, C.c_float, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_resize_to_nhwc4": [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_png_unfilter": [_fp, _ll, C.c_int, C.c_int, C.c_int, _fp],
     "ff_mask_prepare": [C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_chan_stats_fwd": [_fp, C.c_int, C.c_int, _ll, _fp, C.c_int, _fp, _fp],
     "ff_chan_stats_bwd": [_fp, C.c_int, _fp, C.c_int, _ll, _fp, C.c_int, _fp],

@@ -116,6 +116,26 @@ class PackedConv:
         return ops.unpack_conv_wgrad(dwp, cv.out_channels, self.cin, self.kh, self.kw, self.cin_pad, off)
 
 
+def invalidate_packed(module: nn.Module) -> int:
+    """Drop every cached derived tensor under `module`: packed / split conv weights (PackedConv) and folded BatchNorm
+    coefficients (ops.bn_fold).  The caches are keyed on the parameters' version counters and storage, which an in-place
+    write through `.data` (EMA weight swaps, `weight.data.clamp_()`, legacy optimisers) does not change - call this
+    after such an update.  `load_state_dict` and `train()` / `eval()` of the top-level modules call it themselves.
+    Returns the number of caches dropped."""
+    n = 0
+    for m in module.modules():
+        for v in vars(m).values():
+            vs = v if isinstance(v, (list, tuple)) else (v,)
+            for pc in vs:
+                if isinstance(pc, PackedConv):
+                    pc._key = pc._dkey = None
+                    n += 1
+        if hasattr(m, "_ff_fold"):
+            del m._ff_fold
+            n += 1
+    return n
+
+
 def _make_norm(kind: str, c: int):
     if kind == "batch":
         return nn.BatchNorm2d(c)

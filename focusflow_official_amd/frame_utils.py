@@ -70,6 +70,22 @@ _PNG_SIG = b"\x89PNG\r\n\x1a\n"
 
 
 def _unfilter(raw, h, stride, bpp):
+    """PNG scan-line reconstruction.  The per-byte recurrences of filter types 1, 3 and 4 are native code
+    (ff_png_unfilter in libfocusflow_hip.so, host side: a 1242x375 RGB16 KITTI map is 2.8 M dependent steps - seconds per
+    sample in a Python loop, which would starve the GPU); the Python loop below is the fallback when the library has
+    not been built."""
+    try:
+        from . import _hip
+        lib = _hip.load()
+    except Exception:  # noqa: BLE001  (library not built: keep the loader usable)
+        lib = None
+    if lib is not None:
+        buf = np.frombuffer(raw, np.uint8)
+        out = np.empty((h, stride), np.uint8)
+        rc = lib.ff_png_unfilter(buf.ctypes.data, len(buf), h, stride, bpp, out.ctypes.data)
+        if rc != 0:
+            raise ValueError("PNG: " + lib.ff_last_error().decode())
+        return out
     out = np.zeros((h, stride), np.uint8)
     prev = np.zeros(stride, np.int32)
     pos = 0

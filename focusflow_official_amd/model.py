@@ -72,6 +72,22 @@ class FF_RAFT_FUSION(nn.Module):
             self.freeze_self()
             print("freeze flow net.")
 
+    # Derived tensors (packed / split weights, folded BatchNorm) are cached per parameter version; the two entry points
+    # below are where weights change wholesale, and `invalidate_packed()` is the explicit call for in-place `.data`
+    # updates that leave the version counters alone.
+    def invalidate_packed(self) -> int:
+        from .cce import invalidate_packed
+        return invalidate_packed(self)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed()
+        return super().train(mode)
+
     def forward(self, image1, image2, mask1, mask2, raft_iters=12, flow_init=None, test_mode=False):
         b, c, h, w = image1.shape
         assert mask1.shape[1] == 1  # ff_raft.py:34

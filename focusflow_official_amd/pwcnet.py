@@ -365,6 +365,22 @@ class FF_PWCNET(nn.Module):
         if load_pwcnet is not None:
             self.load_state_dict(torch.load(load_pwcnet), strict=False)
 
+    # Derived tensors (packed / split weights, folded BatchNorm) are cached per parameter version; the two entry points
+    # below are where weights change wholesale, and `invalidate_packed()` is the explicit call for in-place `.data`
+    # updates that leave the version counters alone.
+    def invalidate_packed(self) -> int:
+        from .cce import invalidate_packed
+        return invalidate_packed(self)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed()
+        return super().train(mode)
+
     def _nhwc4(self, t, b, h, w, like, fill=0.0):
         dst = ops.empty_nhwc(b, h, w, 4, like)
         _hip.call("ff_nchw_to_nhwc4", _p(t.contiguous() if t is not None else None), t.shape[1] if t is not None else 0,

@@ -379,6 +379,11 @@ int ff_scale_add_fwd(const float* v, int v_ld, const float* s, int s_ld, const f
 int ff_scale_add_bwd(const float* gout, int g_ld, const float* v, int v_ld, const float* s, int s_ld, const float* s2,
                      float* gv, int gv_ld, float* gs, float* scratch, int C, int B, int HW, int mode, void* stream);
 
+/* Host-side (CPU) helper of the data loaders: PNG scan-line reconstruction for the 16-bit KITTI flow maps
+ * (core/utils/frame_utils.py:102-120 decodes them with cv2).  raw = inflated IDAT stream, h rows of 1 + stride bytes;
+ * out = h x stride reconstructed bytes; bpp = bytes per complete pixel.  HOST pointers; no GPU involved. */
+int ff_png_unfilter(const unsigned char* raw, long long raw_len, int h, int stride, int bpp, unsigned char* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -323,3 +323,45 @@ def test_input_padder_and_forward_interpolate_against_reference():
     f = torch.randn(2, 14, 18, generator=gen) * 2
     assert np.array_equal(f.numpy(), g["fi_in"])
     assert np.array_equal(forward_interpolate(f).numpy(), g["fi_out"])
+
+
+def test_png_unfilter_native_matches_python_loop_for_every_filter_type(monkeypatch):
+    """frame_utils._unfilter: the native scan-line reconstruction (ff_png_unfilter, host code in libfocusflow_hip.so)
+    against the pure-Python recurrences, on a stream that uses all five PNG filter types, 8- and 16-bit RGB."""
+    import numpy as np
+    from focusflow_official_amd import _hip, frame_utils
+    rng = np.random.default_rng(5)
+    for bpp, w in ((6, 37), (3, 50), (2, 9)):
+        h, stride = 23, w * bpp
+        rows = []
+        for y in range(h):
+            rows.append(bytes([y % 5]) + rng.integers(0, 256, stride, dtype=np.uint8).tobytes())
+        raw = b"".join(rows)
+        native = frame_utils._unfilter(raw, h, stride, bpp)
+        monkeypatch.setattr(_hip, "load", lambda: (_ for _ in ()).throw(RuntimeError("no library")))
+        slow = frame_utils._unfilter(raw, h, stride, bpp)
+        monkeypatch.undo()
+        assert native.dtype == np.uint8 and np.array_equal(native, slow)
+
+
+def test_invalidate_packed_drops_every_cache():
+    """packed / split weights are cached per parameter version; writes through `.data` do not bump it, so the
+    modules expose invalidate_packed() and call it from load_state_dict / train()."""
+    from argparse import Namespace
+    from focusflow_official_amd import FF_RAFT_FUSION
+    from focusflow_official_amd.cce import PackedConv
+    cfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"), MODEL=Namespace(FUSION_TYPE="1x1conv", LOAD_MODULE_TO_BRANCH=False))
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg)
+    pcs = [v for mod in m.modules() for v in vars(mod).values() if isinstance(v, PackedConv)]
+    assert len(pcs) > 90
+    for pc in pcs:
+        pc._key = pc._dkey = ("stale",)
+    assert m.invalidate_packed() >= len(pcs) and all(pc._key is None and pc._dkey is None for pc in pcs)
+    for pc in pcs:
+        pc._key = ("stale",)
+    m.load_state_dict(m.state_dict())
+    assert all(pc._key is None for pc in pcs)
+    for pc in pcs:
+        pc._key = ("stale",)
+    m.eval()
+    assert all(pc._key is None for pc in pcs)
