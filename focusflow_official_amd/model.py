@@ -82,6 +82,12 @@ class FF_RAFT_FUSION(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self.invalidate_packed()
+        # the default conv arithmetic splits a weight as f16(16 w) + residual: |w| must stay below 4094 (ff_common.h).
+        # Checked where weights arrive wholesale (one reduction), not per step.
+        big = [k for k, v in self.state_dict().items() if v.dim() == 4 and float(v.abs().max()) >= 4094.0] if ops.w_format() else []
+        if big:
+            raise ValueError(f"conv weights beyond the range of the f16x3 split format (|w| >= 4094): {big[:3]}; "
+                             "use FF_CONV_PRECISION=fp32 for this checkpoint")
         return out
 
     def train(self, mode: bool = True):
