@@ -24,4 +24,8 @@ with torch.no_grad():
         out = m(i1, i2, m1, m1, test_mode=True)
     torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print(f"FF-PWC forward B={b} 448x1024: {dt * 1e3:.2f} ms/step = {b / dt:.1f} frame-pairs/s, finite={bool(torch.isfinite(out).all())}")
+print(f"FF-PWC forward B={b} 448x1024: {dt * 1e3:.2f} ms/step = {b / dt:.1f} frame-pairs/s, finite={bool(torch.isfinite(out).all())}", file=sys.stderr)
+import json
+print(json.dumps({"metric": "frame-pairs/sec FF-PWC forward 448x1024 (BASELINE configs[3])", "value": round(b / dt, 2), "unit": "frame-pairs/s",
+                  "n_gpus": 1, "steps": n, "warmup": 3, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": "f32 via fp16x3 split operands",
+                  "data": "synthetic", "config": {"workload": f"FF_PWCNET forward (test_mode), {b} pair(s) 448x1024, SIFT-like mask (2000 points), random-init weights"}}))
