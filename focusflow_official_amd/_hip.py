@@ -28,6 +28,7 @@ class FFConvParams(C.Structure):
         ("act", C.c_int), ("act_res", C.c_int), ("w_format", C.c_int),
         ("dil_h", C.c_int), ("dil_w", C.c_int), ("x_amax", _fp),
         ("in_scale", _fp), ("in_shift", _fp), ("in_act", C.c_int),
+        ("res2", _fp), ("res2_ld", C.c_int), ("res_split", C.c_int),
     ]
 
 

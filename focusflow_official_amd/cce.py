@@ -116,6 +116,9 @@ class PackedConv:
         return ops.unpack_conv_wgrad(dwp, cv.out_channels, self.cin, self.kh, self.kw, self.cin_pad, off)
 
 
+_PAIR_FUSION = os.environ.get("FF_PAIR_FUSION", "1") != "0"   # both 1x1 convs of a fusion unit in one launch (inference)
+
+
 def invalidate_packed(module: nn.Module) -> int:
     """Drop every cached derived tensor under `module`: packed / split conv weights (PackedConv) and folded BatchNorm
     coefficients (ops.bn_fold).  The caches are keyed on the parameters' version counters and storage, which an in-place
@@ -132,6 +135,9 @@ def invalidate_packed(module: nn.Module) -> int:
                     n += 1
         if hasattr(m, "_ff_fold"):
             del m._ff_fold
+            n += 1
+        if getattr(m, "_pair_key", None) is not None:
+            m._pair_key = None
             n += 1
     return n
 
@@ -237,7 +243,34 @@ class FusionUnit(nn.Module):
         else:
             raise ValueError(f"Fusion type {fusion_type} not supported.")
 
+    def _paired(self):
+        """Both 1x1 convs of the unit as one packed weight over the input segments [img, mask] (2C channels):
+        rows 0..C-1 (img') read the mask channels, rows C..2C-1 (mask') the img channels - an anti-diagonal block
+        matrix.  Rebuilt when a parameter changes (same cache key as PackedConv)."""
+        a, b = self.mask2img.conv, self.img2mask.conv
+        key = (ops.conv_precision(),) + tuple((t._version, t.data_ptr()) for t in (a.weight, a.bias, b.weight, b.bias))
+        if getattr(self, "_pair_key", None) != key:
+            c = a.out_channels
+            wf = torch.zeros((2 * c, 2 * c, 1, 1), dtype=torch.float32, device=a.weight.device)
+            wf[:c, c:] = a.weight.detach()       # img' <- mask
+            wf[c:, :c] = b.weight.detach()       # mask' <- img
+            rows = torch.empty((2 * c, 2 * c), dtype=torch.float32, device=wf.device)
+            ops.pack_conv_weight(wf, rows, 2 * c, 0)
+            self._pair_w = ops.pack_split(rows)
+            self._pair_b = torch.cat([a.bias.detach(), b.bias.detach()]).contiguous()
+            self._pair_key = key
+        return self._pair_w, self._pair_b
+
     def run(self, mask, img):
+        if (_PAIR_FUSION and self.fusion_type == "1x1conv" and self.img2mask is not None and not torch.is_grad_enabled()
+                and ops.w_format() != 0 and img.shape[3] % 32 == 0 and img.shape == mask.shape):
+            # inference: ONE launch for img' = img + conv(mask) and mask' = mask + conv(img).  The two separate launches
+            # read both tensors twice (once as input, once as residual) and are HBM-bound at 192x256; here every tensor
+            # is read once from HBM (the residual read hits L2) at the price of the zero blocks' MFMAs, which were idle.
+            c = img.shape[3]
+            w, bias = self._paired()
+            y = ops.conv2d([img, mask], w, bias, 2 * c, 1, 1, res=img, res2=mask, res_split=c, w_fmt=ops.w_format())
+            return y[..., c:], y[..., :c]
         if self.fusion_type in ("SA", "CA"):
             img_out = self.mask2img.run(img, mask)
             mask_out = self.img2mask.run(mask, img) if self.img2mask is not None else mask

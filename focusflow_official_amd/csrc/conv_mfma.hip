@@ -22,6 +22,7 @@
 //
 // The fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision), which
 // is what lets the path hold the reference's fp32 results to ~1e-6.
+#include <cstdlib>
 #include "ff_common.h"
 
 namespace {
@@ -271,7 +272,7 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     const int Ho = (p.H + 2 * p.pad_h - dlh * (p.KH - 1) - 1) / p.stride + 1, Wo = (p.W + 2 * p.pad_w - dlw * (p.KW - 1) - 1) / p.stride + 1;
     FF_REQUIRE(Ho == p.Ho && Wo == p.Wo, "ff_conv2d_fwd: output %dx%d does not match conv arithmetic %dx%d", p.Ho, p.Wo, Ho, Wo);
     FF_REQUIRE(p.y_ld >= p.Cout, "ff_conv2d_fwd: y_ld %d < Cout %d", p.y_ld, p.Cout);
-    FF_REQUIRE(!p.res || p.res_ld >= p.Cout, "ff_conv2d_fwd: res_ld too small");
+    FF_REQUIRE(!p.res || p.res_ld >= (p.res2 ? p.res_split : p.Cout), "ff_conv2d_fwd: res_ld too small");
     FF_REQUIRE((p.ch_scale == nullptr) == (p.ch_shift == nullptr), "ff_conv2d_fwd: ch_scale/ch_shift must come together");
     FF_REQUIRE(p.act >= FF_ACT_NONE && p.act <= FF_ACT_LEAKY, "ff_conv2d_fwd: bad act %d", p.act);
     FF_REQUIRE(p.act_res >= FF_ACT_NONE && p.act_res <= FF_ACT_LEAKY, "ff_conv2d_fwd: bad act_res %d", p.act_res);
@@ -284,6 +285,9 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
                                p.stride == 1 && cin % 32 == 0 && (p.in_act == FF_ACT_NONE || p.in_act == FF_ACT_RELU) &&
                                ff::aligned16(p.in_scale) && ff::aligned16(p.in_shift)),
                "ff_conv2d_fwd: in_scale needs the f16x3 patch kernel (one segment, 3x3, stride 1, Cin %% 32 == 0)");
+    FF_REQUIRE(!p.res2 || (p.res && p.w_format != FF_W_F32 && p.KH == 1 && p.KW == 1 && p.groups == 1 && p.res_split > 0 &&
+                           p.res_split < p.Cout && p.res2_ld >= p.Cout - p.res_split && !getenv("FF_WS_CONV")),
+               "ff_conv2d_fwd: res2 needs res, a split weight format and a 1x1 kernel (0 < res_split < Cout)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (p.w_format != FF_W_F32) return ff::conv2d_fwd_split(p, (int)M, cin, s);
     if (const int rc = ff::conv2d_fwd_small(p, cin, s); rc != 1) return rc;    // 1- and 2-channel 3x3 heads: vector ALU

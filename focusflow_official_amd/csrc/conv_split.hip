@@ -294,11 +294,15 @@ __device__ __forceinline__ void conv_split_body(const KernArgs& a) {
                 vv[r] = ff::apply_act(v, p.act);
             }
             if (p.res) {
+                // FFConvParams.res2: output channels >= res_split add a second tensor (paired fusion convs)
+                const bool second = p.res2 && n >= p.res_split;
+                const float* rb = second ? p.res2 + (n - p.res_split) : p.res + n;
+                const int rld = second ? p.res2_ld : p.res_ld;
                 float rr[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    rr[r] = m < a.M ? p.res[(long long)m * p.res_ld + n] : 0.f;
+                    rr[r] = m < a.M ? rb[(long long)m * rld] : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) vv[r] = ff::apply_act(vv[r] + rr[r], p.act_res);

@@ -139,8 +139,9 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
            res: Optional[Tensor] = None, act_res: int = ACT_NONE, ch_scale: Optional[Tensor] = None,
            ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0, dilation: int = 1,
            x_amax: Optional[Tensor] = None, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None,
-           in_act: int = ACT_NONE) -> Tensor:
-    """Convolution over the channel-concatenation of `xs` (see FFConvParams).  `wpack` is fp32
+           in_act: int = ACT_NONE, res2: Optional[Tensor] = None, res_split: int = 0) -> Tensor:
+    """Convolution over the channel-concatenation of `xs` (see FFConvParams).  res2 / res_split: output channels
+    >= res_split take their residual from `res2` (paired 1x1 fusion convs).  `wpack` is fp32
     [Cout][K] (w_fmt 0) or the split rows of pack_split (w_fmt 1/2).  x_amax: device word holding the bits of
     max|x| (act_bwd): the split formats then scale the input by a power of two so that gradients fit fp16."""
     if isinstance(pad, int):
@@ -171,6 +172,8 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     p.out_scale = out_scale
     p.res = res.data_ptr() if res is not None else None
     p.res_ld = _ld(res) if res is not None else 0
+    if res2 is not None:
+        p.res2, p.res2_ld, p.res_split = res2.data_ptr(), _ld(res2), res_split
     p.y, p.y_ld, p.y_gstride = out.data_ptr(), _ld(out), 0
     p.Ho, p.Wo, p.Cout = ho, wo, cout
     p.KH, p.KW, p.stride, p.pad_h, p.pad_w = kh, kw, stride, pad[0], pad[1]

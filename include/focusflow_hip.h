@@ -91,6 +91,11 @@ typedef struct FFConvParams {
     int in_act;                        /* of its producer applied while loading, zero padding AFTER it.  One segment,    */
                                        /* groups == 1, split formats, stride-1 3x3 with Cin % 32 == 0 (patch kernel);    */
                                        /* in_act: FF_ACT_NONE or FF_ACT_RELU                                             */
+    const float* res2;                 /* NULL, or a second residual for output channels >= res_split (column n reads    */
+    int res2_ld;                       /* res2[m * res2_ld + n - res_split]): both 1x1 convs of a FusionUnit              */
+    int res_split;                     /* (parallel_fusion.py:142-150: img' = img + conv(mask), mask' = mask + conv(img)) */
+                                       /* as ONE launch over the segments [img, mask] with an anti-diagonal weight.       */
+                                       /* Split formats, 1x1 kernels (the im2col kernel's epilogue).                      */
 } FFConvParams;
 
 int ff_conv2d_fwd(const FFConvParams* p, void* stream);

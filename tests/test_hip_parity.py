@@ -505,6 +505,21 @@ def test_normalise_on_load_forward_is_bit_identical(det_sd, monkeypatch):
     assert torch.equal(fl0, fl1) and torch.equal(fu0, fu1)
 
 
+def test_paired_fusion_convs_are_bit_identical(det_sd, monkeypatch):
+    """Inference runs both 1x1 convs of a FusionUnit (parallel_fusion.py:142-150) as one launch over the segments
+    [img, mask] with an anti-diagonal weight and two residuals (FFConvParams.res2).  The added products are exact zeros
+    in whole K chunks, so the result must be bit-identical to the two separate launches."""
+    from focusflow_official_amd import cce
+    inp = [t.to(DEV) for t in orc.shifted_pair(2, 128, 192, seed=1)]
+    m = _model(det_sd)
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(cce, "_PAIR_FUSION", flag)
+        with torch.no_grad():
+            outs.append(m(*inp, raft_iters=2, test_mode=True))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_config5_shape_540x960_padded(det_sd):
     """BASELINE config 5's frame size: 540x960 replicate-padded to 544x960 (68x120 at 1/8: level 3 is 8x15, odd
     widths at two pyramid levels), against the CPU oracle.  Few iterations on purpose: with synthetic weights the
