@@ -42,11 +42,13 @@ __device__ __forceinline__ void tap_1d(float c, float inv_scale, int off, int n,
     w1 = __fsub_rn(u, f);
 }
 
-// LDS window of one level, row-major: fp32 16 rows x 32 columns at a 144-byte pitch, fp16 32 rows x 32 columns at an
-// 80-byte pitch.  The pitch is what keeps the blend's reads conflict-free: 32 lanes read a block of ~9 rows x 4 columns,
-// and with 36 (20) dwords per row consecutive rows start 4 banks apart (at the natural 32 / 16 dwords every row would start
-// on the same bank: a 9-way conflict that cost more than all the arithmetic of the kernel).
-constexpr int LVL_BYTES = 2560;
+// LDS window of one level, row-major, THREE tile columns wide (a window spans at most 3): fp32 16 rows x 24 columns at a
+// 112-byte pitch, fp16 24 rows x 24 columns at an 80-byte pitch.  The pitch is what keeps the blend's reads nearly
+// conflict-free: 32 lanes read a block of ~9 rows x 4 columns, and with 28 (20) dwords per row consecutive rows start
+// 4 banks apart, so only rows 8 apart share banks (at the natural 32 / 16 dwords per row every row started on the same
+// bank: a 9-way conflict that cost more than all the arithmetic of the kernel).  1.8 KB (1.9 KB) per level keeps the
+// block under 10 KB of LDS: 16 one-wave blocks per CU.
+constexpr int LVL_BYTES = 1920;
 
 
 struct __attribute__((aligned(16))) TapEntry {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
     constexpr int TSH = HALF ? 3 : 2;      // log2(tile height)
     constexpr int ESZ = HALF ? 2 : 4;
     constexpr int MAXR = HALF ? 3 : 4;     // tile rows a window can span
-    constexpr int PITCH = HALF ? 80 : 144; // window row pitch in bytes (4 tile columns x 8 elements + padding, see LVL_BYTES)
+    constexpr int PITCH = HALF ? 80 : 112; // window row pitch in bytes (3 tile columns x 8 elements + padding, see LVL_BYTES)
     __shared__ __attribute__((aligned(16))) char win[4 * LVL_BYTES];
     __shared__ TapEntry tab[2][2][4][9];   // [buf][axis][level][offset]
     __shared__ __attribute__((aligned(16))) int geo[2][4][4];           // [buf][level]{tx0, ty0, ntc, ntr}
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
         const int tx0 = xlo >> 3, ty0 = ylo >> TSH;
         if (lane < 36) {
             // window coordinates of tap 0, clamped so that a wild coordinate (and its +1 neighbour) stays inside the window
-            const int wxc = min(max(x0 - tx0 * 8, 0), 30), wyc = min(max(y0 - (ty0 << TSH), 0), (4 << TSH) - 2);
+            const int wxc = min(max(x0 - tx0 * 8, 0), 22), wyc = min(max(y0 - (ty0 << TSH), 0), (MAXR << TSH) - 2);
             TapEntry ex, ey;
             ex.off = wxc * ESZ;
             ex.w1 = wx;
@@ -143,10 +145,11 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
             }
         }
     };
-    auto store_window = [&]() {
+    auto store_window = [&]() {     // the fourth tile column of the slot grid only exists for the loads' lane layout
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<u32x4*>(&win[(i >> 1) * LVL_BYTES + (i & 1) * (2 << TSH) * PITCH + s_dst]) = rv[i];
+            if (s_tc < 3 && (!HALF || (i & 1) == 0 || s_trh == 0))      // fp16: tile rows 0..2 (the window spans <= 3)
+                *reinterpret_cast<u32x4*>(&win[(i >> 1) * LVL_BYTES + (i & 1) * (2 << TSH) * PITCH + s_dst]) = rv[i];
     };
 
     // blend roles: output k = lane + 64 j -> (level, ia, ib): loop-invariant table entries
@@ -404,8 +407,8 @@ extern "C" int ff_corr_lookup_tiled_fwd(const void* const* levels, int half, con
     a.taps = taps_dbg;
     a.queries = queries;
     a.out_ld = out_ld;
-    // one wave per block, 12.7 KB of LDS each: 12 blocks fit a CU
-    static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 12;
+    // one wave per block, 10.1 KB of LDS each: 16 blocks fit a CU
+    static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 16;
     const long long blocks = queries < 256ll * wpc ? queries : 256ll * wpc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (half) lookup_tiled_kernel<true><<<(unsigned)blocks, 64, 0, s>>>(a);
