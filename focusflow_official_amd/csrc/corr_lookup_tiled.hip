@@ -51,10 +51,9 @@ __device__ __forceinline__ void tap_1d(float c, float inv_scale, int off, int n,
 constexpr int LVL_BYTES = 1920;
 
 
-struct __attribute__((aligned(16))) TapEntry {
+struct __attribute__((aligned(8))) TapEntry {      // 8 bytes: one ds_read_b64 (the LDS pipe is this kernel's busiest unit)
     int off;        // byte offset of tap 0 in the level window (x: column part, y: level base + row part)
-    float w1, w0;   // fractional weight of tap 1 and 1 - w1 (ATen: separately rounded subtraction)
-    int pad;
+    float w1;       // fractional weight of tap 1; tap 0 weighs 1 - w1 (ATen: separately rounded subtraction)
 };
 
 // Instruction count is what bounds this kernel (one wave per query, ~24 queries per SIMD at B = 8), next to the number
@@ -102,12 +101,8 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
             TapEntry ex, ey;
             ex.off = wxc * ESZ;
             ex.w1 = wx;
-            ex.w0 = __fsub_rn(1.f, wx);
-            ex.pad = 0;
             ey.off = t_lv * LVL_BYTES + wyc * PITCH;
             ey.w1 = wy;
-            ey.w0 = __fsub_rn(1.f, wy);
-            ey.pad = 0;
             tab[buf][0][t_lv][t_o] = ex;
             tab[buf][1][t_lv][t_o] = ey;
             if (t_o == 0) {
@@ -123,9 +118,11 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
     };
 
     u32x4 rv[8];         // instruction i = level i >> 1, tile rows (i & 1) * 2 + {0, 1}
+    unsigned need = 0;   // bit i: this lane's tile of instruction i lies inside the window (only those go to LDS)
     // Buffer loads over ONE plane (resource = the query's plane of the level, range-checked): a tile outside the plane's
     // tile grid gets an out-of-range offset and the hardware returns zeros - grid_sample's zero padding without a select.
     auto issue_loads = [&](long long q, int buf) {
+        need = 0;
 #pragma unroll
         for (int lv = 0; lv < 4; ++lv) {
             const int4 g4 = *reinterpret_cast<const int4*>(&geo[buf][lv][0]);
@@ -142,13 +139,14 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
                 const bool in = inx && (unsigned)gty < (unsigned)nty;
                 const int off = in ? (gty * ntx + gtx) * 128 + s_p * 16 : 0x7ffffff0;
                 rv[lv * 2 + hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                need |= (s_tc < ntc && hf * 2 + s_trh < ntr) ? 1u << (lv * 2 + hf) : 0u;
             }
         }
     };
     auto store_window = [&]() {     // the fourth tile column of the slot grid only exists for the loads' lane layout
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (s_tc < 3 && (!HALF || (i & 1) == 0 || s_trh == 0))      // fp16: tile rows 0..2 (the window spans <= 3)
+            if (need >> i & 1u)      // ntc <= 3, ntr <= MAXR: never the fourth column / a row past the image
                 *reinterpret_cast<u32x4*>(&win[(i >> 1) * LVL_BYTES + (i & 1) * (2 << TSH) * PITCH + s_dst]) = rv[i];
     };
 
@@ -202,9 +200,10 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
                 v11 = *reinterpret_cast<const float*>(p + PITCH + 4);
             }
             // nw*s*e + ne*s*w + sw*n*e + se*n*w  (ATen's weight naming): s = 1 - wy, e = 1 - wx
-            float o = __fmul_rn(v00, __fmul_rn(ey.w0, ex.w0));
-            o = __fadd_rn(o, __fmul_rn(v01, __fmul_rn(ey.w0, ex.w1)));
-            o = __fadd_rn(o, __fmul_rn(v10, __fmul_rn(ey.w1, ex.w0)));
+            const float e0 = __fsub_rn(1.f, ex.w1), s0 = __fsub_rn(1.f, ey.w1);
+            float o = __fmul_rn(v00, __fmul_rn(s0, e0));
+            o = __fadd_rn(o, __fmul_rn(v01, __fmul_rn(s0, ex.w1)));
+            o = __fadd_rn(o, __fmul_rn(v10, __fmul_rn(ey.w1, e0)));
             o = __fadd_rn(o, __fmul_rn(v11, __fmul_rn(ey.w1, ex.w1)));
             if (j < 5 || lane < 4) orow[lane + 64 * j] = o;
         }
