@@ -182,15 +182,18 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 #pragma unroll
     for (int t = 0; t < TM; ++t) abase[t] = sP + (((wm * TM + t) * 2 + lrow) * PW + lcol) * ROWP + lh * 16;
 
+    f16x8 abl_f;                               // ABL 5 only
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abl_f[i] = (_Float16)(0.37f + 0.01f * (float)((lane * 7 + i * 3) & 31));
     load_patch(0);
     load_w(0);
     int wbuf = 0;
     for (int c = 0; c < a.nci; ++c) {
         __syncthreads();                     // previous chunk's taps are done with sP
-        store_patch();
+        if (ABL != 6 || c == 0) store_patch();       // ABL 6: timing only, the patch is staged once
         store_w(wbuf);
         __syncthreads();
-        if (c + 1 < a.nci) load_patch(c + 1);        // lands during this chunk's taps
+        if (c + 1 < a.nci && ABL != 6) load_patch(c + 1);        // lands during this chunk's taps
         for (int tap = 0; tap < ntaps; ++tap) {
             const bool last = tap + 1 == ntaps;
             const int next_kc = last ? (c + 1) : (tap + 1) * a.nci + c;   // K order = (tap, ci): chunk index tap*nci + c
@@ -205,6 +208,13 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 f16x8 a0[TM], a1[TM], b0[TN], b1[TN];
+                if constexpr (ABL == 5) {      // timing only: no fragment reads, the MFMAs run on dense garbage kept in a register
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) { a0[t] = abl_f; a1[t] = abl_f; }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { b0[j] = abl_f; b1[j] = abl_f; }
+                    asm volatile("" : "+v"(abl_f));
+                } else {
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
                     const char* pa = abase[t] + tapoff;            // + k-slice s (32 B) and term (64 B) as immediates
@@ -215,6 +225,7 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
                 for (int j = 0; j < TN; ++j) {
                     b0[j] = *reinterpret_cast<const f16x8*>(cW + j * 32 * ROWP + s * 32);
                     if (TERMS == 3) b1[j] = *reinterpret_cast<const f16x8*>(cW + j * 32 * ROWP + 64 + s * 32);
+                }
                 }
 #pragma unroll
                 for (int t = 0; t < TM; ++t)
@@ -299,11 +310,14 @@ int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
         conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
         return ff::check_launch("ff_conv2d_fwd(patch)");
     }
-    static const bool nobar = getenv("FF_PATCH_ABLATE") && atoi(getenv("FF_PATCH_ABLATE")) == 4;   // timing only
-    if (nobar) {
-        conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 4><<<(unsigned)blocks, 256, lds, s>>>(a);
-        return ff::check_launch("ff_conv2d_fwd(patch)");
-    }
+    // Timing-only ablations of the high-occupancy kernels (WRONG results), FF_PATCH_ABLATE = 4 no per-tap barriers,
+    // 11 no weight loads, 12 no weight loads / stores / per-tap barriers, 13 no MFMAs, 15 no LDS fragment reads,
+    // 16 the patch is staged once per block instead of once per chunk.  Measured table: DESIGN.md section 4.
+    static const int oabl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;
+#define FF_OCC_ABL(ENV_, ABL_) \
+    if (oabl == ENV_) { conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, ABL_><<<(unsigned)blocks, 256, lds, s>>>(a); return ff::check_launch("ff_conv2d_fwd(patch)"); }
+    FF_OCC_ABL(4, 4) FF_OCC_ABL(11, 1) FF_OCC_ABL(12, 2) FF_OCC_ABL(13, 3) FF_OCC_ABL(15, 5) FF_OCC_ABL(16, 6)
+#undef FF_OCC_ABL
     if (!pin) {
         conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, false><<<(unsigned)blocks, 256, lds, s>>>(a);
         return ff::check_launch("ff_conv2d_fwd(patch)");
@@ -376,7 +390,7 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     const size_t lds = ((npix * ROWP + 255) & ~255) + (occ ? 1 : 2) * 64 * tn * ROWP + lds_pad;
     if (lds > 96 * 1024) return 1;
     static const int abl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;   // timing experiments (wrong results!)
-    if (abl && abl != 4 && th == 8 && tn == 1 && nitem <= 6 && t3) {
+    if (abl >= 1 && abl <= 3 && th == 8 && tn == 1 && nitem <= 6 && t3) {
         if (abl == 1) return launch<3, 6, 2, 1, 1>(a, lds, s);
         if (abl == 2) return launch<3, 6, 2, 1, 2>(a, lds, s);
         return launch<3, 6, 2, 1, 3>(a, lds, s);

@@ -11,6 +11,8 @@ g = torch.Generator().manual_seed(0)
 x = torch.randn(b, h, w, cin, generator=g).cuda()
 wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda()
 bias = torch.randn(cout, generator=g).cuda()
+if os.environ.get("ZERO"):          # all-zero operands: the same instruction stream at a fraction of the matrix pipe's power
+    x.zero_(); wt.zero_()
 wp = torch.empty(cout, k * k * cin, device="cuda")
 ops.pack_conv_weight(wt, wp, cin)
 if fmt:
