@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
     __shared__ __attribute__((aligned(16))) char win[4 * LVL_BYTES];
     __shared__ TapEntry tab[2][2][4][9];   // [buf][axis][level][offset]
     __shared__ __attribute__((aligned(16))) int geo[2][4][4];           // [buf][level]{tx0, ty0, ntc, ntr}
+    __shared__ __attribute__((aligned(16))) int slot[2][64];            // [buf][lane group g][load i]: tile offset | need
     const int lane = threadIdx.x;
     const int t_lv = min(lane / 9, 3), t_o = lane - (lane / 9) * 9;   // tap role (lanes < 36)
     const float t_inv = 1.f / (float)(1 << t_lv);
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
     const int s_p = lane & 7, s_tc = (lane >> 3) & 3, s_trh = lane >> 5;
     // LDS position of the piece (row-major window): fp32 piece = tile row p >> 1, half p & 1 ; fp16 piece = tile row p
     const int s_dst = (s_trh << TSH) * PITCH + s_tc * 8 * ESZ + (HALF ? s_p * PITCH : (s_p >> 1) * PITCH + (s_p & 1) * 16);
+    // slot role: lane L prepares ONE of the 64 tile slots of a query - load i = L & 7 (level i >> 1, tile rows
+    // (i & 1) * 2 + {0, 1}) of the eight lanes of group g = L >> 3 (tile row half g >> 2, tile column g & 3) - so that
+    // issue_loads is two table reads and eight and-ors instead of ten vector instructions per load.
+    const int b_lv = (lane & 7) >> 1, b_row = (lane & 1) * 2 + (lane >> 5), b_col = (lane >> 3) & 3;
+    const int b_ntx = a.ntx[b_lv], b_nty = a.nty[b_lv];
 
     auto publish_taps = [&](long long q, float cx, float cy, int buf) {
         int x0, y0;
@@ -115,38 +121,38 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
                 t[9 + t_o] = y0;
             }
         }
+        // the slot table of this query (same wave: LDS operations complete in program order)
+        const int4 g4 = *reinterpret_cast<const int4*>(&geo[buf][b_lv][0]);
+        const int gtx = g4.x + min(b_col, g4.z - 1), gty = g4.y + min(b_row, g4.w - 1);   // slots past the window re-read its edge
+        const bool in = (unsigned)gtx < (unsigned)b_ntx && (unsigned)gty < (unsigned)b_nty;
+        const int need1 = (b_col < g4.z && b_row < g4.w) ? 1 : 0;
+        slot[buf][lane] = (in ? (gty * b_ntx + gtx) * 128 : 0x7ffffff0) | need1;
     };
 
     u32x4 rv[8];         // instruction i = level i >> 1, tile rows (i & 1) * 2 + {0, 1}
-    unsigned need = 0;   // bit i: this lane's tile of instruction i lies inside the window (only those go to LDS)
+    int se[8];           // slot entries of the loads in flight; bit 0: the tile lies inside the window (only those go to LDS)
     // Buffer loads over ONE plane (resource = the query's plane of the level, range-checked): a tile outside the plane's
     // tile grid gets an out-of-range offset and the hardware returns zeros - grid_sample's zero padding without a select.
     auto issue_loads = [&](long long q, int buf) {
-        need = 0;
+        const int4 e0 = *reinterpret_cast<const int4*>(&slot[buf][(lane >> 3) * 8]);
+        const int4 e1 = *reinterpret_cast<const int4*>(&slot[buf][(lane >> 3) * 8 + 4]);
+        se[0] = e0.x; se[1] = e0.y; se[2] = e0.z; se[3] = e0.w;
+        se[4] = e1.x; se[5] = e1.y; se[6] = e1.z; se[7] = e1.w;
 #pragma unroll
         for (int lv = 0; lv < 4; ++lv) {
-            const int4 g4 = *reinterpret_cast<const int4*>(&geo[buf][lv][0]);
-            const int tx0 = __builtin_amdgcn_readfirstlane(g4.x), ty0 = __builtin_amdgcn_readfirstlane(g4.y);
-            const int ntc = __builtin_amdgcn_readfirstlane(g4.z), ntr = __builtin_amdgcn_readfirstlane(g4.w);
-            const int ntx = a.ntx[lv], nty = a.nty[lv];
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(a.lvl[lv] + q * a.plane_bytes[lv]), 0, (int)a.plane_bytes[lv], 0x00020000);
-            const int gtx = tx0 + min(s_tc, ntc - 1);                                    // slots past the window re-read its edge
-            const bool inx = (unsigned)gtx < (unsigned)ntx;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const int gty = ty0 + min(hf * 2 + s_trh, ntr - 1);
-                const bool in = inx && (unsigned)gty < (unsigned)nty;
-                const int off = in ? (gty * ntx + gtx) * 128 + s_p * 16 : 0x7ffffff0;
+                const int off = (se[lv * 2 + hf] & ~1) | (s_p * 16);          // the out-of-range marker stays out of range
                 rv[lv * 2 + hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-                need |= (s_tc < ntc && hf * 2 + s_trh < ntr) ? 1u << (lv * 2 + hf) : 0u;
             }
         }
     };
     auto store_window = [&]() {     // the fourth tile column of the slot grid only exists for the loads' lane layout
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (need >> i & 1u)      // ntc <= 3, ntr <= MAXR: never the fourth column / a row past the image
+            if (se[i] & 1)           // ntc <= 3, ntr <= MAXR: never the fourth column / a row past the image
                 *reinterpret_cast<u32x4*>(&win[(i >> 1) * LVL_BYTES + (i & 1) * (2 << TSH) * PITCH + s_dst]) = rv[i];
     };
 
