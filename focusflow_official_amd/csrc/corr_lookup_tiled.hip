@@ -28,6 +28,7 @@ struct TLookupArgs {
     int* taps;
     long long queries;
     int out_ld;
+    int abl;          // FF_LOOKUP_ABLATE (timing only, WRONG results): 1 no output stores, 2 no window loads, 3 neither
 };
 
 // One separately-rounded replay of the sampler's coordinate chain (corr.py:41-43, utils.py:61-62, ATen's un-normalise).
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
                 const_cast<char*>(a.lvl[lv] + q * a.plane_bytes[lv]), 0, (int)a.plane_bytes[lv], 0x00020000);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const int off = (se[lv * 2 + hf] & ~1) | (s_p * 16);          // the out-of-range marker stays out of range
+                const int off = (a.abl & 2) ? 0x7ffffff0 : ((se[lv * 2 + hf] & ~1) | (s_p * 16));          // the out-of-range marker stays out of range
                 rv[lv * 2 + hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             }
         }
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
 
     long long q = blockIdx.x;
     if (q >= a.queries) return;
+
     int cur = 0;
     const float2* cptr = reinterpret_cast<const float2*>(a.coords);
     publish_taps(q, cptr[q].x, cptr[q].y, 0);
@@ -182,8 +184,8 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
         const long long qs = has_next ? qn : q;          // the last round re-stages its own query: nothing under a branch
         const long long qnn = qn + gridDim.x;
         const float2 cnn = cptr[qnn < a.queries ? qnn : qs];   // past the end: the query that is re-staged then
-        store_window();                                  // waits for this query's window loads
-        publish_taps(qs, cn.x, cn.y, cur ^ 1);
+        if (!(a.abl & 16)) store_window();                                  // waits for this query's window loads
+        if (!(a.abl & 8)) publish_taps(qs, cn.x, cn.y, cur ^ 1);
         __syncthreads();                                 // win + both table sets visible
         issue_loads(qs, cur ^ 1);                        // in flight during the blend below
         float* orow = a.out + q * a.out_ld;
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
         const TapEntry* ty = &tab[cur][1][0][0];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
+            if (a.abl & 4) break;
             const TapEntry ex = tx[bx[j]], ey = ty[by[j]];
             const char* p = &win[ey.off + ex.off];
             float v00, v01, v10, v11;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
             o = __fadd_rn(o, __fmul_rn(v01, __fmul_rn(s0, ex.w1)));
             o = __fadd_rn(o, __fmul_rn(v10, __fmul_rn(ey.w1, e0)));
             o = __fadd_rn(o, __fmul_rn(v11, __fmul_rn(ey.w1, ex.w1)));
-            if (j < 5 || lane < 4) orow[lane + 64 * j] = o;
+            if ((j < 5 || lane < 4) && (!(a.abl & 1) || o == 12345.678f)) orow[lane + 64 * j] = o;
         }
         if (!has_next) break;
         __syncthreads();                                 // everyone done reading win before it is overwritten
@@ -412,6 +415,8 @@ extern "C" int ff_corr_lookup_tiled_fwd(const void* const* levels, int half, con
     a.taps = taps_dbg;
     a.queries = queries;
     a.out_ld = out_ld;
+    static const int abl = getenv("FF_LOOKUP_ABLATE") ? atoi(getenv("FF_LOOKUP_ABLATE")) : 0;
+    a.abl = abl;
     // one wave per block, 10.1 KB of LDS each: 16 blocks fit a CU
     static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 16;
     const long long blocks = queries < 256ll * wpc ? queries : 256ll * wpc;
