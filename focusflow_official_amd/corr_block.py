@@ -40,7 +40,18 @@ class CorrBlock:
         # pad channels zero once), so that convc1 takes the block-uniform loader (32-channel chunks) of the conv
         # kernel instead of the generic im2col one.  The buffer is reused by every iteration of this pair.
         self._nk = num_levels * (2 * radius + 1) ** 2
+        self._pairs = fmap1.shape[0]
         self._padded = None
+
+    def batch_slice(self, lo: int, hi: int) -> "CorrBlock":
+        """The same pyramid restricted to pairs lo..hi-1 (views, no copy; inference: one update loop per batch slice)."""
+        assert self._token is None, "batch_slice is an inference-only view"
+        q = self.pyr.levels[0].shape[0] // self._pairs
+        v = object.__new__(CorrBlock)
+        v.num_levels, v.radius, v.half, v.grad_pyr, v._token = self.num_levels, self.radius, self.half, None, None
+        v.pyr = ops.TiledPyramid([lv[lo * q:hi * q] for lv in self.pyr.levels], self.pyr.h0, self.pyr.w0, self.pyr.half)
+        v._pairs, v._nk, v._padded = hi - lo, self._nk, None
+        return v
 
     @property
     def corr_pyramid(self):

@@ -11,6 +11,7 @@ from .ops import ACT_RELU, ACT_TANH
 from .update_block import BasicUpdateBlock
 
 _GRU_CTX_ONCE = os.environ.get("FF_GRU_CTX_ONCE", "1") != "0"      # measurement switch (see SepConvGRU.prepare)
+_UPDATE_SPLIT = int(os.environ.get("FF_UPDATE_SPLIT", "1"))         # experiment: update loop of n batch slices on n streams
 
 
 class RAFT(nn.Module):
@@ -99,6 +100,20 @@ class RAFT(nn.Module):
             ops.act_copy(cnet[..., :128], net, ACT_TANH)
             ops.act_copy(cnet[..., 128:], inp, ACT_RELU)
         coords1 = ops.coords_init(b, h8, w8, cnet, flow_init)      # never differentiated (raft.py:216)
+        # the context features' share of the GRU gate convolutions does not change over the iterations
+        gru_pre = None if (taped or torch.is_grad_enabled() or not _GRU_CTX_ONCE) else self.update_block.gru.prepare(inp)
+        if _UPDATE_SPLIT > 1 and test_mode and not taped and not torch.is_grad_enabled() and b % _UPDATE_SPLIT == 0:
+            # Experiment (FF_UPDATE_SPLIT=n): the update loop of n batch slices on n streams.  At 1/8 resolution every
+            # kernel of the loop is a 20-90 us launch with several us of ramp; independent slices overlap them.
+            return self._split_loop(net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8)
+        flow4, flow_up, flow_predictions = self._loop(net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8, taped, test_mode)
+        if test_mode:
+            return ops.nhwc_to_nchw(flow4[..., :2]), flow_up
+        return flow_predictions
+
+    def _loop(self, net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8, taped, test_mode):
+        """raft.py:218-236 for one batch (or batch slice): returns (flow4, flow_up, flow_predictions)."""
+        cnet = net
         flow_predictions = []
         flow_up = None
         flow4 = None
@@ -106,8 +121,6 @@ class RAFT(nn.Module):
         # (raft.py:226-236).  Default: do the same work.  skip_unused_upsample (opt-in, inference only) computes
         # the mask head + convex up-sampling for the last iteration only; flow_low / flow_up are bit-identical.
         lazy = bool(getattr(self, "skip_unused_upsample", False)) and test_mode and not taped
-        # the context features' share of the GRU gate convolutions does not change over the iterations
-        gru_pre = None if (taped or torch.is_grad_enabled() or not _GRU_CTX_ONCE) else self.update_block.gru.prepare(inp)
         for it in range(iters):
             # coords1 is advanced in place by ff_coords_step (raw pointer: autograd cannot see it), so a
             # recorded lookup keeps its own snapshot for the backward scatter
@@ -127,6 +140,30 @@ class RAFT(nn.Module):
             else:
                 flow_up = ops.upsample_flow(flow4, up_mask)
             flow_predictions.append(flow_up)
-        if test_mode:
-            return ops.nhwc_to_nchw(flow4[..., :2]), flow_up
-        return flow_predictions
+        return flow4, flow_up, flow_predictions
+
+    def _split_loop(self, net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8):
+        n = _UPDATE_SPLIT
+        m = b // n
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_split_streams") or len(self._split_streams) != n:
+            self._split_streams = [torch.cuda.Stream(device=net.device) for _ in range(n)]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        outs = []
+        for k, st in enumerate(self._split_streams):
+            lo, hi = k * m, (k + 1) * m
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                pre = None if gru_pre is None else [(z[lo:hi], q[lo:hi]) for z, q in gru_pre]
+                f4, fup, _ = self._loop(net[lo:hi], inp[lo:hi], corr_fn.batch_slice(lo, hi), coords1[lo:hi], pre, iters,
+                                        m, h8, w8, False, True)
+                low = ops.nhwc_to_nchw(f4[..., :2])
+                for t in (low, fup):
+                    t.record_stream(main)
+                join = torch.cuda.Event()
+                join.record(st)
+            outs.append((low, fup, join))
+        for _, _, join in outs:
+            main.wait_event(join)
+        return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)

@@ -22,7 +22,9 @@ _side_streams = {}
 
 
 def _side_stream(device):
-    key = torch.device(device).index
+    # one side stream per (device, stream the caller runs on): two update loops on two streams (RAFT._split_loop) must
+    # not funnel their flow branches through one queue
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]
