@@ -189,10 +189,11 @@ def harness_selftest(args):
         dist.destroy_process_group()
 
 
-def train_mode(args, world, rank, local_rank, device):
+def train_setup(args, world, rank, local_rank, device):
     """One training step = train.py:291-328 on synthetic FlyingChairs-shaped data: forward (train mode),
     MixLoss (ffraft_chairs_orb.yaml:35-39), loss *= world_size, backward (+ DDP all-reduce over RCCL),
-    clip_grad_norm_(1.0), AdamW + OneCycleLR step.  Optimiser/scheduler are stock PyTorch as in the reference."""
+    clip_grad_norm_(1.0), AdamW + OneCycleLR step.  Optimiser/scheduler are stock PyTorch as in the reference.
+    Returns (step closure, h, w)."""
     from torch.nn.parallel import DistributedDataParallel
     from focusflow_official_amd import FF_RAFT_FUSION
     from focusflow_official_amd.losses import build_losses
@@ -218,6 +219,11 @@ def train_mode(args, world, rank, local_rank, device):
         sched.step()
         return loss
 
+    return step, h, w
+
+
+def train_mode(args, world, rank, local_rank, device):
+    step, h, w = train_setup(args, world, rank, local_rank, device)
     log(f"train mode rank {rank}/{world}: {args.batch} pairs {h}x{w}")
     for i in range(args.warmup):
         step()
@@ -241,6 +247,65 @@ def train_mode(args, world, rank, local_rank, device):
         dist.destroy_process_group()
 
 
+def secondary_measurements(args, device):
+    """The two secondary BASELINE configs on the same GPU, after the headline measurement (N = 1 only, a few seconds):
+    the training step (configs[2] shape, one GPU) and the FF-PWC forward (configs[3]).  Reported next to the headline
+    line, never mixed into it; a failure is reported as text and does not touch the headline."""
+    import copy
+    import time
+    out = {}
+    try:
+        targs = copy.copy(args)
+        targs.batch, targs.height, targs.width, targs.iters = 8, 384, 512, 12      # -> 368 x 496 crops (train_setup)
+        step, h, w = train_setup(targs, 1, 0, 0, device)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        n = 3
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out["train_step"] = {"metric": f"training frame-pairs/sec FF-RAFT {h}x{w} iters=12 (fwd+MixLoss+bwd+clip+AdamW)",
+                             "value": round(8 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 2), "steps": n, "warmup": 2,
+                             "workload": "BASELINE configs[2] shape on ONE GPU: 8 pairs, MixLoss, no DDP", "finite_loss": bool(torch.isfinite(loss))}
+        del step
+    except Exception as e:          # noqa: BLE001 - reported, never fatal for the headline line
+        out["train_step"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    try:
+        from argparse import Namespace
+        from focusflow_official_amd.pwcnet import FF_PWCNET
+        pcfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"), MODEL=Namespace(FUSION="parallel", FUSION_TYPE="1x1conv"))
+        torch.manual_seed(0)
+        m = FF_PWCNET(pcfg).to(device).eval()
+        with torch.no_grad():       # unnormalised 0..255 inputs: keep the first layer's activations in fp16 range
+            m.netExtractor.netOne[0].weight.mul_(1 / 255.0)
+            m.netExtractor.mask_netOne[0].weight.mul_(1 / 255.0)
+        g = torch.Generator().manual_seed(0)
+        i1 = torch.randint(0, 256, (1, 3, 448, 1024), generator=g).float().to(device)
+        i2 = torch.roll(i1, (3, -5), (2, 3))
+        m1 = ((torch.rand(1, 1, 448, 1024, generator=g) < 2000 / (448 * 1024)).float() * 255).to(device)
+        with torch.no_grad():
+            for _ in range(3):
+                o = m(i1, i2, m1, m1, test_mode=True)
+            torch.cuda.synchronize()
+            n = 10
+            t0 = time.perf_counter()
+            for _ in range(n):
+                o = m(i1, i2, m1, m1, test_mode=True)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out["ff_pwc_forward"] = {"metric": "frame-pairs/sec FF-PWC forward 448x1024", "value": round(1 / dt, 2), "unit": "frame-pairs/s",
+                                 "ms_per_step": round(dt * 1e3, 3), "steps": n, "warmup": 3,
+                                 "workload": "BASELINE configs[3]: FF_PWCNET test_mode, 1 pair 448x1024, SIFT-like mask (2000 points)",
+                                 "finite": bool(torch.isfinite(o).all())}
+    except Exception as e:          # noqa: BLE001
+        out["ff_pwc_forward"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def TiledPyramidBytes(h8, w8, half):
     """Bytes of one query's four tiled planes (ops.TiledPyramid / csrc/corr_layout.h)."""
     from focusflow_official_amd import ops
@@ -262,6 +327,8 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary configs (training step, FF-PWC forward) measured after the headline at N = 1")
     ap.add_argument("--pyramid", choices=["fp32", "fp16"], default="fp32",
                     help="storage type of the correlation pyramid: fp32 = the reference's arithmetic (headline); fp16 = "
                          "BASELINE configs[4] (540x960 padded to 544x960, iters 32: --height 544 --width 960 --iters 32 --batch 1)")
@@ -391,6 +458,10 @@ def main():
             "launches": len(conv_ms), "sum_launch_ms": round(tot_ms, 3), "useful_gflop_per_step": round(useful / 1e9, 1)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.height, args.width, args.iters)
+        if world == 1 and c2 and not args.no_secondary and not args.graph:
+            step = model = batch = None          # noqa: F841 - release the forward model before the secondary configs
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary_measurements(args, device)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -9,7 +9,7 @@ python bench.py --steps 10 --warmup 2 --height 544 --width 960 --iters 32 --batc
 python bench.py --steps 10 --warmup 2 --height 544 --width 960 --iters 32 --batch 4 --pyramid fp16 --no-cpu-baseline > $o/bench_c5_fp16_b4_line.json 2> $o/bench_c5_fp16_b4.err
 python bench.py --mode train --steps 5 --warmup 2 > $o/train_line.json 2> $o/train_line.err
 python tools/bench_pwc.py > $o/pwc_line.json 2> $o/pwc_line.err
-tools/prof_trace.sh r02/bench_b8 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+tools/prof_trace.sh r02/bench_b8 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
 tools/prof_trace.sh r02/train_b8 bench.py --mode train --steps 3 --warmup 1
 ONLY=lookup tools/prof_pmc.sh r02/lookup_pmc tools/bench_lookup.py > $o/pmc_lookup.log 2>&1
 HALF=1 ONLY=lookup tools/prof_pmc.sh r02/lookup_pmc_fp16 tools/bench_lookup.py > $o/pmc_lookup16.log 2>&1
