@@ -28,7 +28,6 @@ struct TLookupArgs {
     int* taps;
     long long queries;
     int out_ld;
-    int abl;          // FF_LOOKUP_ABLATE (timing only, WRONG results): 1 no output stores, 2 no window loads, 3 neither
 };
 
 // One separately-rounded replay of the sampler's coordinate chain (corr.py:41-43, utils.py:61-62, ATen's un-normalise).
@@ -70,7 +69,10 @@ struct __attribute__((aligned(8))) TapEntry {      // 8 bytes: one ds_read_b64 (
 //            of an edge tile beyond the plane are zero in memory (ff_corr_build / ff_corr_retile guarantee it).  The
 //            tiles are written to LDS UN-tiled (row-major window), so the blend needs one address per output.
 //   blend    324 outputs = 2 table reads + 2 two-element LDS reads + 11 separately rounded fp32 ops each.
-template <bool HALF>
+// ABL: timing-only ablation bits (FF_LOOKUP_ABLATE, WRONG results): 1 no output stores, 2 no window loads, 4 no blend,
+// 8 no tap chains after the first query, 16 no window stores to LDS.  A template parameter: as run-time tests inside the
+// blend they cost the fp16 kernel 60 % (43 instead of 26 us).
+template <bool HALF, int ABL = 0>
 __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
     constexpr int TSH = HALF ? 3 : 2;      // log2(tile height)
     constexpr int ESZ = HALF ? 2 : 4;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
                 const_cast<char*>(a.lvl[lv] + q * a.plane_bytes[lv]), 0, (int)a.plane_bytes[lv], 0x00020000);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const int off = (a.abl & 2) ? 0x7ffffff0 : ((se[lv * 2 + hf] & ~1) | (s_p * 16));          // the out-of-range marker stays out of range
+                const int off = (ABL & 2) ? 0x7ffffff0 : ((se[lv * 2 + hf] & ~1) | (s_p * 16));          // the out-of-range marker stays out of range
                 rv[lv * 2 + hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             }
         }
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
         const long long qs = has_next ? qn : q;          // the last round re-stages its own query: nothing under a branch
         const long long qnn = qn + gridDim.x;
         const float2 cnn = cptr[qnn < a.queries ? qnn : qs];   // past the end: the query that is re-staged then
-        if (!(a.abl & 16)) store_window();                                  // waits for this query's window loads
-        if (!(a.abl & 8)) publish_taps(qs, cn.x, cn.y, cur ^ 1);
+        if (!(ABL & 16)) store_window();                                  // waits for this query's window loads
+        if (!(ABL & 8)) publish_taps(qs, cn.x, cn.y, cur ^ 1);
         __syncthreads();                                 // win + both table sets visible
         issue_loads(qs, cur ^ 1);                        // in flight during the blend below
         float* orow = a.out + q * a.out_ld;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
         const TapEntry* ty = &tab[cur][1][0][0];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            if (a.abl & 4) break;
+            if (ABL & 4) break;
             const TapEntry ex = tx[bx[j]], ey = ty[by[j]];
             const char* p = &win[ey.off + ex.off];
             float v00, v01, v10, v11;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
             o = __fadd_rn(o, __fmul_rn(v01, __fmul_rn(s0, ex.w1)));
             o = __fadd_rn(o, __fmul_rn(v10, __fmul_rn(ey.w1, e0)));
             o = __fadd_rn(o, __fmul_rn(v11, __fmul_rn(ey.w1, ex.w1)));
-            if ((j < 5 || lane < 4) && (!(a.abl & 1) || o == 12345.678f)) orow[lane + 64 * j] = o;
+            if ((j < 5 || lane < 4) && (!(ABL & 1) || o == 12345.678f)) orow[lane + 64 * j] = o;
         }
         if (!has_next) break;
         __syncthreads();                                 // everyone done reading win before it is overwritten
@@ -416,11 +418,15 @@ extern "C" int ff_corr_lookup_tiled_fwd(const void* const* levels, int half, con
     a.queries = queries;
     a.out_ld = out_ld;
     static const int abl = getenv("FF_LOOKUP_ABLATE") ? atoi(getenv("FF_LOOKUP_ABLATE")) : 0;
-    a.abl = abl;
     // one wave per block, 10.1 KB of LDS each: 16 blocks fit a CU
     static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 16;
     const long long blocks = queries < 256ll * wpc ? queries : 256ll * wpc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+#define FF_LK_ABL(V_) if (abl == V_) { if (half) lookup_tiled_kernel<true, V_><<<(unsigned)blocks, 64, 0, s>>>(a); \
+                                       else lookup_tiled_kernel<false, V_><<<(unsigned)blocks, 64, 0, s>>>(a); \
+                                       return ff::check_launch("ff_corr_lookup_tiled_fwd"); }
+    FF_LK_ABL(1) FF_LK_ABL(3) FF_LK_ABL(7) FF_LK_ABL(11) FF_LK_ABL(19) FF_LK_ABL(31)
+#undef FF_LK_ABL
     if (half) lookup_tiled_kernel<true><<<(unsigned)blocks, 64, 0, s>>>(a);
     else lookup_tiled_kernel<false><<<(unsigned)blocks, 64, 0, s>>>(a);
     return ff::check_launch("ff_corr_lookup_tiled_fwd");
