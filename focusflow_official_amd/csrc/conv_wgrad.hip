@@ -221,7 +221,10 @@ extern "C" int ff_conv2d_wgrad(const FFConvParams* pp, float* dw, long long dw_g
     FF_REQUIRE(M < (1ll << 30), "ff_conv2d_wgrad: too many pixels");
     const bool split = p.w_format != FF_W_F32 && p.groups == 1;
     FF_REQUIRE(!db || split, "ff_conv2d_wgrad: the bias gradient is produced by the split-format kernel only (groups == 1)");
-    if (split) return ff::conv2d_wgrad_split(p, dw, db, (int)M, cin, static_cast<hipStream_t>(stream));
+    if (split) {
+        if (dw_gstride == 0 && ff::conv2d_wgrad_patch(p, dw, db, cin, static_cast<hipStream_t>(stream)) == FF_OK) return FF_OK;
+        return ff::conv2d_wgrad_split(p, dw, db, (int)M, cin, static_cast<hipStream_t>(stream));
+    }
     WgArgs a;
     a.p = p;
     a.dw = dw;

@@ -51,6 +51,7 @@ __device__ __forceinline__ void input_scale(const unsigned int* x_amax, float& x
     }
 }
 int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int cin, hipStream_t s);   // conv_wgrad_split.hip
+int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hipStream_t s);          // conv_wgrad_patch.hip; 1 = not eligible
 int conv2d_fwd_small(const FFConvParams& p, int cin, hipStream_t s);         // conv_small.hip (Cout <= 2, 3x3); 1 = not eligible
 int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s);         // conv_patch.hip; 1 = not eligible
 int conv2d_fwd_ws(const FFConvParams& p, int cin, hipStream_t s);            // conv_ws.hip (wave-specialised); 1 = not eligible
