@@ -62,7 +62,7 @@ __device__ __forceinline__ f16x8 cat8(const f16x4 a, const f16x4 b) {
     return r;
 }
 
-// NT = taps a wave accumulates (3x3: 5 and 4 of the 9; 1x5 / 5x1: 3 and 2 of the 5); NXI = patch items per thread
+// NT = accumulators of a wave = (taps + 1) / 2: its own taps and the shared middle one; NXI = patch items per thread
 template <int NT, int NXI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_patch_kernel(const WpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     char* sX = smem + NPIX * PY;             // [PPIX][PX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wt = wave >> 1;
-    const int tap0 = wt * NT;                                   // first tap of this wave; it owns min(NT, ntaps - tap0)
-    const int ntw = min(NT, ntaps - tap0);                      // a tap past the end repeats the last one into an unused accumulator
+    // Taps = 2m + 1 over two wave groups: group wt owns the m taps wt (m + 1) .. and the MIDDLE tap m on the tile rows
+    // of its parity (both groups add their share of it to dW) - 4.5 (3x3) or 2.5 (1x5, 5x1) taps of MFMAs each.
+    const int wts = __builtin_amdgcn_readfirstlane(wt);
     const int t1 = blockIdx.x / a.nci, cchunk = blockIdx.x - t1 * a.nci;
     const int co0 = t1 * 64, ci0 = cchunk * 32;
     const int H = p.H, W = p.W;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     xs *= ff::XSPLIT; xinv *= 1.f / (ff::XSPLIT * ff::XSPLIT);
 
     // the input segment of this block's 32-channel chunk (block-uniform)
-    const float* xseg; int xld, xc;
+    const float* xseg; int xld, xc;        // xc: first channel of the chunk inside its segment
     {
         const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
         if (ci0 < c0) { xseg = p.x[0]; xld = p.x_ld[0]; xc = ci0; }
@@ -94,32 +95,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool yok = co0 + yq * 4 < p.Cout;                   // dY is channel-padded to a multiple of 4
 
     f32x4 ry[NYI], rx[NXI];
-    auto tile_coords = [&](int t, int& b, int& y0, int& x0) {
-        b = t / (a.tiles_y * a.tiles_x);
-        const int r = t - b * a.tiles_y * a.tiles_x;
-        const int ty = r / a.tiles_x;
-        y0 = ty * TH; x0 = (r - ty * a.tiles_x) * TW;
-    };
+    // Range-checked buffer loads: a pixel outside the image (or a channel quad past Cout) gets an out-of-range offset and
+    // reads as zeros - no branch around a load (a load under a branch costs a vmcnt(0) and its own exec juggling).
+    const long long pixels = (long long)p.B * H * W;
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.y), 0, (int)(pixels * p.y_ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xseg), 0, (int)(pixels * xld * 4), 0x00020000);
+    const int ycol = yok ? (co0 + yq * 4) * 4 : 0x7fffffff, xcol = (xc + xq * 4) * 4;
     auto load_tile = [&](int t) {
-        int b, y0, x0;
-        tile_coords(t, b, y0, x0);
+        const int b = t / (a.tiles_y * a.tiles_x), r = t - b * a.tiles_y * a.tiles_x;
+        const int ty = r / a.tiles_x, y0 = ty * TH, x0 = (r - ty * a.tiles_x) * TW;
 #pragma unroll
         for (int i = 0; i < NYI; ++i) {
             const int px = ypx + 16 * i, y = y0 + (px >> 4), x = x0 + (px & 15);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (yok && y < H && x < W) v = *reinterpret_cast<const f32x4*>(p.y + ((long long)(b * H + y) * W + x) * p.y_ld + co0 + yq * 4);
-            ry[i] = v;
+            const int off = (yok && y < H && x < W) ? ((b * H + y) * W + x) * (p.y_ld * 4) + ycol : 0x7fffffff;
+            ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
-            const int px = xpx + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (px < PPIX) {
-                const int py = px / PW, y = y0 - p.pad_h + py, x = x0 - p.pad_w + (px - py * PW);
-                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                    v = *reinterpret_cast<const f32x4*>(xseg + ((long long)(b * H + y) * W + x) * xld + xc + xq * 4);
-            }
-            rx[i] = v;
+            const int px = xpx + 32 * i, py = px / PW, y = y0 - p.pad_h + py, x = x0 - p.pad_w + (px - py * PW);
+            const int off = (px < PPIX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? ((b * H + y) * W + x) * (xld * 4) + xcol : 0x7fffffff;
+            rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
         }
     };
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -163,7 +158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int tapoff[NT];                          // patch-row offset of each of this wave's taps (wave-uniform)
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        const int tap = __builtin_amdgcn_readfirstlane(min(tap0 + k, ntaps - 1)), dy = tap / KW, dx = tap - dy * KW;
+        const int tap = k == NT - 1 ? ntaps / 2 : wts * NT + k, dy = tap / KW, dx = tap - dy * KW;
         tapoff[k] = (dy * PW + dx) * PX;
     }
     const int tbeg = blockIdx.y * a.tiles_per_block, tend = min(tbeg + a.tiles_per_block, a.tiles);
@@ -180,7 +175,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const f16x8 a0 = cat8(tr_read(py), tr_read(py + 4 * PY));
             const f16x8 a1 = cat8(tr_read(py + 128), tr_read(py + 4 * PY + 128));
 #pragma unroll
-            for (int k = 0; k < NT; ++k) {   // no branch in here: the compiler then reads tap k + 1's fragments under tap k's MFMAs
+            for (int k = 0; k < NT; ++k) {   // no branch around the own taps: tap k + 1's fragments are read under tap k's MFMAs
+                if (k == NT - 1 && (y & 1) != wts) break;          // the shared middle tap: rows of this group's parity only
                 const char* px = aX + (y * PW * PX + tapoff[k]);
                 const f16x8 b0 = cat8(tr_read(px), tr_read(px + 4 * PX));
                 const f16x8 b1 = cat8(tr_read(px + 64), tr_read(px + 4 * PX + 64));
@@ -197,8 +193,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        if (k >= ntw) break;
-        const int tap = tap0 + k;
+        const int tap = k == NT - 1 ? ntaps / 2 : wts * NT + k;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
@@ -247,7 +242,7 @@ int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hip
     if (cin % 32) return 1;
     for (int i = 0; i < FF_MAX_SEG; ++i)
         if (p.x_c[i] % 32) return 1;
-    if ((long long)p.B * p.H * p.W * std::max(p.y_ld, std::max(p.x_ld[0], std::max(p.x_ld[1], p.x_ld[2]))) >= (1ll << 31)) return 1;
+    if ((long long)p.B * p.H * p.W * std::max(p.y_ld, std::max(p.x_ld[0], std::max(p.x_ld[1], p.x_ld[2]))) * 4 >= (1ll << 31)) return 1;
     WpArgs a;
     a.p = p;
     a.dw = dw;

@@ -52,6 +52,9 @@ CONV_BWD = [
     ([256], [2], 3, 3, 1, (1, 1), 1, 16, 24, 0, False),          # flow head conv2
     ([128], [256, 256], 3, 3, 1, (1, 1), 1, 16, 24, 1, False),   # flow_head.conv1|mask.0 group
     ([256], [576], 1, 1, 1, (0, 0), 1, 16, 24, 0, False),        # mask.2 (Cout 576 > 256: bias-grad chunks)
+    ([96], [96], 3, 3, 1, (1, 1), 3, 23, 37, 0, False),          # patch-stationary wgrad: ragged 8x16 tiles, Cout 96 (second co tile half empty)
+    ([32], [64], 5, 1, 1, (2, 0), 2, 9, 17, 0, False),           # ... 5x1, one 32-channel chunk, tiles of 1 row / 1 column
+    ([32, 32], [40], 1, 5, 1, (0, 2), 2, 8, 16, 1, False),       # ... 1x5, two segments, Cout 40, exactly one tile
     ([64], [64], 3, 3, 1, (1, 1), 8, 96, 128, 0, False),         # long reduction (98k pixels), split + atomics (linear: a ReLU over 6M outputs flips masks at |y|~1e-7)
 ]
 
