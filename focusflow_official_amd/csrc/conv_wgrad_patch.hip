@@ -254,8 +254,11 @@ int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hip
     a.tiles_y = (p.H + TH - 1) / TH;
     a.tiles = p.B * a.tiles_y * a.tiles_x;
     const int combos = ((p.Cout + 63) / 64) * a.nci;
-    static const int target = getenv("FF_WGRAD_PATCH_BLOCKS") ? atoi(getenv("FF_WGRAD_PATCH_BLOCKS")) : 1024;   // tuning knob
-    int splits = std::max(1, std::min(a.tiles, (target + combos - 1) / combos));
+    // Pixel splits: at most one resident wave of blocks (2 per CU: every block ends in NT x 16 atomic wave-instructions and
+    // restages from scratch, so more, shorter blocks lost 10-25 % in tools/wgrad_table.py), and the fewest blocks that
+    // keep the longest block's tile count.
+    static const int target = getenv("FF_WGRAD_PATCH_BLOCKS") ? atoi(getenv("FF_WGRAD_PATCH_BLOCKS")) : 512;   // tuning knob
+    int splits = std::max(1, std::min(a.tiles, target / combos));
     a.tiles_per_block = (a.tiles + splits - 1) / splits;
     splits = (a.tiles + a.tiles_per_block - 1) / a.tiles_per_block;
     const int ppix = (TH + p.KH - 1) * (TW + p.KW - 1);
