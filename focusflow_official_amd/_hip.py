@@ -66,7 +66,7 @@ _SIGS = {
     "ff_act_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp],
     "ff_dilate2": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_norm_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp, _fp,
-                    C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+                    C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "ff_gru_rh_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
     "ff_gru_blend_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
                          _fp, C.c_int, _ll, C.c_int, _fp],

@@ -124,6 +124,7 @@ struct NormBwdArgs {
     int HW, C, per_sample, relu, has_res, fixed_stats;
     double inv_count;
     float eps;
+    unsigned int* dx_amax;             // nullable: bits of max|dx| (atomicMax; the consumer conv's gradient scale)
 };
 
 __device__ __forceinline__ void norm_coeffs(const NormBwdArgs& a, int b, int c, float& mean, float& rstd, float& gm, float& bt) {
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormBwdArgs a
     __syncthreads();
     const int cg = a.C >> 2;
     const int total = a.HW * cg;
+    float mx = 0.f;
     for (int i = blockIdx.x * 256 + t; i < total; i += gridDim.x * 256) {
         const int g4 = i % cg;
         const long long pix = (long long)b * a.HW + i / cg;
@@ -219,6 +221,19 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormBwdArgs a
         }
         *reinterpret_cast<f32x4*>(a.dx + pix * a.dx_ld + g4 * 4) = dxv;
         if (a.dres) *reinterpret_cast<f32x4*>(a.dres + pix * a.dres_ld + g4 * 4) = drv;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(dxv[0]), fabsf(dxv[1]))), fmaxf(fabsf(dxv[2]), fabsf(dxv[3])));
+    }
+    if (a.dx_amax) {                   // what ff_act_bwd would measure in a pass of its own over dx
+        __shared__ float wmax[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((t & 63) == 0) wmax[t >> 6] = mx;
+        __syncthreads();
+        if (t == 0) {
+            mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (mx > 0.f && mx < INFINITY && __float_as_uint(mx) > *reinterpret_cast<volatile unsigned int*>(a.dx_amax))
+                atomicMax(a.dx_amax, __float_as_uint(mx));
+        }
     }
 }
 
@@ -362,7 +377,7 @@ extern "C" int ff_dilate2(const float* src, int src_ld, float* dst, int B, int H
 extern "C" int ff_norm_bwd(const float* x, int x_ld, const float* dy, int dy_ld, const float* y, int y_ld,
                            const double* fstats, double* bstats, int per_sample, int fixed_stats, float eps,
                            const float* gamma, const float* beta, int relu, float* dx, int dx_ld, float* dres,
-                           int dres_ld, int B, int HW, int C, void* stream) {
+                           int dres_ld, int B, int HW, int C, unsigned int* dx_amax, void* stream) {
     FF_REQUIRE(x && dy && fstats && bstats && dx, "ff_norm_bwd: null pointer");
     FF_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 256, "ff_norm_bwd: C=%d unsupported", C);
     FF_REQUIRE(x_ld % 4 == 0 && dy_ld % 4 == 0 && dx_ld % 4 == 0 && ff::aligned16(x) && ff::aligned16(dy) && ff::aligned16(dx), "ff_norm_bwd: alignment");
@@ -374,6 +389,7 @@ extern "C" int ff_norm_bwd(const float* x, int x_ld, const float* dy, int dy_ld,
     a.HW = HW; a.C = C; a.per_sample = per_sample; a.relu = relu; a.has_res = dres != nullptr; a.fixed_stats = fixed_stats;
     a.inv_count = 1.0 / ((double)HW * (per_sample ? 1 : B));
     a.eps = eps;
+    a.dx_amax = dx_amax;
     hipStream_t s = static_cast<hipStream_t>(stream);
     dim3 g1((HW + NSLAB - 1) / NSLAB, B);
     norm_bwd_stats_kernel<<<g1, 256, 0, s>>>(a);

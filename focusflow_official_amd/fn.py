@@ -7,6 +7,8 @@ launch when no gradient is being recorded and the autograd node otherwise.
 """
 from typing import List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -39,6 +41,9 @@ class GraphScope:
     def __init__(self):
         self.acc, self.gates = {}, {}
         self._amax_pool, self._amax_used = None, 0
+        # data_ptr of a gradient tensor -> (word with the bits of its max|.|, shape): left by the producer of the
+        # gradient (NormFn.backward), consumed - and removed - by the ConvFn.backward it flows into
+        self.amax_hint = {}
 
     def amax_word(self, device):
         if self._amax_pool is None or self._amax_used >= self._amax_pool.numel():
@@ -83,6 +88,7 @@ class ParamGate(torch.autograd.Function):
 
 
 _scope: Optional[GraphScope] = None
+_AMAX_HINT = os.environ.get("FF_AMAX_HINT", "1") != "0"      # A/B switch: the norm backward measures max|dx| for the conv it feeds
 
 
 def begin_graph() -> GraphScope:
@@ -135,8 +141,12 @@ class ConvFn(torch.autograd.Function):
         xs, y = list(saved[:nseg]), saved[nseg]
         dy = _dense(dy)
         scope = ctx.scope
-        g, amax = ops.act_bwd(dy, y, act, ctx.out_scale, pc.cout, want_amax=True,    # (B,Ho,Wo,Cpad), zero padded
-                              amax=scope.amax_word(dy.device) if scope is not None else None)
+        hint = scope.amax_hint.pop(dy.data_ptr(), None) if scope is not None else None
+        if hint is not None and hint[1] == tuple(dy.shape) and ops.act_bwd_is_alias(dy, act, ctx.out_scale, pc.cout):
+            g, amax = dy, hint[0]          # conv -> norm: the norm's backward kernel has measured max|dy| already
+        else:
+            g, amax = ops.act_bwd(dy, y, act, ctx.out_scale, pc.cout, want_amax=True,    # (B,Ho,Wo,Cpad), zero padded
+                                  amax=scope.amax_word(dy.device) if scope is not None else None)
         grads: List[Optional[Tensor]] = [None] * NFIX
         # input gradient: forward conv over g with flipped/transposed weights
         need_dx = any(ctx.needs_input_grad[NFIX + i] for i in range(nseg))
@@ -196,6 +206,7 @@ class NormFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, res, per_sample, fixed, eps, relu, stats):
         y = ops.norm_apply(x, stats, per_sample, eps, gamma, beta, act=ACT_RELU if relu else ACT_NONE, res=res)
         ctx.meta = (per_sample, fixed, eps, relu, res is not None)
+        ctx.scope = _scope
         ctx.save_for_backward(x, gamma, beta, y if res is not None else None, stats)
         return y
 
@@ -203,7 +214,11 @@ class NormFn(torch.autograd.Function):
     def backward(ctx, dy):
         per_sample, fixed, eps, relu, has_res = ctx.meta
         x, gamma, beta, y, stats = ctx.saved_tensors
-        dx, dres, bst = ops.norm_bwd(x, _dense(dy), y, stats, per_sample, fixed, eps, gamma, beta, relu, has_res)
+        scope = ctx.scope
+        word = scope.amax_word(x.device) if (scope is not None and _AMAX_HINT) else None
+        dx, dres, bst = ops.norm_bwd(x, _dense(dy), y, stats, per_sample, fixed, eps, gamma, beta, relu, has_res, amax=word)
+        if word is not None:
+            scope.amax_hint[dx.data_ptr()] = (word, tuple(dx.shape))
         dgamma = dbeta = None
         if gamma is not None and ctx.needs_input_grad[1]:
             dgamma = bst[0, :, 1].float()

@@ -648,14 +648,20 @@ def channel_sum(g: Tensor, c: int) -> Tensor:
     return torch.cat(outs)[:c].float()
 
 
-def norm_bwd(x, dy, y, fstats, per_sample, fixed_stats, eps, gamma, beta, relu, want_dres):
+def act_bwd_is_alias(dy: Tensor, act: int, scale: float, c: int) -> bool:
+    """act_bwd's no-copy case: no activation, no scale, nothing to pad - the conv's gradient IS dy."""
+    return act == ACT_NONE and scale == 1.0 and dy.shape[3] == c == (c + 3) // 4 * 4 and _ld(dy) == c and dy.data_ptr() % 16 == 0
+
+
+def norm_bwd(x, dy, y, fstats, per_sample, fixed_stats, eps, gamma, beta, relu, want_dres, amax: Optional[Tensor] = None):
+    """amax: a zeroed int32 word that receives the bits of max|dx| (saves the consumer conv's measuring pass)."""
     b, h, w, c = x.shape
     bstats = torch.zeros((b if per_sample else 1, c, 2), dtype=torch.float64, device=x.device)
     dx = empty_nhwc(b, h, w, c, x)
     dres = empty_nhwc(b, h, w, c, x) if want_dres else None
     _hip.call("ff_norm_bwd", _p(x), _ld(x), _p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(fstats),
               _p(bstats), int(per_sample), int(fixed_stats), eps, _p(gamma), _p(beta), int(relu), _p(dx), c,
-              _p(dres), c if want_dres else 0, b, h * w, c, _stream())
+              _p(dres), c if want_dres else 0, b, h * w, c, _p(amax), _stream())
     return dx, dres, bstats
 
 

@@ -254,11 +254,13 @@ int ff_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* g, i
 int ff_dilate2(const float* src, int src_ld, float* dst, int B, int Ho, int Wo, int Hd, int Wd, int C,
                void* stream);
 /* Instance/BatchNorm backward for y = relu?(norm(x)) [; y = relu(y + res)].
- * bstats (fp64 [S][C][2], CALLER ZEROES) returns {sum g, sum g*xhat} = {dbeta, dgamma}. */
+ * bstats (fp64 [S][C][2], CALLER ZEROES) returns {sum g, sum g*xhat} = {dbeta, dgamma}.
+ * dx_amax (nullable, a zeroed word): receives the bits of max|dx| - what ff_act_bwd would measure in a pass of its own
+ * before the producing convolution's gradient kernels (FFConvParams.x_amax). */
 int ff_norm_bwd(const float* x, int x_ld, const float* dy, int dy_ld, const float* y, int y_ld,
                 const double* fstats, double* bstats, int per_sample, int fixed_stats, float eps,
                 const float* gamma, const float* beta, int relu, float* dx, int dx_ld,
-                float* dres, int dres_ld, int B, int HW, int C, void* stream);
+                float* dres, int dres_ld, int B, int HW, int C, unsigned int* dx_amax, void* stream);
 /* GridSampler2DBackward (w.r.t. the pyramid only: coords are detached, raft.py:216) and the AvgPool2DBackward chain:
  * ff_corr_lookup_tiled_bwd / ff_corr_pyramid_tiled_bwd above (gradient planes share the tiled fp32 layout). */
 int ff_gru_rh_bwd(const float* drh, int drh_ld, const float* r, int r_ld, const float* h, int h_ld,
