@@ -64,6 +64,7 @@ _SIGS = {
     "ff_unpack_conv_wgrad": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "ff_pack_conv_weight_dgrad": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp],
     "ff_act_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp],
+    "ff_deconv4x4s2_small": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, _fp],
     "ff_dilate2": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_norm_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp, _fp,
                     C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],

@@ -122,3 +122,105 @@ int conv2d_fwd_small(const FFConvParams& p, int cin, hipStream_t s) {
     return check_launch("ff_conv2d_fwd(small)");
 }
 }  // namespace ff
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nn.ConvTranspose2d(Cin, Cout <= 2, kernel 4, stride 2, padding 1) - FF-PWC's netUpflow / netUpfeat
+// (ff_pwcnet.py:243-244) - without the zero-dilated copy of the input and without a matrix tile: on the MFMA path the
+// 640 -> 2 layer at 56 x 128 took 257 us (a 4x larger, three-quarters-zero input and 62 of 64 tile columns empty).
+// Written as the equivalent forward convolution over the dilated input D (D[2i][2j] = x[i][j], 4 x 4 kernel Wf = the
+// flipped, transposed parameter, pad 2): out[oy][ox] = sum_{a,b} D[oy-2+a][ox-2+b] Wf[a][b]; D is non-zero only at even
+// coordinates, so an output pixel sees 2 x 2 taps: a = oy mod 2 (+2), input row (oy - 2 + a) / 2, likewise in x.
+// One wave = a run of 8 output pixels of one output row (6 input columns x 2 input rows); lane = 4 input channels
+// (256 channels per pass); the 2 x 4 taps of the row parity stay in registers; exact fp32.
+namespace {
+
+struct DArgs {
+    const float* x; int x_ld;
+    const float* w;          // [Cout][16 * Cin] fp32 rows, k = (a * 4 + b) * Cin + ci  (ff_pack_conv_weight of Wf)
+    const float* bias;
+    float* y; int y_ld;
+    int B, H, W, Cin, runs_x;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256) void deconv4x4s2_small_kernel(const DArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int Ho = 2 * a.H, Wo = 2 * a.W;
+    const long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);       // (b, oy, run)
+    if (task >= (long long)a.B * Ho * a.runs_x) return;
+    const int run = (int)(task % a.runs_x);
+    const int oy = (int)((task / a.runs_x) % Ho);
+    const int b = (int)(task / ((long long)a.runs_x * Ho));
+    const int ox0 = run * RUN, n0 = ox0 >> 1;               // RUN = 8 outputs = input columns n0 - 1 .. n0 + 4
+    const int a0 = oy & 1;                                   // kernel rows a0, a0 + 2 -> input rows iy0, iy0 + 1
+    const int iy0 = (oy - 2 + a0) >> 1;                      // arithmetic shift: -1 for oy = 0
+    const int K = 16 * a.Cin;
+
+    float mine[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) mine[c] = 0.f;
+    for (int cbase = 0; cbase < a.Cin; cbase += 256) {
+        const int cpos = cbase + lane * 4;
+        const bool cok = cpos < a.Cin;
+        f32x4 w[COUT][2][4];                                  // [co][row tap a0 + 2 r][b]
+#pragma unroll
+        for (int c = 0; c < COUT; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb)
+                    w[c][r][bb] = cok ? *reinterpret_cast<const f32x4*>(a.w + (long long)c * K + ((a0 + 2 * r) * 4 + bb) * a.Cin + cpos)
+                                      : (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto load = [&](int iy, int ix) {                     // no load under a branch: clamp, then select
+            const bool ok = cok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int yc = min(max(iy, 0), a.H - 1), xc = min(max(ix, 0), a.W - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((long long)(b * a.H + yc) * a.W + xc) * a.x_ld + (cok ? cpos : 0));
+            return ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+        f32x4 col[6][2];                                       // input columns n0 - 1 + j, rows iy0 + r
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) col[j][r] = load(iy0 + r, n0 - 1 + j);
+#pragma unroll
+        for (int i = 0; i < RUN; ++i) {                       // ox = ox0 + i: b0 = i & 1, input columns (ox - 2 + b0) / 2 (+1)
+            const int b0 = i & 1, j0 = ((i - 2 + b0) >> 1) + 1;   // column slot of the first tap: (ox - 2 + b0) / 2 - (n0 - 1)
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) s = dot4(col[j0 + t][r], w[c][r][b0 + 2 * t], s);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                if (lane == i) mine[c] += s;
+            }
+        }
+    }
+    const int ox = ox0 + lane;
+    if (lane < RUN && ox < Wo) {
+        const long long m = ((long long)b * Ho + oy) * Wo + ox;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) a.y[m * a.y_ld + c] = mine[c] + (a.bias ? a.bias[c] : 0.f);
+    }
+}
+
+}  // namespace
+
+extern "C" int ff_deconv4x4s2_small(const float* x, int x_ld, int B, int H, int W, int Cin, const float* w, const float* bias,
+                                    int Cout, float* y, int y_ld, void* stream) {
+    FF_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 4 == 0 && (Cout == 1 || Cout == 2),
+               "ff_deconv4x4s2_small: Cin must be a multiple of 4, Cout 1 or 2");
+    FF_REQUIRE(x_ld >= Cin && x_ld % 4 == 0 && y_ld >= Cout && ff::aligned16(x) && ff::aligned16(w), "ff_deconv4x4s2_small: ld/alignment");
+    DArgs a;
+    a.x = x; a.x_ld = x_ld; a.w = w; a.bias = bias; a.y = y; a.y_ld = y_ld;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin;
+    a.runs_x = (2 * W + RUN - 1) / RUN;
+    const long long tasks = (long long)B * 2 * H * a.runs_x;
+    const unsigned blocks = (unsigned)((tasks + 3) / 4);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cout == 1) deconv4x4s2_small_kernel<1><<<blocks, 256, 0, s>>>(a);
+    else deconv4x4s2_small_kernel<2><<<blocks, 256, 0, s>>>(a);
+    return ff::check_launch("ff_deconv4x4s2_small");
+}

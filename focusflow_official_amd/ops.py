@@ -630,6 +630,15 @@ def act_bwd(dy: Tensor, y: Optional[Tensor], act: int, scale: float, c: int, wan
     return (g, amax) if want_amax else g
 
 
+def deconv4x4s2_small(x: Tensor, w_rows: Tensor, bias: Optional[Tensor], cout: int, out: Tensor) -> Tensor:
+    """ConvTranspose2d(Cin, cout <= 2, 4, 2, 1) of NHWC x (B,H,W,Cin) into `out` (B,2H,2W,>=cout) - ff_deconv4x4s2_small.
+    w_rows: fp32 rows [cout][16*Cin] of the equivalent forward conv (transposed + flipped parameter, pack_conv_weight)."""
+    b, h, w, cin = x.shape
+    assert out.shape[:3] == (b, 2 * h, 2 * w) and w_rows.shape == (cout, 16 * cin) and w_rows.dtype == torch.float32
+    _hip.call("ff_deconv4x4s2_small", _p(x), _ld(x), b, h, w, cin, _p(w_rows), _p(bias), cout, _p(out), _ld(out), _stream())
+    return out
+
+
 def dilate2(g: Tensor, hd: int, wd: int) -> Tensor:
     b, ho, wo, c = g.shape
     out = empty_nhwc(b, hd, wd, c, g)

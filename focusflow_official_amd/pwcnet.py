@@ -17,6 +17,8 @@ resized first and the flow is resized / rescaled back, as the reference does; BA
 needs no resize).  Training: when gradients are recorded every step goes through an autograd Function whose backward is HIP as well
 (conv / transposed conv / dilated conv gradients, cost volume, backwarp); torch.cat builds the DenseNet tensors.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -38,6 +40,8 @@ def _pad4(c):
 # instead of the generic im2col loader (which was 65 % of the forward).  The autograd path keeps the 84 / 4 / 4 layout.
 VOLP, FLP = 96, 16
 
+
+_DIRECT_DECONV = os.environ.get("FF_DIRECT_DECONV", "1") != "0"     # A/B switch: ff_deconv4x4s2_small for netUpflow / netUpfeat
 
 class _Packed:
     """Packed weights of one conv whose input is a padded-piece buffer: `pieces` = [(real, padded), ...]."""
@@ -64,6 +68,7 @@ class _Packed:
             packed = torch.empty((co, kh * kw * cpad), dtype=torch.float32, device=w.device)
             ops.pack_conv_weight(wp, packed, cpad, 0)
             self.fmt = 0 if (co <= 2 and kh == 3 and not self.transposed) else ops.w_format()   # small heads: conv_small.hip (fp32)
+            self.w32 = packed if (self.transposed and co <= 2 and kh == 4) else None           # -> ops.deconv4x4s2_small
             self.w = ops.pack_split(packed) if self.fmt else packed
             self.b = cv.bias.detach()
             self.cout, self.k = co, kh
@@ -290,8 +295,13 @@ class Decoder(nn.Module):
             feat_slot = buf[..., 448 + VOLP + one.shape[3] + FLP:]
             pf, pb = prev["tenFlow"], prev["tenFeat"]
             hp, wp = pf.shape[1], pf.shape[2]
-            self._upflow(ops.dilate2(pf, 2 * hp - 1, 2 * wp - 1), pad=2, out=flow_slot[..., :2])      # ConvTranspose2d
-            self._upfeat(ops.dilate2(pb, 2 * hp - 1, 2 * wp - 1), pad=2, out=feat_slot[..., :2])
+            if _DIRECT_DECONV:     # ConvTranspose2d(., 2, 4, 2, 1) without the zero-dilated copy and the matrix tile
+                for pk, src, slot in ((self._upflow, pf, flow_slot), (self._upfeat, pb, feat_slot)):
+                    pk.get()
+                    ops.deconv4x4s2_small(src, pk.w32, pk.b, 2, slot)
+            else:
+                self._upflow(ops.dilate2(pf, 2 * hp - 1, 2 * wp - 1), pad=2, out=flow_slot[..., :2])      # ConvTranspose2d
+                self._upfeat(ops.dilate2(pb, 2 * hp - 1, 2 * wp - 1), pad=2, out=feat_slot[..., :2])
             warped = pwc.backwarp(two, flow_slot, BACKWARP_SCALE[self.level])
             ops.act_copy(one, buf[..., 448 + VOLP: 448 + VOLP + one.shape[3]], ACT_NONE)
         vol = buf[..., 448:448 + VOLP]

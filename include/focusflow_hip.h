@@ -253,6 +253,13 @@ int ff_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* g, i
 /* zero-dilation by 2: dst[b][2y][2x][:] = src[b][y][x][:] (input gradient of stride-2 convs) */
 int ff_dilate2(const float* src, int src_ld, float* dst, int B, int Ho, int Wo, int Hd, int Wd, int C,
                void* stream);
+/* nn.ConvTranspose2d(Cin, Cout <= 2, kernel 4, stride 2, padding 1) as a direct fp32 kernel: FF-PWC's netUpflow /
+ * netUpfeat (ff_pwcnet.py:243-244, called at :283-284).  x: NHWC [B][H][W][x_ld] (Cin % 4 == 0), y: [B][2H][2W][y_ld];
+ * w: the fp32 rows ff_pack_conv_weight makes of the EQUIVALENT forward convolution's weight (the parameter transposed to
+ * [Cout][Cin][4][4] and flipped in both kernel axes): [Cout][16 * Cin], k = (a * 4 + b) * Cin + ci.  Replaces
+ * ff_dilate2 + ff_conv2d_fwd for these layers (same result to fp32 rounding). */
+int ff_deconv4x4s2_small(const float* x, int x_ld, int B, int H, int W, int Cin, const float* w, const float* bias,
+                         int Cout, float* y, int y_ld, void* stream);
 /* Instance/BatchNorm backward for y = relu?(norm(x)) [; y = relu(y + res)].
  * bstats (fp64 [S][C][2], CALLER ZEROES) returns {sum g, sum g*xhat} = {dbeta, dgamma}.
  * dx_amax (nullable, a zeroed word): receives the bits of max|dx| - what ff_act_bwd would measure in a pass of its own

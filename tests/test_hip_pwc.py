@@ -273,3 +273,24 @@ def test_ffpwcnet_mask_modes(modal):
             assert [crc(i1), crc(i2), crc(m1)] == g[f"{modal}_{tag}_in_crc"].tolist(), "synthetic inputs drifted"
             close(got[0].cpu(), g[f"{modal}_{tag}_flow2"], tol=2e-4, what=f"{modal} {tag} finest flow vs reference")
             close(got_full.cpu(), g[f"{modal}_{tag}_full"], tol=2e-4, what=f"{modal} {tag} test_mode flow vs reference")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,b,h,w", [(4, 2, 2, 7, 16), (644, 2, 1, 14, 32), (36, 1, 1, 5, 9)])
+def test_direct_transposed_conv_matches_conv_transpose2d(cin, cout, b, h, w):
+    """ff_deconv4x4s2_small (netUpflow / netUpfeat, ff_pwcnet.py:243-244) against nn.functional.conv_transpose2d in fp64."""
+    import torch.nn.functional as F
+    from focusflow_official_amd import ops
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5        # ConvTranspose2d layout [Cin][Cout][k][k]
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv_transpose2d(x.double(), wt.double(), bias.double(), stride=2, padding=1).float()
+    wf = wt.permute(1, 0, 2, 3).flip(2, 3).contiguous().cuda()              # the equivalent forward conv's weight
+    rows = torch.empty((cout, 16 * cin), device="cuda")
+    ops.pack_conv_weight(wf, rows, cin, 0)
+    out = torch.full((b, 2 * h, 2 * w, 4), 7.0, device="cuda")               # a wider slot: channels >= cout stay untouched
+    ops.deconv4x4s2_small(x.permute(0, 2, 3, 1).contiguous().cuda(), rows, bias.cuda(), cout, out)
+    got = out[..., :cout].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert bool((out[..., cout:] == 7.0).all())
