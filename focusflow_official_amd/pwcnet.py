@@ -456,8 +456,10 @@ class FF_PWCNET(nn.Module):
             finally:
                 fn.end_graph()
         else:
-            f1 = self.netExtractor.run(i1, m1)
-            f2 = self.netExtractor.run(i2, m2)
+            # both frames through the extractor as ONE batch of 2B (no normalisation in it: the same arithmetic as the
+            # reference's two calls, ff_pwcnet.py:436-437) - half the launches, grids twice as large at the tiny levels
+            f12 = self.netExtractor.run(torch.cat([i1, i2], 0), torch.cat([m1, m2], 0))
+            f1, f2 = [f[:b] for f in f12], [f[b:] for f in f12]
             for level, dec in decoders:
                 est = dec.run(f1[level - 1], f2[level - 1], est)
                 if level == 2:
