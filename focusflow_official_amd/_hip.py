@@ -29,6 +29,7 @@ class FFConvParams(C.Structure):
         ("dil_h", C.c_int), ("dil_w", C.c_int), ("x_amax", _fp),
         ("in_scale", _fp), ("in_shift", _fp), ("in_act", C.c_int),
         ("res2", _fp), ("res2_ld", C.c_int), ("res_split", C.c_int),
+        ("splitk_ws", _fp), ("splitk", C.c_int),
     ]
 
 
@@ -104,7 +105,7 @@ _SIGS = {
     "ff_scale_add_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int,
                          C.c_int, _fp],
 }
-EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems"])
+EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint"])
 
 _lib = None
 
@@ -133,6 +134,8 @@ def load():
     lib.ff_abi_version.argtypes = []
     lib.ff_corr_plane_elems.restype = C.c_int
     lib.ff_corr_plane_elems.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.ff_conv2d_splitk_hint.restype = C.c_int
+    lib.ff_conv2d_splitk_hint.argtypes = [C.POINTER(FFConvParams)]
     _lib = lib
     return lib
 

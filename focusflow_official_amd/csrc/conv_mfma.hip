@@ -247,6 +247,13 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 
 }  // namespace
 
+extern "C" int ff_conv2d_splitk_hint(const FFConvParams* pp) {
+    if (!pp || pp->groups != 1 || pp->w_format == FF_W_F32) return 0;
+    int cin = 0;
+    for (int s = 0; s < FF_MAX_SEG && pp->x_c[s]; ++s) cin += pp->x_c[s];
+    return cin > 0 ? ff::conv2d_splitk_hint(*pp, cin) : 0;
+}
+
 extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     FF_REQUIRE(pp != nullptr, "ff_conv2d_fwd: null params");
     const FFConvParams& p = *pp;

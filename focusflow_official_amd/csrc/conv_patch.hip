@@ -36,6 +36,7 @@ struct PArgs {
     int Cin, nci;            // channels, 32-channel chunks
     int tiles_x, tiles_y, n_tiles;
     long long w_row_bytes;
+    int nci_split;           // SPLITK: input chunks per K split (blockIdx.y), partial sums to p.splitk_ws
 };
 
 __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {     // both halves on v's scale (ff_common.h)
@@ -49,7 +50,10 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {   
 
 // NITEM = patch items per thread; TM x TN = 32-pixel x 32-channel MFMA tiles per wave (block: 2 x 2 waves =
 // 64 TM pixels x 64 TN channels); ABL = timing-only ablation
-template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false, bool INORM = false>   // WB = weight buffers in LDS
+// SPLITK: blockIdx.y owns a range of the 32-channel input chunks and writes raw partial sums (splitk_finish_kernel adds
+// them in a fixed order and applies the epilogue): small planes with long reductions - FF-PWC's DenseNet decoders at
+// 7x16 .. 56x128 - are otherwise 8-60 blocks walking 100-190 taps one after the other on an empty chip.
+template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false, bool INORM = false, bool SPLITK = false>   // WB = weight buffers in LDS
 __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
     constexpr int TH = 4 * TM, BN = 64 * TN, NW = 2 * TN;       // NW = 16-byte weight pieces per thread and tap
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -185,19 +189,21 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
     f16x8 abl_f;                               // ABL 5 only
 #pragma unroll
     for (int i = 0; i < 8; ++i) abl_f[i] = (_Float16)(0.37f + 0.01f * (float)((lane * 7 + i * 3) & 31));
-    load_patch(0);
-    load_w(0);
+    const int c_beg = SPLITK ? (int)blockIdx.y * a.nci_split : 0;
+    const int c_end = SPLITK ? min(c_beg + a.nci_split, a.nci) : a.nci;
+    load_patch(c_beg);
+    load_w(c_beg);
     int wbuf = 0;
-    for (int c = 0; c < a.nci; ++c) {
+    for (int c = c_beg; c < c_end; ++c) {
         __syncthreads();                     // previous chunk's taps are done with sP
-        if (ABL != 6 || c == 0) store_patch();       // ABL 6: timing only, the patch is staged once
+        if (ABL != 6 || c == c_beg) store_patch();       // ABL 6: timing only, the patch is staged once
         store_w(wbuf);
         __syncthreads();
-        if (c + 1 < a.nci && ABL != 6) load_patch(c + 1);        // lands during this chunk's taps
+        if (c + 1 < c_end && ABL != 6) load_patch(c + 1);        // lands during this chunk's taps
         for (int tap = 0; tap < ntaps; ++tap) {
             const bool last = tap + 1 == ntaps;
             const int next_kc = last ? (c + 1) : (tap + 1) * a.nci + c;   // K order = (tap, ci): chunk index tap*nci + c
-            if (!(last && c + 1 == a.nci) && ABL != 1 && ABL != 2) load_w(last ? c + 1 : next_kc);
+            if (!(last && c + 1 == c_end) && ABL != 1 && ABL != 2) load_w(last ? c + 1 : next_kc);
             // Keep the next tap's weight loads HERE: left alone, the scheduler sinks them below this tap's MFMAs
             // (8 fewer live registers) to two MFMAs before the store that waits for them - an L2 round trip per tap
             // with nothing to hide it.
@@ -254,6 +260,23 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
     }
 
     // epilogue: acc[t][j][r]: column n = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*lh = pixel index within the m-tile
+    if constexpr (SPLITK) {           // raw partial sums [split][pixel][Cout]; bias, scale, activation, residual: splitk_finish_kernel
+        float* ws = p.splitk_ws + (long long)blockIdx.y * pix_total * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + li;
+            if (n >= p.Cout) continue;
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + ((pi - (pi >> 4) * rot) & 15);
+                    if (y < H && x < W) ws[(((long long)bimg * H + y) * W + x) * p.Cout + n] = acc[t][j][r] * xinv;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + li;
@@ -299,12 +322,36 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, WB>(a); }
 // one weight buffer: 35 KB of LDS, so four blocks fit a CU if the registers allow four waves per SIMD
-template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0, bool INORM = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN, INORM>(a); }
+template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0, bool INORM = false, bool SPLITK = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN, INORM, SPLITK>(a); }
+
+// sum of the K splits in a fixed order, then the epilogue of conv_patch_body (same operations in the same order)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const FFConvParams p, int splits, long long npix) {
+    const long long total = npix * p.Cout;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / p.Cout;
+        const int n = (int)(i - m * p.Cout);
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += p.splitk_ws[(long long)s * total + i];
+        v += p.bias ? p.bias[n] : 0.f;
+        v *= p.out_scale;
+        if (p.ch_scale) v = v * p.ch_scale[n] + p.ch_shift[n];
+        v = ff::apply_act(v, p.act);
+        if (p.res) v = ff::apply_act(v + p.res[m * p.res_ld + n], p.act_res);
+        p.y[m * p.y_ld + n] = v;
+    }
+}
 
 template <int TERMS, int NITEM, int TM, int TN, int OCC>
 int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
     const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    if (a.p.splitk > 1) {        // validated by the caller: no in_scale, no res2, workspace present
+        const int splits = (a.nci + a.nci_split - 1) / a.nci_split;
+        conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, true><<<dim3((unsigned)blocks, splits), 256, lds, s>>>(a);
+        const long long npix = (long long)a.p.B * a.p.H * a.p.W, total = npix * a.p.Cout;
+        splitk_finish_kernel<<<(unsigned)std::min<long long>((total + 255) / 256, 2048), 256, 0, s>>>(a.p, splits, npix);
+        return ff::check_launch("ff_conv2d_fwd(patch, split-K)");
+    }
     static const bool pin = !(getenv("FF_PATCH_PIN") && atoi(getenv("FF_PATCH_PIN")) == 0);      // A/B switch
     if (a.p.in_scale) {          // normalise-on-load variant
         conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
@@ -395,6 +442,9 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
         if (abl == 2) return launch<3, 6, 2, 1, 2>(a, lds, s);
         return launch<3, 6, 2, 1, 3>(a, lds, s);
     }
+    // split-K (FFConvParams.splitk, see conv2d_splitk_hint): the 4-row high-occupancy variant only
+    if (!(occ && th == 4 && p.splitk > 1 && p.splitk_ws && !p.in_scale && !p.res2)) a.p.splitk = 0;
+    a.nci_split = a.p.splitk > 1 ? (a.nci + a.p.splitk - 1) / a.p.splitk : a.nci;
     if (occ) return th == 8 ? launch_occ<3, 6, 2, 1, 4>(a, lds, s) : launch_occ<3, 4, 1, 1, 5>(a, lds, s);
     if (p.in_scale) return 1;            // only the two variants above normalise while loading (the caller fails loudly)
 #define FF_PATCH_CASE(TH_, TN_, NI_) \
@@ -406,5 +456,30 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     FF_PATCH_CASE(16, 1, 11) FF_PATCH_CASE(16, 1, 16)
 #undef FF_PATCH_CASE
     return 1;
+}
+
+// How many K splits ff_conv2d_fwd would use for this convolution if given a workspace (0: none).  Same eligibility as
+// conv2d_fwd_patch's 4-row variant; worth it when the plane is so small that the blocks do not even cover the CUs and
+// the reduction is long: every split needs >= 2 chunks, the grid is brought to ~768 blocks at most.
+int conv2d_splitk_hint(const FFConvParams& p, int cin) {
+    static const bool enabled = !getenv("FF_NO_PATCH_CONV") && !(getenv("FF_SPLITK") && atoi(getenv("FF_SPLITK")) == 0);
+    if (!enabled || p.w_format != FF_W_F16X3 || p.in_scale || p.res2) return 0;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
+    if (p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1) return 0;
+    if (p.KH % 2 == 0 || p.KW % 2 == 0 || p.pad_h != p.KH / 2 || p.pad_w != p.KW / 2 || p.KH * p.KW < 3) return 0;
+    if (cin % 32) return 0;
+    for (int i = 0; i < FF_MAX_SEG; ++i)
+        if (p.x_c[i] % 32) return 0;
+    const int tiles_x = (p.W + TW - 1) / TW, n_tiles = (p.Cout + 63) / 64;
+    if ((long long)p.B * ((p.H + 7) / 8) * tiles_x * n_tiles >= 512) return 0;            // the dispatcher takes 8-row tiles
+    const int npix = (4 + p.KH - 1) * (TW + p.KW - 1);
+    if ((npix * 8 + 255) / 256 > 4) return 0;
+    const long long blocks = (long long)p.B * ((p.H + 3) / 4) * tiles_x * n_tiles;
+    const int nci = cin / 32;
+    // long reductions only (more than 72 tap steps per block): below that the finishing launch and the workspace cost a
+    // host-bound caller more than the kernel gains (FF-RAFT's update block at one pair per step: 7.3 -> 8.0 ms eager)
+    if (blocks > 256 || nci < 6 || nci * p.KH * p.KW <= 72) return 0;
+    const int splits = (int)std::min<long long>(std::min(16, nci / 2), 768 / blocks);
+    return splits >= 2 ? splits : 0;
 }
 }  // namespace ff

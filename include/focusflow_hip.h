@@ -96,6 +96,10 @@ typedef struct FFConvParams {
     int res_split;                     /* (parallel_fusion.py:142-150: img' = img + conv(mask), mask' = mask + conv(img)) */
                                        /* as ONE launch over the segments [img, mask] with an anti-diagonal weight.       */
                                        /* Split formats, 1x1 kernels (the im2col kernel's epilogue).                      */
+    float* splitk_ws;                  /* NULL, or a workspace of splitk * B*Ho*Wo * Cout floats: the reduction over the  */
+    int splitk;                        /* input channels is cut into `splitk` ranges computed by separate blocks, summed   */
+                                       /* in a fixed order by a second launch (deterministic).  Use ff_conv2d_splitk_hint: */
+                                       /* it pays for small planes with long reductions (FF-PWC decoders, 7x16..56x128).   */
 } FFConvParams;
 
 int ff_conv2d_fwd(const FFConvParams* p, void* stream);
@@ -110,6 +114,9 @@ int ff_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW,
  * same scale (one accumulator serves all three product terms).  Values must satisfy |v| < 4094; the convolutions'
  * activations (split the same way at scale 4 inside the kernels) |x| < 16376. */
 int ff_pack_split_f16(const float* src_rows, void* dst, long long rows, int K, void* stream);
+/* Number of K splits ff_conv2d_fwd would put to use for this convolution (0: none - leave splitk_ws NULL).  A plain
+ * return value, not a status.  Does not launch anything. */
+int ff_conv2d_splitk_hint(const FFConvParams* p);
 
 /* ------------------------------------------------------------------------
  * Normalisation: nn.InstanceNorm2d (extractor.py:28-32, per-sample statistics,

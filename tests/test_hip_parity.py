@@ -440,8 +440,11 @@ def test_config1_384x512_and_batch_consistency(det_sd):
         rep = [t.repeat(8, 1, 1, 1) for t in inp]
         fl8, fu8 = m(*rep, raft_iters=12, test_mode=True)
     assert fu8.shape == (8, 2, 384, 512)
+    # not bit-identical: the dispatcher picks other tile shapes - and, for the single pair, K splits - for 3072 pixels than
+    # for 24576 (different fp32 summation orders over 12 iterations); every copy inside the batch IS identical
     for i in range(8):
-        close(fu8[i].cpu(), flow_up[0].cpu(), rtol=0, atol=2e-4, what=f"batch sample {i}")
+        close(fu8[i].cpu(), flow_up[0].cpu(), rtol=0, atol=5e-4, what=f"batch sample {i}")
+        assert torch.equal(fu8[i], fu8[0])
 
 
 def test_skip_unused_upsample_is_bit_identical(det_sd):
@@ -687,3 +690,38 @@ def test_input_padder_roundtrip():
         p = InputPadder(x.shape, mode)
         (y,) = p.pad(x)
         assert y.shape[-2] % 8 == 0 and y.shape[-1] % 8 == 0 and torch.equal(p.unpad(y), x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,h,w,k,res", [(672, 32, 14, 32, (3, 3), False), (416, 96, 7, 16, (3, 3), True), (544, 128, 12, 20, (1, 5), False)])
+def test_split_k_convolution_small_plane_long_reduction(cin, cout, h, w, k, res):
+    """FFConvParams.splitk (ff_conv2d_splitk_hint): partial sums of K ranges by separate blocks, added in a fixed order
+    by the finishing launch - same result as torch's conv to fp32 rounding, identical from run to run."""
+    import torch.nn.functional as F
+    from focusflow_official_amd import ops, _hip
+    g = torch.Generator().manual_seed(cin + cout)
+    kh, kw = k
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / (cin * kh * kw) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    r = torch.randn(1, cout, h, w, generator=g) if res else None
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), bias.double(), padding=(kh // 2, kw // 2)), 0.1)
+    if res:
+        ref = torch.relu(ref + r.double())
+    rows = torch.empty((cout, kh * kw * cin), device="cuda")
+    ops.pack_conv_weight(wt.cuda(), rows, cin, 0)
+    wsplit = ops.pack_split(rows)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    rd = r.permute(0, 2, 3, 1).contiguous().cuda() if res else None
+    # the library must want to split this shape (otherwise the test tests nothing)
+    p = _hip.FFConvParams()
+    p.x[0], p.x_ld[0], p.x_c[0] = xd.data_ptr(), cin, cin
+    p.groups, p.B, p.H, p.W, p.Ho, p.Wo, p.Cout = 1, 1, h, w, h, w, cout
+    p.KH, p.KW, p.stride, p.pad_h, p.pad_w, p.w_format = kh, kw, 1, kh // 2, kw // 2, _hip.W_F16X3
+    assert _hip.load().ff_conv2d_splitk_hint(p) >= 2
+    outs = [ops.conv2d([xd], wsplit, bias.cuda(), cout, kh, kw, 1, (kh // 2, kw // 2), act=ops.ACT_LEAKY, res=rd,
+                       act_res=ops.ACT_RELU if res else ops.ACT_NONE, w_fmt=_hip.W_F16X3) for _ in range(2)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].permute(0, 3, 1, 2).cpu().double()
+    assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
