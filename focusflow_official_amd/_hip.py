@@ -75,6 +75,7 @@ _SIGS = {
     "ff_upsample_flow_bwd": [_fp, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
     # FF-PWC native component
     "ff_pwc_costvolume_fwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_pwc_costvolume_fwd_ex": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp],
     "ff_pwc_costvolume_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_pwc_gout_transpose": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_pwc_backwarp": [_fp, C.c_int, _fp, C.c_int, C.c_float, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],

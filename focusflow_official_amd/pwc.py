@@ -7,11 +7,17 @@ from . import _hip, ops
 from .ops import _ld, _p, _stream, empty_nhwc
 
 
-def _cv_fwd(one, two, out=None):
+def _cv_fwd(one, two, out=None, act=0):
+    """81-channel cost volume (act: the activation applied to it on the way out).  Coarse levels - a few 8 x 16 tiles with
+    many channels - split the channel reduction over blocks (deterministic: fixed-order sum in a second launch)."""
     b, h, w, c = one.shape
     if out is None:
         out = empty_nhwc(b, h, w, 81, one)
-    _hip.call("ff_pwc_costvolume_fwd", _p(one), _ld(one), _p(two), _ld(two), _p(out), _ld(out), b, h, w, c, _stream())
+    tiles, chunks = b * ((h + 7) // 8) * ((w + 15) // 16), (c + 15) // 16
+    splits = min(chunks, 256 // tiles) if (tiles < 128 and chunks >= 4) else 1
+    ws = torch.empty(splits * b * h * w * 81, dtype=torch.float32, device=one.device) if splits > 1 else None
+    _hip.call("ff_pwc_costvolume_fwd_ex", _p(one), _ld(one), _p(two), _ld(two), _p(out), _ld(out), b, h, w, c, act, _p(ws), splits,
+              _stream())
     return out
 
 

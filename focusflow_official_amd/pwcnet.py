@@ -305,8 +305,7 @@ class Decoder(nn.Module):
             warped = pwc.backwarp(two, flow_slot, BACKWARP_SCALE[self.level])
             ops.act_copy(one, buf[..., 448 + VOLP: 448 + VOLP + one.shape[3]], ACT_NONE)
         vol = buf[..., 448:448 + VOLP]
-        pwc._cv_fwd(one, warped, out=vol[..., :81])
-        ops.act_copy(vol, vol, ACT_LEAKY)                     # leaky_relu(volume); the 3 pad channels stay 0
+        pwc._cv_fwd(one, warped, out=vol[..., :81], act=ACT_LEAKY)      # leaky_relu(volume) on the way out; the pad channels stay 0
         off = 448
         for (name, pk), (_, co) in zip(self._convs, reversed(GROWTH)):
             pk(buf[..., off:], act=ACT_LEAKY, out=buf[..., off - co:off])

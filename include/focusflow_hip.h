@@ -296,6 +296,11 @@ int ff_upsample_flow_bwd(const float* dout_nchw, const float* flow, int flow_ld,
  * ======================================================================== */
 int ff_pwc_costvolume_fwd(const float* one, int one_ld, const float* two, int two_ld, float* out,
                           int out_ld, int B, int H, int W, int C, void* stream);
+/* The same with the activation that follows the volume everywhere (leaky_relu, ff_pwcnet.py:289) applied on the way out, and -
+ * splits > 1, ws = splits * B*H*W * 81 floats - the channel reduction cut into ranges computed by separate blocks and
+ * added in a fixed order by a second launch: the coarse levels are a handful of tiles with 96-196 channels. */
+int ff_pwc_costvolume_fwd_ex(const float* one, int one_ld, const float* two, int two_ld, float* out, int out_ld,
+                             int B, int H, int W, int C, int act, float* ws, int splits, void* stream);
 int ff_pwc_costvolume_bwd(const float* g, int g_ld, const float* other, int other_ld, float* grad,
                           int grad_ld, int B, int H, int W, int C, void* stream);
 int ff_pwc_gout_transpose(const float* g, int g_ld, float* gt, int gt_ld, int B, int H, int W, void* stream);
