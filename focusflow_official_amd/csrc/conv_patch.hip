@@ -478,7 +478,8 @@ int conv2d_splitk_hint(const FFConvParams& p, int cin) {
     const int nci = cin / 32;
     // long reductions only (more than 72 tap steps per block): below that the finishing launch and the workspace cost a
     // host-bound caller more than the kernel gains (FF-RAFT's update block at one pair per step: 7.3 -> 8.0 ms eager)
-    if (blocks > 256 || nci < 6 || nci * p.KH * p.KW <= 72) return 0;
+    // p.splitk < 0 on input = the caller is being captured into a hipGraph (no host cost per launch): split from 36 steps
+    if (blocks > 256 || nci < 6 || nci * p.KH * p.KW <= (p.splitk < 0 ? 36 : 72)) return 0;
     const int splits = (int)std::min<long long>(std::min(16, nci / 2), 768 / blocks);
     return splits >= 2 ? splits : 0;
 }

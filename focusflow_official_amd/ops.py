@@ -184,11 +184,17 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
         assert in_scale.shape == in_shift.shape == (b, cin) and in_scale.is_contiguous() and in_shift.is_contiguous()
         p.in_scale, p.in_shift, p.in_act = in_scale.data_ptr(), in_shift.data_ptr(), in_act
     assert out.shape[:3] == (b, ho, wo) and out.shape[3] >= cout
-    if w_fmt and b * ho * wo <= 16384 and cin * kh * kw > 2304:       # small plane, long reduction: ask the library whether K splits pay
-        nsplit = _hip.load().ff_conv2d_splitk_hint(C.byref(p))
-        if nsplit > 1:
-            ws = torch.empty(nsplit * b * ho * wo * cout, dtype=torch.float32, device=x0.device)
-            p.splitk_ws, p.splitk = ws.data_ptr(), nsplit
+    klen = cin * kh * kw
+    if w_fmt and b * ho * wo <= 16384 and klen > 1152:       # small plane, long reduction: ask the library whether K splits pay
+        # reductions of 36-72 tap steps are split only when no host time is at stake: while a hipGraph is being captured
+        short = klen <= 2304
+        if not short or torch.cuda.is_current_stream_capturing():
+            p.splitk = -1 if short else 0
+            nsplit = _hip.load().ff_conv2d_splitk_hint(C.byref(p))
+            p.splitk = 0
+            if nsplit > 1:
+                ws = torch.empty(nsplit * b * ho * wo * cout, dtype=torch.float32, device=x0.device)
+                p.splitk_ws, p.splitk = ws.data_ptr(), nsplit
     _timed_call("conv", "ff_conv2d_fwd", C.byref(p), _stream(), note=(2.0 * b * ho * wo * cout * kh * kw * cin, w_fmt))
     return out
 

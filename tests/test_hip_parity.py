@@ -617,7 +617,9 @@ def test_baseline_config5_544x960_it32_fp16_pyramid():
 
 
 def test_hipgraph_replay_matches_eager(det_sd):
-    """The captured forward (focusflow_official_amd/graph.py) replays bit-identically and tracks new inputs."""
+    """The captured forward (focusflow_official_amd/graph.py) replays bit-identically and tracks new inputs.  Against the
+    eager forward it agrees to fp32 summation order only: while a graph is captured - no host time per launch at stake -
+    the 1/8-resolution convolutions of a single pair take K splits that the eager path leaves alone (ops.conv2d)."""
     from focusflow_official_amd.graph import GraphedForward
     m = _model(det_sd)
     a = [t.to(DEV) for t in orc.shifted_pair(1, 128, 192, seed=31)]
@@ -631,11 +633,12 @@ def test_hipgraph_replay_matches_eager(det_sd):
     ga2 = [t.clone() for t in gf(*a)]
     torch.cuda.synchronize()
     for x, y in zip(ea, ga):
-        assert torch.equal(x, y)
+        close(y.cpu(), x.cpu(), rtol=0, atol=2e-4, what="graph vs eager (input a)")
     for x, y in zip(eb, gb):
-        assert torch.equal(x, y)
+        close(y.cpu(), x.cpu(), rtol=0, atol=2e-4, what="graph vs eager (input b)")
     for x, y in zip(ga, ga2):
         assert torch.equal(x, y)
+    assert not torch.equal(ga[1], gb[1])
 
 
 @pytest.mark.parametrize("modal", ["frame", "neighborG", "neighborE", "context"])
