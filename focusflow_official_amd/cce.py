@@ -116,6 +116,17 @@ class PackedConv:
         return ops.unpack_conv_wgrad(dwp, cv.out_channels, self.cin, self.kh, self.kw, self.cin_pad, off)
 
 
+_BRANCH_STREAMS = os.environ.get("FF_BRANCH_STREAMS", "1") != "0"   # mask branch of the CCE encoder on a side stream (inference)
+_branch_streams = {}
+
+
+def _branch_stream(device):
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)     # one per caller stream
+    if key not in _branch_streams:
+        _branch_streams[key] = torch.cuda.Stream(device=device)
+    return _branch_streams[key]
+
+
 _PAIR_FUSION = os.environ.get("FF_PAIR_FUSION", "1") != "0"   # both 1x1 convs of a fusion unit in one launch (inference)
 
 
@@ -387,15 +398,37 @@ class BasicParallelFusionLayer(nn.Module):
     def _run_stage(self, stage, x):
         return self._block(stage[1], self._block(stage[0], x))
 
+    def _branches(self, fm, fx, m, x):
+        """(fm(m), fx(x)): the mask branch and the image branch between two fusion units are independent.  Inference runs
+        the mask branch on a side stream (forked and joined with events: capturable): one branch's memory-bound norm passes
+        overlap the other's convolutions."""
+        # (not while a hipGraph is being captured: a fork inside a forked stream - cnet runs beside fnet - kills the capture)
+        if not (_BRANCH_STREAMS and not torch.is_grad_enabled() and x.is_cuda) or torch.cuda.is_current_stream_capturing():
+            return fm(m), fx(x)
+        main = torch.cuda.current_stream()
+        side = _branch_stream(x.device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            mo = fm(m)
+            join = torch.cuda.Event()
+            join.record(side)
+        m.record_stream(side)              # allocated on the main stream, read on the side stream
+        xo = fx(x)
+        main.wait_event(join)
+        mo.record_stream(main)             # allocated on the side stream, read on the main stream
+        return mo, xo
+
     def forward(self, x, mask):
-        m = self._conv_norm(mask, self._mstem, self.mask_norm1, ACT_RELU)
-        x = self._conv_norm(x, self._stem, self.norm1, ACT_RELU)
+        m, x = self._branches(lambda t: self._conv_norm(t, self._mstem, self.mask_norm1, ACT_RELU),
+                              lambda t: self._conv_norm(t, self._stem, self.norm1, ACT_RELU), mask, x)
         m, x = self.fusion1.run(m, x)
-        m, x = self._run_stage(self.mask_layer1, m), self._run_stage(self.layer1, x)
+        m, x = self._branches(lambda t: self._run_stage(self.mask_layer1, t), lambda t: self._run_stage(self.layer1, t), m, x)
         m, x = self.fusion2.run(m, x)
-        m, x = self._run_stage(self.mask_layer2, m), self._run_stage(self.layer2, x)
+        m, x = self._branches(lambda t: self._run_stage(self.mask_layer2, t), lambda t: self._run_stage(self.layer2, t), m, x)
         m, x = self.fusion3.run(m, x)
-        m, x = self._run_stage(self.mask_layer3, m), self._run_stage(self.layer3, x)
+        m, x = self._branches(lambda t: self._run_stage(self.mask_layer3, t), lambda t: self._run_stage(self.layer3, t), m, x)
         m, x = self.fusion4.run(m, x)
         m, x = fn.conv(self._mout, m), fn.conv(self._out, x)
         m, x = self.fusion5.run(m, x)

@@ -11,6 +11,7 @@ from .ops import ACT_RELU, ACT_TANH
 from .update_block import BasicUpdateBlock
 
 _GRU_CTX_ONCE = os.environ.get("FF_GRU_CTX_ONCE", "1") != "0"      # measurement switch (see SepConvGRU.prepare)
+_ENC_STREAMS = os.environ.get("FF_ENC_STREAMS", "1") != "0"           # cnet on a second stream beside fnet (inference)
 _UPDATE_SPLIT = int(os.environ.get("FF_UPDATE_SPLIT", "1"))         # experiment: update loop of n batch slices on n streams
 
 
@@ -85,11 +86,31 @@ class RAFT(nn.Module):
         # both frames through fnet as ONE batch of 2B (InstanceNorm is per sample, so this is the same arithmetic as
         # the reference's two calls, raft.py:187-189): grids twice as large at the 1/4- and 1/8-resolution layers
         # (fewer ragged last waves of blocks) and half the launches
+        # Inference: the context encoder (BatchNorm folded: convolutions only) on a second stream beside the feature
+        # encoder, whose InstanceNorm statistics / apply passes are memory-bound - the two use different parts of the chip.
+        two_streams = _ENC_STREAMS and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
+        if two_streams:
+            main = torch.cuda.current_stream()
+            if getattr(self, "_enc_stream", None) is None:
+                self._enc_stream = torch.cuda.Stream(device=image1.device)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(self._enc_stream):
+                self._enc_stream.wait_event(fork)
+                cnet = self.cnet(image1, mask1)
+                join = torch.cuda.Event()
+                join.record(self._enc_stream)
+            for t in (image1, mask1):
+                t.record_stream(self._enc_stream)
         f12 = self.fnet(torch.cat([image1, image2], 0), torch.cat([mask1, mask2], 0))
         fmap1, fmap2 = f12[:b], f12[b:]
         self.fmap = fmap1
         corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
-        cnet = self.cnet(image1, mask1)
+        if two_streams:
+            main.wait_event(join)
+            cnet.record_stream(main)
+        else:
+            cnet = self.cnet(image1, mask1)
         taped = fn.recording(cnet)
         if taped:
             net = fn.ActFn.apply(cnet[..., :128], ACT_TANH)
