@@ -403,7 +403,7 @@ class BasicParallelFusionLayer(nn.Module):
         the mask branch on a side stream (forked and joined with events: capturable): one branch's memory-bound norm passes
         overlap the other's convolutions."""
         # (not while a hipGraph is being captured: a fork inside a forked stream - cnet runs beside fnet - kills the capture)
-        if not (_BRANCH_STREAMS and not torch.is_grad_enabled() and x.is_cuda) or torch.cuda.is_current_stream_capturing():
+        if not (_BRANCH_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and not torch.is_grad_enabled() and x.is_cuda) or torch.cuda.is_current_stream_capturing():
             return fm(m), fx(x)
         main = torch.cuda.current_stream()
         side = _branch_stream(x.device)

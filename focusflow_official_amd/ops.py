@@ -54,6 +54,13 @@ def pack_split(rows_f32: Tensor) -> Tensor:
     return dst
 
 
+# Set by a caller that brackets single launches with events (bench.py's roofline_conv leg): every forward then runs on
+# ONE stream, so that the bracketed durations add up to wall time instead of overlapping.
+SINGLE_STREAM = False
+# Set per forward by RAFT._forward: below ~3.5 pairs of 384x512 a step is host-bound and the fork / join events of the
+# encoder streams cost more than the overlap gains (BASELINE configs[4] at one pair: 16.4 -> 16.7 ms).
+ENCODER_STREAMS_OK = True
+
 # Optional per-launch timing of ONE entry point with HIP events recorded on the
 # launch stream (bench.py's roofline leg).  Off unless profile_begin() is called.
 _prof_on = False

@@ -88,7 +88,9 @@ class RAFT(nn.Module):
         # (fewer ragged last waves of blocks) and half the launches
         # Inference: the context encoder (BatchNorm folded: convolutions only) on a second stream beside the feature
         # encoder, whose InstanceNorm statistics / apply passes are memory-bound - the two use different parts of the chip.
-        two_streams = _ENC_STREAMS and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
+        ops.ENCODER_STREAMS_OK = b * hh * ww >= 700_000
+        two_streams = (_ENC_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and not torch.is_grad_enabled()
+                       and not torch.cuda.is_current_stream_capturing())
         if two_streams:
             main = torch.cuda.current_stream()
             if getattr(self, "_enc_stream", None) is None:
