@@ -116,6 +116,7 @@ class PackedConv:
         return ops.unpack_conv_wgrad(dwp, cv.out_channels, self.cin, self.kh, self.kw, self.cin_pad, off)
 
 
+_TRAIN_STREAMS = os.environ.get("FF_TRAIN_STREAMS", "1") != "0"      # the same overlap in recorded (training) passes: autograd replays the streams
 _BRANCH_STREAMS = os.environ.get("FF_BRANCH_STREAMS", "1") != "0"   # mask branch of the CCE encoder on a side stream (inference)
 _branch_streams = {}
 
@@ -403,7 +404,7 @@ class BasicParallelFusionLayer(nn.Module):
         the mask branch on a side stream (forked and joined with events: capturable): one branch's memory-bound norm passes
         overlap the other's convolutions."""
         # (not while a hipGraph is being captured: a fork inside a forked stream - cnet runs beside fnet - kills the capture)
-        if not (_BRANCH_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and not torch.is_grad_enabled() and x.is_cuda) or torch.cuda.is_current_stream_capturing():
+        if not (_BRANCH_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and (_TRAIN_STREAMS or not torch.is_grad_enabled()) and x.is_cuda) or torch.cuda.is_current_stream_capturing():
             return fm(m), fx(x)
         main = torch.cuda.current_stream()
         side = _branch_stream(x.device)

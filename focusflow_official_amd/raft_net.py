@@ -5,12 +5,13 @@ import torch
 import torch.nn as nn
 
 from . import fn, ops
-from .cce import BasicParallelFusionLayer
+from .cce import BasicParallelFusionLayer, _TRAIN_STREAMS
 from .corr_block import CorrBlock
 from .ops import ACT_RELU, ACT_TANH
 from .update_block import BasicUpdateBlock
 
 _GRU_CTX_ONCE = os.environ.get("FF_GRU_CTX_ONCE", "1") != "0"      # measurement switch (see SepConvGRU.prepare)
+_STREAMS_MIN_PIXELS = int(os.environ.get("FF_STREAMS_MIN_PIXELS", "700000"))   # below: host-bound, the fork / join events cost more than they gain
 _ENC_STREAMS = os.environ.get("FF_ENC_STREAMS", "1") != "0"           # cnet on a second stream beside fnet (inference)
 _UPDATE_SPLIT = int(os.environ.get("FF_UPDATE_SPLIT", "1"))         # experiment: update loop of n batch slices on n streams
 
@@ -88,8 +89,8 @@ class RAFT(nn.Module):
         # (fewer ragged last waves of blocks) and half the launches
         # Inference: the context encoder (BatchNorm folded: convolutions only) on a second stream beside the feature
         # encoder, whose InstanceNorm statistics / apply passes are memory-bound - the two use different parts of the chip.
-        ops.ENCODER_STREAMS_OK = b * hh * ww >= 700_000
-        two_streams = (_ENC_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and not torch.is_grad_enabled()
+        ops.ENCODER_STREAMS_OK = b * hh * ww >= _STREAMS_MIN_PIXELS
+        two_streams = (_ENC_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and (_TRAIN_STREAMS or not torch.is_grad_enabled())
                        and not torch.cuda.is_current_stream_capturing())
         if two_streams:
             main = torch.cuda.current_stream()

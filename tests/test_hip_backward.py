@@ -542,3 +542,22 @@ def test_dilated_leaky_conv_backward(mods, dil, act):
     close(nchw(xd.grad), x.grad, what="dx")
     close(dcv.weight.grad.cpu(), cv.weight.grad, what="dW")
     close(dcv.bias.grad.cpu(), cv.bias.grad, what="db")
+
+
+def test_encoder_branch_streams_at_test_sizes():
+    """The encoder branches run on separate streams only for steps of >= 700 k pixels (RAFT._forward) - none of the
+    fixtures here.  One child process forces them on at every size (FF_STREAMS_MIN_PIXELS=0) and repeats the reference
+    train-step comparison, the block-level fp64 gradient checks and the forward vectors: the stream choreography (fork /
+    join events, record_stream, autograd replaying the forward streams) must not change a result."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FF_STREAMS_MIN_PIXELS="0", FF_TRAIN_STREAMS="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_hip_backward.py"), os.path.join(here, "test_hip_parity.py"), "-k",
+                        "train_step_matches_reference or residual_block_backward or model_matches_reference_vectors or "
+                        "overfitting or shared_weight_gradient_scope"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
