@@ -404,6 +404,10 @@ def main():
             lookup_ms, vol_ms = prof["lookup"], prof["corr_volume"]
         per_launch_ms = sum(lookup_ms) / max(1, len(lookup_ms))
         per_q = LOOKUP_BYTES_PER_QUERY[args.pyramid]
+        # queries per LAUNCH from the launches actually seen: one lookup per iteration covers the rank's whole batch,
+        # unless the opt-in FF_UPDATE_SPLIT runs the loop on batch slices (then every launch covers a slice)
+        timed_steps = 1 if args.graph else args.steps
+        q = int(round(q * args.iters * timed_steps / max(1, len(lookup_ms))))
         achieved = per_q * q / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         c2 = (args.height, args.width, args.iters, args.batch) == (384, 512, 12, 8) and args.pyramid == "fp32"
         line = {

@@ -126,9 +126,13 @@ class RAFT(nn.Module):
         coords1 = ops.coords_init(b, h8, w8, cnet, flow_init)      # never differentiated (raft.py:216)
         # the context features' share of the GRU gate convolutions does not change over the iterations
         gru_pre = None if (taped or torch.is_grad_enabled() or not _GRU_CTX_ONCE) else self.update_block.gru.prepare(inp)
-        if _UPDATE_SPLIT > 1 and test_mode and not taped and not torch.is_grad_enabled() and b % _UPDATE_SPLIT == 0:
-            # Experiment (FF_UPDATE_SPLIT=n): the update loop of n batch slices on n streams.  At 1/8 resolution every
-            # kernel of the loop is a 20-90 us launch with several us of ramp; independent slices overlap them.
+        if (_UPDATE_SPLIT > 1 and test_mode and not taped and not torch.is_grad_enabled() and b % _UPDATE_SPLIT == 0
+                and not ops.SINGLE_STREAM and not torch.cuda.is_current_stream_capturing()):
+            # Opt-in (FF_UPDATE_SPLIT=2): the update loop of n batch slices on n streams, the iterations issued alternately.
+            # At 1/8 resolution every kernel of the loop is a 5-90 us launch with several us of ramp; two independent
+            # chains fill each other's: +3 % at 8 pairs per step.  Not the default: every launch of the loop - the lookup
+            # first of all - then covers half the batch, i.e. the kernel the bench's roofline is quoted on runs as two
+            # half-size, ramp-dominated launches.
             return self._split_loop(net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8)
         flow4, flow_up, flow_predictions = self._loop(net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8, taped, test_mode)
         if test_mode:
@@ -137,6 +141,14 @@ class RAFT(nn.Module):
 
     def _loop(self, net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8, taped, test_mode):
         """raft.py:218-236 for one batch (or batch slice): returns (flow4, flow_up, flow_predictions)."""
+        out = {}
+        for _ in self._loop_steps(net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8, taped, test_mode, out):
+            pass
+        return out["flow4"], out["flow_up"], out["preds"]
+
+    def _loop_steps(self, net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8, taped, test_mode, out):
+        """The same as a generator that yields after every iteration (so that _split_loop can issue the iterations of
+        several batch slices alternately, each on its own stream); results land in `out`."""
         cnet = net
         flow_predictions = []
         flow_up = None
@@ -157,14 +169,14 @@ class RAFT(nn.Module):
             net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre)
             flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
             ops.coords_step(coords1, delta.detach(), flow4, None)         # coords1 += delta
-            if not need_mask:
-                continue
-            if fn.recording(delta, up_mask):
-                flow_up = fn.UpsampleFn.apply(flow4, delta, up_mask)
-            else:
-                flow_up = ops.upsample_flow(flow4, up_mask)
-            flow_predictions.append(flow_up)
-        return flow4, flow_up, flow_predictions
+            if need_mask:
+                if fn.recording(delta, up_mask):
+                    flow_up = fn.UpsampleFn.apply(flow4, delta, up_mask)
+                else:
+                    flow_up = ops.upsample_flow(flow4, up_mask)
+                flow_predictions.append(flow_up)
+            out.update(flow4=flow4, flow_up=flow_up, preds=flow_predictions)
+            yield
 
     def _split_loop(self, net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8):
         n = _UPDATE_SPLIT
@@ -174,20 +186,29 @@ class RAFT(nn.Module):
             self._split_streams = [torch.cuda.Stream(device=net.device) for _ in range(n)]
         fork = torch.cuda.Event()
         fork.record(main)
-        outs = []
+        # one generator per slice, advanced in turn: the host feeds every stream an iteration at a time (issuing one
+        # slice's twelve iterations before the next one's only serialises two half-size loops: 408 instead of 518 pairs/s)
+        res, gens = [{} for _ in range(n)], []
         for k, st in enumerate(self._split_streams):
             lo, hi = k * m, (k + 1) * m
             st.wait_event(fork)
             with torch.cuda.stream(st):
                 pre = None if gru_pre is None else [(z[lo:hi], q[lo:hi]) for z, q in gru_pre]
-                f4, fup, _ = self._loop(net[lo:hi], inp[lo:hi], corr_fn.batch_slice(lo, hi), coords1[lo:hi], pre, iters,
-                                        m, h8, w8, False, True)
-                low = ops.nhwc_to_nchw(f4[..., :2])
-                for t in (low, fup):
+                gens.append(self._loop_steps(net[lo:hi], inp[lo:hi], corr_fn.batch_slice(lo, hi), coords1[lo:hi], pre, iters,
+                                             m, h8, w8, False, True, res[k]))
+        for _ in range(iters):
+            for st, g in zip(self._split_streams, gens):
+                with torch.cuda.stream(st):
+                    next(g)
+        outs = []
+        for st, r in zip(self._split_streams, res):
+            with torch.cuda.stream(st):
+                low = ops.nhwc_to_nchw(r["flow4"][..., :2])
+                for t in (low, r["flow_up"]):
                     t.record_stream(main)
                 join = torch.cuda.Event()
                 join.record(st)
-            outs.append((low, fup, join))
+            outs.append((low, r["flow_up"], join))
         for _, _, join in outs:
             main.wait_event(join)
         return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
