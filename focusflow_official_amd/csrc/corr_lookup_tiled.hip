@@ -412,6 +412,15 @@ extern "C" int ff_corr_lookup_tiled_fwd(const void* const* levels, int half, con
         a.lvl[l] = static_cast<const char*>(levels[l]);
         a.plane_bytes[l] = (long long)L.plane[l] * (half ? 2 : 4);
     }
+    // round-3 kernel (corr_lookup_dma.hip) whenever the four levels lie within 4 GB of each other (ops.TiledPyramid
+    // allocates them as one buffer); FF_LOOKUP_IMPL=2 keeps the round-2 kernel below (A/B runs, read at every call)
+    {
+        const char* impl = getenv("FF_LOOKUP_IMPL");
+        if (!(impl && atoi(impl) == 2) && !getenv("FF_LOOKUP_ABLATE")) {
+            const int r = ff::lookup_dma_fwd(levels, half, coords, queries, h0, w0, out, out_ld, taps_dbg, static_cast<hipStream_t>(stream));
+            if (r != 1) return r;
+        }
+    }
     a.coords = coords;
     a.out = out;
     a.taps = taps_dbg;

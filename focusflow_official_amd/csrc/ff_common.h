@@ -56,6 +56,9 @@ int conv2d_fwd_small(const FFConvParams& p, int cin, hipStream_t s);         // 
 int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s);         // conv_patch.hip; 1 = not eligible
 int conv2d_splitk_hint(const FFConvParams& p, int cin);                       // conv_patch.hip; K splits worth using, 0 = none
 int conv2d_fwd_ws(const FFConvParams& p, int cin, hipStream_t s);            // conv_ws.hip (wave-specialised); 1 = not eligible
+// corr_lookup_dma.hip: the LDS-DMA lookup; 1 = not eligible (levels more than 4 GB apart)
+int lookup_dma_fwd(const void* const* levels, int half, const float* coords, long long queries, int h0, int w0, float* out,
+                   int out_ld, int* taps_dbg, hipStream_t s);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

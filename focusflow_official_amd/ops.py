@@ -225,9 +225,18 @@ class TiledPyramid:
 
     @classmethod
     def empty(cls, planes: int, h0: int, w0: int, half: bool, device, zero: bool = False) -> "TiledPyramid":
+        # ONE allocation for the four levels (each starts on a 256-byte boundary): the lookup kernel addresses them
+        # through a single buffer resource (csrc/corr_lookup_dma.hip), which needs them within 4 GB of each other
         dt = torch.float16 if half else torch.float32
         mk = torch.zeros if zero else torch.empty
-        return cls([mk((planes, cls.plane_elems(h0, w0, l, half)), dtype=dt, device=device) for l in range(4)], h0, w0, half)
+        esz = 2 if half else 4
+        n = [planes * cls.plane_elems(h0, w0, l, half) for l in range(4)]
+        start, total = [], 0
+        for l in range(4):
+            start.append(total)
+            total += (n[l] * esz + 255) // 256 * 256 // esz
+        flat = mk((total,), dtype=dt, device=device)
+        return cls([flat[start[l]:start[l] + n[l]].view(planes, n[l] // planes) for l in range(4)], h0, w0, half)
 
     def ptrs(self):
         return (C.c_void_p * 4)(*[lv.data_ptr() for lv in self.levels])

@@ -48,3 +48,12 @@ def lookup(levels, coords: np.ndarray, radius=4):
     arr = (C.c_void_p * nl)(*[lv.ctypes.data for lv in levels])
     lib().orc_corr_lookup(arr, nl, radius, _f(coords), b, h, w, _f(out), _f(taps))
     return out, taps
+
+
+def div5_mismatches(xs: np.ndarray, d: int):
+    """How many of xs give (2 x) / d != the five fused operations of csrc/corr_lookup_dma.hip (and the first index)."""
+    xs = np.ascontiguousarray(xs, np.float32)
+    first = C.c_long(-1)
+    f = lib().orc_div5_mismatches
+    f.restype = C.c_long
+    return f(_f(xs), C.c_long(xs.size), int(d), C.byref(first)), first.value

@@ -74,3 +74,27 @@ void orc_corr_lookup(const float* const* levels, int L, int r, const float* coor
             }
         }
 }
+
+/* The five fused operations csrc/corr_lookup_dma.hip uses for g = 2 x / (n - 1) (utils.py:61) next to the true
+ * division, so that the GPU kernel's tap arithmetic is pinned on the CPU: r2 = 2 RN(1 / d), dh = d / 2. */
+static float div5(float x, float r2, float dh) {
+    const float q0 = x * r2;
+    const float e0 = fmaf(-q0, dh, x);
+    const float q1 = fmaf(e0, r2, q0);
+    const float e1 = fmaf(-q1, dh, x);
+    return fmaf(e1, r2, q1);
+}
+
+/* number of x in xs[0..n) for which div5 differs (bit pattern) from (2 x) / d; *first = index of the first one */
+long orc_div5_mismatches(const float* xs, long n, int d, long* first) {
+    const float df = (float)d, r = 1.0f / df, r2 = r + r, dh = 0.5f * df;
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        const float a = div5(xs[i], r2, dh), b = (2.f * xs[i]) / df;
+        if (a != b && !(a != a && b != b)) {
+            if (!bad && first) *first = i;
+            ++bad;
+        }
+    }
+    return bad;
+}

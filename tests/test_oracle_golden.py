@@ -327,3 +327,21 @@ def test_pwc_oracle_mask_modes_match_reference(modal):
             flows = pwc_ref.ffpwc_forward(sd, i1, i2, m1, mask_modal=modal, dilate=7, kernel_size=9, kernel_sigma=1.5)
         np.testing.assert_allclose(full.numpy(), g[f"{modal}_{tag}_full"], rtol=0, atol=2e-6)
         np.testing.assert_allclose(flows[0].numpy(), g[f"{modal}_{tag}_flow2"], rtol=0, atol=2e-6)
+
+
+def test_division_by_plane_size_in_five_fused_operations_is_the_true_quotient():
+    """csrc/corr_lookup_dma.hip replaces the division of utils.py:61, 2 x / (n - 1), by reciprocal refinement with two
+    exact remainders.  It must be THE correctly rounded quotient for every coordinate: all divisors a plane can have
+    (1 .. 4096) against random, integer, half-integer, near-tie and huge numerators."""
+    from oracle import corr_c
+    rng = np.random.default_rng(5)
+    xs = [rng.uniform(-600, 600, 40000).astype(np.float32),
+          np.arange(-300, 300, dtype=np.float32), np.arange(-300, 300, dtype=np.float32) + 0.5,
+          (rng.integers(-(1 << 24), 1 << 24, 20000) * np.float32(2.0) ** rng.integers(-30, 8, 20000)).astype(np.float32),
+          rng.standard_normal(20000).astype(np.float32) * np.float32(1e-30), np.float32([0.0, -0.0, 1e30, -1e30, 1e37])]      # |x| < 2^126: 2 x must not overflow
+    # numerators whose quotient sits next to a rounding boundary: x = d * (m + 1/2 ulp) / 2 for random significands m
+    m = rng.integers(1 << 23, 1 << 24, 20000).astype(np.float64)
+    for d in list(range(1, 260)) + [383, 511, 959, 1023, 2047, 4095, 4096] + list(rng.integers(260, 4096, 60)):
+        tie = (d * (m + rng.choice([-0.5, 0.5], m.size)) / 2 * 2.0 ** -20).astype(np.float32)
+        bad, first = corr_c.div5_mismatches(np.concatenate(xs + [tie]), int(d))
+        assert bad == 0, (d, bad, first)
