@@ -29,6 +29,9 @@ constexpr int TW = 16, ROWB = 128;   // tile height TH = 4*TM (template): 16, 8 
 // immediate offset from one base register.  PMC on the swizzled version: 35 % of the LDS-active cycles were
 // bank-conflict cycles and the kernel issued 10 VALU instructions per MFMA, mostly swizzle arithmetic.
 constexpr int ROWP = 144;
+// MF16: row i of a 16-row MFMA tile <-> position in the tile (pixel column / LDS row of the weight tile)
+__device__ __forceinline__ int PI16(int i) { return (i >= 4 && i < 12) ? 2 * (i - 4) : (i < 4 ? 2 * i + 1 : 2 * (i - 12) + 9); }
+__device__ __forceinline__ int KG16(int g) { return ((g & 1) << 1) | (g >> 1); }     // place of k-group g inside a term's 64 bytes
 
 
 struct PArgs {
@@ -53,7 +56,15 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {   
 // SPLITK: blockIdx.y owns a range of the 32-channel input chunks and writes raw partial sums (splitk_finish_kernel adds
 // them in a fixed order and applies the epilogue): small planes with long reductions - FF-PWC's DenseNet decoders at
 // 7x16 .. 56x128 - are otherwise 8-60 blocks walking 100-190 taps one after the other on an empty chip.
-template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false, bool INORM = false, bool SPLITK = false>   // WB = weight buffers in LDS
+// MF16: the matrix work as v_mfma_f32_16x16x32_f16 instead of 32x32x16 - on dense data the chip holds a higher clock on
+// the small shape (tools/proto/mfma_shape.hip: the LDS-fed three-term loop of this kernel's wave tile runs 1.59 vs
+// 1.28-1.37 PFLOP/s).  Channels are the MFMA rows (A operand: a lane's four accumulator registers of a tile are four
+// CONSECUTIVE output channels of one pixel: 16-byte stores and residual loads), pixels the columns; one MFMA covers the
+// whole 32-channel chunk of a term.  LDS image for conflict-free ds_read_b128 in this lane layout (lane = (row i = lane &
+// 15, k-group g = lane >> 4); the instruction serves lanes {0-3,12-15} of one k-group together with {4-11} of the next):
+// the 16-byte k-groups of a term sit in the order 0, 2, 1, 3, and MFMA rows 4..11 read the even rows of a tile,
+// rows 0..3 / 12..15 the odd ones (a weight row's place in LDS, a pixel's column in the tile: PI16).
+template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false, bool INORM = false, bool SPLITK = false, bool MF16 = false>   // WB = weight buffers in LDS
 __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
     constexpr int TH = 4 * TM, BN = 64 * TN, NW = 2 * TN;       // NW = 16-byte weight pieces per thread and tap
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,7 +139,7 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
         }
     };
     auto store_patch = [&]() {
-        const int pc = kq >> 1, half = (kq & 1) * 8;
+        const int pc = MF16 ? KG16(kq >> 1) : kq >> 1, half = (kq & 1) * 8;
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
             const int row = prow[i];
@@ -159,9 +170,147 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int row = (tid >> 3) + 32 * i;
-            *reinterpret_cast<f32x4*>(d + row * ROWP + kq * 16) = rw[i];
+            if (MF16) *reinterpret_cast<f32x4*>(d + ((row & ~15) + PI16(row & 15)) * ROWP + ((kq & 4) | KG16(kq & 3)) * 16) = rw[i];
+            else *reinterpret_cast<f32x4*>(d + row * ROWP + kq * 16) = rw[i];
         }
     };
+
+    if constexpr (MF16) {
+        constexpr int NU = 2 * TM, NV = 2 * TN;          // pixel rows (16 columns each) and 16-channel tiles of this wave
+        f32x4 acc[NV][NU];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) acc[v][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int i16 = lane & 15, g16 = lane >> 4, pcol = PI16(i16);
+        const int ntaps = KH * KW;
+        const char* xbase = sP + ((wm * NU) * PW + pcol) * ROWP + KG16(g16) * 16;            // pixel row u: + u * PW * ROWP
+        const int wrow0 = (wn * TN * 32 + PI16(i16)) * ROWP + KG16(g16) * 16;                 // channel tile v: + 16 v * ROWP
+        const int c_beg = SPLITK ? (int)blockIdx.y * a.nci_split : 0;
+        const int c_end = SPLITK ? min(c_beg + a.nci_split, a.nci) : a.nci;
+        load_patch(c_beg);
+        load_w(c_beg);
+        int wbuf = 0;
+        for (int c = c_beg; c < c_end; ++c) {
+            __syncthreads();                     // previous chunk's taps are done with sP
+            store_patch();
+            store_w(wbuf);
+            __syncthreads();
+            if (c + 1 < c_end) load_patch(c + 1);        // lands during this chunk's taps
+            for (int tap = 0; tap < ntaps; ++tap) {
+                const bool last = tap + 1 == ntaps;
+                const int next_kc = last ? (c + 1) : (tap + 1) * a.nci + c;
+                if (!(last && c + 1 == c_end)) load_w(last ? c + 1 : next_kc);
+                if (PIN) __builtin_amdgcn_sched_barrier(0);
+                const int dy = tap / KW, dx = tap - dy * KW;
+                const char* pa = xbase + (dy * PW + dx) * ROWP;
+                const char* cW = sW + wbuf * BN * ROWP + wrow0;
+                f16x8 w0[NV], w1[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    w0[v] = *reinterpret_cast<const f16x8*>(cW + v * 16 * ROWP);
+                    if (TERMS == 3) w1[v] = *reinterpret_cast<const f16x8*>(cW + v * 16 * ROWP + 64);
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const f16x8 xa = *reinterpret_cast<const f16x8*>(pa + u * PW * ROWP);
+                    f16x8 xb;
+                    if (TERMS == 3) xb = *reinterpret_cast<const f16x8*>(pa + u * PW * ROWP + 64);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[v], xa, acc[v][u], 0, 0, 0);
+                        if (TERMS == 3) {
+                            acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[v], xa, acc[v][u], 0, 0, 0);
+                            acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[v], xb, acc[v][u], 0, 0, 0);
+                        }
+                    }
+                }
+                if (!last) {                  // next tap's weights go to the other buffer
+                    if (WB == 1) __syncthreads();     // ... or, with one buffer, wait until everybody has read this tap's
+                    store_w(WB == 1 ? 0 : wbuf ^ 1);
+                    __syncthreads();
+                    if (WB == 2) wbuf ^= 1;
+                }
+            }
+            if (WB == 2) wbuf ^= 1;
+        }
+        // epilogue: acc[v][u][r] = channel n4 + r (n4 = tile base + 4 g16) of pixel (row u, column pcol)
+        const int x = x0 + pcol;
+        const bool vec_y = (p.y_ld & 3) == 0 && ff::aligned16(p.y);
+        const bool vec_r = !p.res || ((p.res_ld & 3) == 0 && ff::aligned16(p.res));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int n4 = n0 + wn * TN * 32 + v * 16 + g16 * 4;
+            if (n4 >= p.Cout) continue;
+            const bool full = n4 + 3 < p.Cout;
+            if constexpr (SPLITK) {       // raw partial sums [split][pixel][Cout]
+                float* ws = p.splitk_ws + (long long)blockIdx.y * pix_total * p.Cout;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int y = y0 + wm * NU + u;
+                    if (y >= H || x >= W) continue;
+                    float* d = ws + (((long long)bimg * H + y) * W + x) * p.Cout + n4;
+                    if (full && (p.Cout & 3) == 0) *reinterpret_cast<f32x4*>(d) = acc[v][u] * xinv;
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n4 + r < p.Cout) d[r] = acc[v][u][r] * xinv;
+                    }
+                }
+                continue;
+            }
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f}, cs = {1.f, 1.f, 1.f, 1.f}, ct = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = min(n4 + r, p.Cout - 1);
+                if (p.bias) bias[r] = p.bias[n];
+                if (p.ch_scale) { cs[r] = p.ch_scale[n]; ct[r] = p.ch_shift[n]; }
+            }
+            f32x4 vv[NU], rr[NU];
+            long long po[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int y = y0 + wm * NU + u;
+                po[u] = (y < H && x < W) ? ((long long)bimg * H + y) * W + x : -1;
+                f32x4 t = acc[v][u] * xinv + bias;
+                t *= p.out_scale;
+                if (p.ch_scale) t = t * cs + ct;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = ff::apply_act(t[r], p.act);
+                vv[u] = t;
+            }
+            if (p.res) {                  // all residual loads of the tile column together, then add + store
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    rr[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (po[u] < 0) continue;
+                    const float* rp2 = p.res + po[u] * p.res_ld + n4;
+                    if (full && vec_r) rr[u] = *reinterpret_cast<const f32x4*>(rp2);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n4 + r < p.Cout) rr[u][r] = rp2[r];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[u][r] = ff::apply_act(vv[u][r] + rr[u][r], p.act_res);
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (po[u] < 0) continue;
+                float* d = p.y + po[u] * p.y_ld + n4;
+                if (full && vec_y) *reinterpret_cast<f32x4*>(d) = vv[u];
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n4 + r < p.Cout) d[r] = vv[u][r];
+                }
+            }
+        }
+        return;
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -322,8 +471,8 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, WB>(a); }
 // one weight buffer: 35 KB of LDS, so four blocks fit a CU if the registers allow four waves per SIMD
-template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0, bool INORM = false, bool SPLITK = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN, INORM, SPLITK>(a); }
+template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0, bool INORM = false, bool SPLITK = false, bool MF16 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN, INORM, SPLITK, MF16>(a); }
 
 // sum of the K splits in a fixed order, then the epilogue of conv_patch_body (same operations in the same order)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const FFConvParams p, int splits, long long npix) {
@@ -345,6 +494,23 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const FFConvParams p
 template <int TERMS, int NITEM, int TM, int TN, int OCC>
 int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
     const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    // FF_MFMA16=1: the 16x16x32 matrix instruction instead of 32x32x16.  Opt-in: parity-green, and the bare LDS-fed loop is
+    // 16-24 % faster on the small shape (tools/proto/mfma_shape.hip), but the whole kernel is not bound by its matrix
+    // loop: per-layer times are equal within 1 % (12.70 vs 12.73 ms of convolutions per step) and the normalise-on-load
+    // variant spills (+13 % on its layers).
+    static const bool mf16 = getenv("FF_MFMA16") && atoi(getenv("FF_MFMA16")) == 1;
+    if (mf16 && !getenv("FF_PATCH_ABLATE")) {
+        if (a.p.splitk > 1) {
+            const int splits = (a.nci + a.nci_split - 1) / a.nci_split;
+            conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, true, true><<<dim3((unsigned)blocks, splits), 256, lds, s>>>(a);
+            const long long npix = (long long)a.p.B * a.p.H * a.p.W, total = npix * a.p.Cout;
+            splitk_finish_kernel<<<(unsigned)std::min<long long>((total + 255) / 256, 2048), 256, 0, s>>>(a.p, splits, npix);
+            return ff::check_launch("ff_conv2d_fwd(patch, split-K)");
+        }
+        if (a.p.in_scale) conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, true, false, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+        else conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, false, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+        return ff::check_launch("ff_conv2d_fwd(patch)");
+    }
     if (a.p.splitk > 1) {        // validated by the caller: no in_scale, no res2, workspace present
         const int splits = (a.nci + a.nci_split - 1) / a.nci_split;
         conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, true><<<dim3((unsigned)blocks, splits), 256, lds, s>>>(a);

@@ -60,7 +60,7 @@ int conv2d_fwd_ws(const FFConvParams& p, int cin, hipStream_t s);            // 
 int lookup_dma_fwd(const void* const* levels, int half, const float* coords, long long queries, int h0, int w0, float* out,
                    int out_ld, int* taps_dbg, hipStream_t s);
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
