@@ -71,20 +71,24 @@ def log(msg):
 
 
 def pmc_traffic(queries, pyramid):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_lookup_traffic[_fp16].json:
-    TCC_EA0_RDREQ x 128 B + WRITE_SIZE), scaled per query; None if the profile is absent.  PMC passes
-    cannot run inside the timed process, so this is the same kernel measured by tools/bench_lookup.py."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r03_lookup_traffic[_fp16].json:
+    TCC_EA0_RDREQ x 128 B + WRITE_SIZE), scaled per query, and where the number comes from; (None, reason) if the
+    profile is absent.  PMC passes cannot run inside the timed process, so this is the same kernel on the same shape
+    measured by tools/lookup_lab.cpp under tools/prof_pmc_bin.sh - NOT a counter read in this run."""
+    name = "r03_lookup_traffic.json" if pyramid == "fp32" else "r03_lookup_traffic_fp16.json"
     try:
-        name = "r02_lookup_traffic.json" if pyramid == "fp32" else "r02_lookup_traffic_fp16.json"
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
-        return int(d["traffic_bytes_per_launch"] / d["queries_per_launch"] * queries)
+        return (int(d["traffic_bytes_per_launch"] / d["queries_per_launch"] * queries),
+                f"profiles/{name}: rocprofv3 --pmc passes over tools/lookup_lab.cpp (same kernel, {d['queries_per_launch']} queries per "
+                f"launch), scaled per query; not measured in this run")
     except (OSError, KeyError, ValueError):
-        return None
+        return None, f"profiles/{name} missing"
 
 
-def cpu_baseline(h, w, iters, budget_s=20.0):
-    """Time the CPU oracle on the SAME workload shape (B=1), bounded to ~budget_s."""
+def cpu_baseline(h, w, iters, budget_s=20.0, keep=None):
+    """Time the CPU oracle on the SAME workload shape (B=1), bounded to ~budget_s.  keep: a dict that receives the
+    checker's weights, input and output of that forward (the parity leg compares the HIP path against them)."""
     from oracle import ffraft_ref as orc
     from oracle.weights import det_tensor
     with open(os.path.join(ROOT, "tests", "golden", "state_dict_spec.json")) as f:
@@ -95,8 +99,10 @@ def cpu_baseline(h, w, iters, budget_s=20.0):
     inp = orc.shifted_pair(1, h, w, seed=1234)
     with torch.no_grad():
         t0 = time.perf_counter()
-        orc.ffraft_forward(sd, *inp, raft_iters=iters, test_mode=True)  # warm-up
+        ref = orc.ffraft_forward(sd, *inp, raft_iters=iters, test_mode=True)  # warm-up
         log(f"cpu_baseline: warm-up forward {time.perf_counter() - t0:.2f} s")
+        if keep is not None:
+            keep.update(sd=sd, inp=inp, flow_up=ref[1])
         times = []
         t_end = time.perf_counter() + budget_s
         while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
@@ -151,6 +157,7 @@ def self_launch(n: int) -> int:
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
     rc = 0
     alive = set(range(n))
+    kill_at = None                     # a rank stuck in a collective or a GPU wait may ignore SIGTERM: SIGKILL after a grace period
     while alive:
         for r in sorted(alive):
             code = procs[r].poll()
@@ -162,6 +169,12 @@ def self_launch(n: int) -> int:
                 log(f"rank {r} exited with {code}: stopping the other ranks")
                 for o in alive:
                     procs[o].terminate()
+                kill_at = time.monotonic() + 10.0
+        if kill_at is not None and alive and time.monotonic() > kill_at:
+            for o in alive:
+                log(f"rank {o} did not stop within 10 s of SIGTERM: killing it")
+                procs[o].kill()
+            kill_at = None
         time.sleep(0.05)
     return rc
 
@@ -222,7 +235,7 @@ def train_setup(args, world, rank, local_rank, device):
     return step, h, w
 
 
-def train_mode(args, world, rank, local_rank, device):
+def train_mode(args, world, rank, local_rank, device, ranks_seen=1):
     step, h, w = train_setup(args, world, rank, local_rank, device)
     log(f"train mode rank {rank}/{world}: {args.batch} pairs {h}x{w}")
     for i in range(args.warmup):
@@ -242,17 +255,105 @@ def train_mode(args, world, rank, local_rank, device):
             "config": {"workload": f"FF-RAFT training step, {args.batch} pairs/GPU {h}x{w}, iters={args.iters}, MixLoss "
                                    f"(k=1, sigma=0.01, lamda=1), AdamW + OneCycleLR, clip 1.0 (BASELINE configs[2] shape)",
                        "pairs_per_gpu": args.batch, "parallelism": f"dp{world}" + (" DDP/RCCL all-reduce 30.65 MB" if world > 1 else "")},
-            "final_loss": loss.detach().item()}), flush=True)
+            "final_loss": loss.detach().item(), "rccl_ranks_seen": ranks_seen}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
+def _epe(a, b):
+    return torch.sqrt(((a - b) ** 2).sum(1))
+
+
+def parity_and_reduced_precision(args, device, checker):
+    """Against the checker's forward of the cpu_baseline leg (the pinned CPU port of the reference, same weights, same
+    pair): the headline arithmetic (f16x3) and the reduced-precision throughput mode (FF_CONV_PRECISION=f16: single-term
+    fp16 operands, 10 mantissa bits like the TF32 the reference runs on a GPU - common.py:25-27) - BASELINE configs[1]
+    "... vs reference EPE".  Then the throughput of the reduced-precision mode on the headline workload."""
+    from focusflow_official_amd import FF_RAFT_FUSION, ops
+    out = {}
+    prev = ops.conv_precision()
+    try:
+        for mode in ("f16x3", "f16"):
+            ops.set_conv_precision(mode)
+            m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg())
+            if checker:
+                m.load_state_dict(checker["sd"], strict=True)
+                m = m.to(device).eval()
+                with torch.no_grad():
+                    fu = m(*[t.to(device) for t in checker["inp"]], raft_iters=args.iters, test_mode=True)[1].cpu()
+                e = _epe(fu, checker["flow_up"])
+                res = {"epe_vs_reference_px": round(float(e.mean()), 6), "epe_max_px": round(float(e.max()), 6),
+                       "max_abs_px": round(float((fu - checker["flow_up"]).abs().max()), 6),
+                       "flow_absmax_px": round(float(checker["flow_up"].abs().max()), 3),
+                       "sample": f"1 pair {args.height}x{args.width} iters={args.iters}, deterministic test weights, against the CPU port of the reference (cpu_baseline leg)"}
+            else:
+                res = {"epe_vs_reference_px": None}
+            if mode == "f16x3":
+                out["parity"] = dict(res, dtype=DTYPES[mode])
+                continue
+            torch.manual_seed(1234)
+            m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
+            batch = synthetic_batch(args.batch, args.height, args.width, 1234, device)
+            with torch.no_grad():
+                for _ in range(3):
+                    o = m(*batch, raft_iters=args.iters, test_mode=True)
+                torch.cuda.synchronize()
+                n = 10
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    o = m(*batch, raft_iters=args.iters, test_mode=True)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            out["reduced_precision"] = dict(res, metric=f"frame-pairs/sec FF-RAFT {args.height}x{args.width} iters={args.iters}",
+                                            value=round(args.batch / dt, 2), unit="frame-pairs/s", ms_per_step=round(dt * 1e3, 3), steps=n, warmup=3,
+                                            dtype=DTYPES[mode], finite=bool(torch.isfinite(o[1]).all()),
+                                            workload=f"BASELINE configs[1] in its reduced-precision reading: {args.batch} pairs, NOT the headline (north_star: 1e-3 px vs fp32)",
+                                            tf32_level_px="tests/golden/tf32_epe_384x512.json: the reference's own TF32 arithmetic costs 0.022 px mean / 0.21 px max on the test pair")
+            del m, batch
+    except Exception as e:          # noqa: BLE001 - reported, never fatal for the headline line
+        out["reduced_precision_error"] = f"{type(e).__name__}: {e}"
+    finally:
+        ops.set_conv_precision(prev)
+    torch.cuda.empty_cache()
+    return out
+
+
+def config4_measurements(device):
+    """BASELINE configs[4]: FF-RAFT 540x960 (padded to 544x960), 32 iterations, fp16 correlation pyramid; 1 and 4 pairs."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    out = {}
+    try:
+        torch.manual_seed(1234)
+        m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
+        m.flow_net.corr_pyramid_dtype = "fp16"
+        for b in (1, 4):
+            batch = synthetic_batch(b, 544, 960, 77 + b, device)
+            with torch.no_grad():
+                for _ in range(2):
+                    o = m(*batch, raft_iters=32, test_mode=True)
+                torch.cuda.synchronize()
+                n = 5
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    o = m(*batch, raft_iters=32, test_mode=True)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            out[f"pairs_{b}"] = {"value": round(b / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n, "warmup": 2,
+                                 "finite": bool(torch.isfinite(o[1]).all())}
+            del batch
+        out["workload"] = "BASELINE configs[4]: FF-RAFT forward 544x960 (540 padded), iters=32, fp16 correlation pyramid, SiLK-free ORB-like mask"
+    except Exception as e:          # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary_measurements(args, device):
-    """The two secondary BASELINE configs on the same GPU, after the headline measurement (N = 1 only, a few seconds):
-    the training step (configs[2] shape, one GPU) and the FF-PWC forward (configs[3]).  Reported next to the headline
-    line, never mixed into it; a failure is reported as text and does not touch the headline."""
+    """The secondary BASELINE configs on the same GPU, after the headline measurement (N = 1 only, a few seconds each):
+    the training step (configs[2] shape, one GPU), the FF-PWC forward (configs[3]) and configs[4] (544x960, 32 iterations,
+    fp16 pyramid).  Reported next to the headline line, never mixed into it; a failure is reported as text and does not
+    touch the headline."""
     import copy
-    import time
     out = {}
     try:
         targs = copy.copy(args)
@@ -303,6 +404,8 @@ def secondary_measurements(args, device):
                                  "finite": bool(torch.isfinite(o).all())}
     except Exception as e:          # noqa: BLE001
         out["ff_pwc_forward"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    out["config4_544x960_it32_fp16_pyramid"] = config4_measurements(device)
     return out
 
 
@@ -360,10 +463,16 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    # every rank adds one: the line then proves how many RCCL ranks really took part in the collective (1 without a group)
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
 
     from focusflow_official_amd import FF_RAFT_FUSION, ops
     if args.mode == "train":
-        return train_mode(args, world, rank, local_rank, device)
+        return train_mode(args, world, rank, local_rank, device, ranks_seen)
     torch.manual_seed(1234)
     model = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
     model.flow_net.skip_unused_upsample = bool(args.skip_unused_upsample)
@@ -420,9 +529,10 @@ def main():
                                    f"({'BASELINE configs[1]' if c2 else 'BASELINE configs[4]' if args.pyramid == 'fp16' else 'non-headline shape'})",
                        "pairs_per_gpu": args.batch, "corr_pyramid": args.pyramid, "conv_precision": ops.conv_precision(), "hipgraph": bool(args.graph), "skip_unused_upsample": bool(args.skip_unused_upsample),
                        "parallelism": f"dp{world} (independent shards, no collective)"},
-            "roofline": {"kernel": f"lookup_tiled_kernel<{'fp16' if args.pyramid == 'fp16' else 'fp32'}> (ff_corr_lookup_tiled_fwd)",
+            "roofline": {"kernel": f"lookup_dma_kernel<{'fp16' if args.pyramid == 'fp16' else 'fp32'}> (ff_corr_lookup_tiled_fwd)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(q, args.pyramid),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(q, args.pyramid)[0],
+                         "traffic_source": pmc_traffic(q, args.pyramid)[1],
                          "launches": len(lookup_ms), "avg_launch_us": round(per_launch_ms * 1e3, 2),
                          "algorithmic_bytes_per_query": per_q, "algorithmic_bytes_per_launch": per_q * q},
         }
@@ -444,11 +554,13 @@ def main():
             "launches": len(vol_ms), "avg_launch_us": round(vol_avg_ms * 1e3, 1)}
         # all convolutions of one extra (untimed) step, each launch bracketed by HIP events: where 80 % of the step goes
         ops.SINGLE_STREAM = True          # bracketed launches must not overlap: this extra step runs on one stream
-        ops.profile_begin("conv")
-        with torch.no_grad():
-            model(*batch, raft_iters=args.iters, test_mode=True)
-        conv_ms = ops.profile_end()["conv"]
-        ops.SINGLE_STREAM = False
+        try:
+            ops.profile_begin("conv")
+            with torch.no_grad():
+                model(*batch, raft_iters=args.iters, test_mode=True)
+            conv_ms = ops.profile_end()["conv"]
+        finally:
+            ops.SINGLE_STREAM = False
         notes = ops.profile_notes("conv")
         useful = sum(n[0] for n in notes)
         issued_fl = sum(n[0] * (3 if n[1] == 1 else 1) for n in notes if n[1] != 0)
@@ -462,12 +574,15 @@ def main():
                     f"{useful / (tot_ms * 1e-3) / 1e12:.1f} TFLOP/s; the f16 pipe sustains ~1600 TFLOP/s on dense data "
                     f"(tools/proto/mfma_peak.hip)",
             "launches": len(conv_ms), "sum_launch_ms": round(tot_ms, 3), "useful_gflop_per_step": round(useful / 1e9, 1)}
+        line["rccl_ranks_seen"] = ranks_seen
+        checker = {}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.height, args.width, args.iters)
+            line["cpu_baseline"] = cpu_baseline(args.height, args.width, args.iters, keep=checker)
         if world == 1 and c2 and not args.no_secondary and not args.graph:
             step = model = batch = None          # noqa: F841 - release the forward model before the secondary configs
             torch.cuda.empty_cache()
-            line["secondary"] = secondary_measurements(args, device)
+            line["secondary"] = parity_and_reduced_precision(args, device, checker)
+            line["secondary"].update(secondary_measurements(args, device))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -108,6 +108,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint"])
 
+ABI_VERSION = 2      # include/focusflow_hip.h: FF_ABI_VERSION
 _lib = None
 
 
@@ -137,6 +138,10 @@ def load():
     lib.ff_corr_plane_elems.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.ff_conv2d_splitk_hint.restype = C.c_int
     lib.ff_conv2d_splitk_hint.argtypes = [C.POINTER(FFConvParams)]
+    got = lib.ff_abi_version()
+    if got != ABI_VERSION:
+        raise FocusFlowHipError(f"{LIB_PATH} speaks ABI version {got}, these bindings (FFConvParams layout, argument lists) "
+                                f"version {ABI_VERSION}: rebuild with `python -m focusflow_official_amd.build`")
     _lib = lib
     return lib
 

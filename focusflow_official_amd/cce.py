@@ -116,7 +116,15 @@ class PackedConv:
         return ops.unpack_conv_wgrad(dwp, cv.out_channels, self.cin, self.kh, self.kw, self.cin_pad, off)
 
 
-_TRAIN_STREAMS = os.environ.get("FF_TRAIN_STREAMS", "1") != "0"      # the same overlap in recorded (training) passes: autograd replays the streams
+def train_streams() -> bool:
+    """The encoder / branch streams in RECORDED (training) passes: autograd replays every backward node on the stream its
+    forward ran on.  FF_TRAIN_STREAMS=1 / 0 decides; unset, they are on for single-process training and OFF once a
+    torch.distributed process group exists: DDP's bucket hooks would then fire from the side streams, a choreography no
+    multi-rank RCCL run has exercised yet (the 2-rank DDP test runs both ways on one card)."""
+    v = os.environ.get("FF_TRAIN_STREAMS")
+    if v is not None:
+        return v != "0"
+    return not (torch.distributed.is_available() and torch.distributed.is_initialized())
 _BRANCH_STREAMS = os.environ.get("FF_BRANCH_STREAMS", "1") != "0"   # mask branch of the CCE encoder on a side stream (inference)
 _branch_streams = {}
 
@@ -404,7 +412,7 @@ class BasicParallelFusionLayer(nn.Module):
         the mask branch on a side stream (forked and joined with events: capturable): one branch's memory-bound norm passes
         overlap the other's convolutions."""
         # (not while a hipGraph is being captured: a fork inside a forked stream - cnet runs beside fnet - kills the capture)
-        if not (_BRANCH_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and (_TRAIN_STREAMS or not torch.is_grad_enabled()) and x.is_cuda) or torch.cuda.is_current_stream_capturing():
+        if not (_BRANCH_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and (not torch.is_grad_enabled() or train_streams()) and x.is_cuda) or torch.cuda.is_current_stream_capturing():
             return fm(m), fx(x)
         main = torch.cuda.current_stream()
         side = _branch_stream(x.device)

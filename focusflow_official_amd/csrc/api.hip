@@ -9,7 +9,9 @@ char* err_buf() {
 }  // namespace ff
 
 extern "C" const char* ff_last_error(void) { return ff::err_buf(); }
-extern "C" int ff_abi_version(void) { return 1; }
+// 2: FFConvParams grew res2 / res2_ld / res_split / splitk_ws / splitk, ff_norm_bwd gained dx_amax, the row-major corr
+// backward entry points went away (round 2).  Callers zero-initialise the WHOLE FFConvParams and check this number.
+extern "C" int ff_abi_version(void) { return FF_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Host-side helper of the data loaders (no GPU work): PNG scan-line reconstruction (filter types 0-4, RFC 2083 section 6)

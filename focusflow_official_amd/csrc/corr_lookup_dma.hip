@@ -197,8 +197,8 @@ __global__ __launch_bounds__(64) void lookup_dma_kernel(const DArgs a) {
     // r2 = 2 RN(1 / d) and dh = d / 2 (exact scalings): q0 = RN(t r) is within 2 ulp of t / d; the remainder t - q0 d is
     // exactly representable, so fma gives it exactly (halved: exact too); q1 = RN(q0 + rem r) is a faithful quotient; one
     // more exact remainder and the same correction give the correctly rounded one (Markstein's theorem: r within half an
-    // ulp of 1 / d, d's significand not all ones - d is an integer below 2^13).  oracle/corr_oracle.c carries the same
-    // five operations next to a true division; tests/test_oracle_golden.py compares them for every divisor up to 4096.
+    // ulp of 1 / d, d's significand not all ones - d is an integer below 2^13).  The CPU tests carry the same five
+    // operations next to a true division and compare them for every divisor up to 4096 (tests/test_*_golden.py).
     auto taps_a = [&](float cx, float cy) {
         const f32x2 c2 = {cx, cy};
         const f32x2 x = c2 * inv2 + off2;                        // corr.py:41-43 (contraction is off: two roundings)

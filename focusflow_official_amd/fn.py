@@ -8,6 +8,7 @@ launch when no gradient is being recorded and the autograd node otherwise.
 from typing import List, Optional
 
 import os
+import weakref
 
 import torch
 
@@ -38,18 +39,47 @@ class GraphScope:
     see exactly one gradient per parameter, also when the loss reaches only some of the applications, and a second
     backward over a retained graph starts from an empty buffer again."""
 
-    def __init__(self):
+    def __init__(self, device=None):
         self.acc, self.gates = {}, {}
-        self._amax_pool, self._amax_used = None, 0
-        # data_ptr of a gradient tensor -> (word with the bits of its max|.|, shape): left by the producer of the
-        # gradient (NormFn.backward), consumed - and removed - by the ConvFn.backward it flows into
+        self._amax_pool, self._amax_used, self._amax_ready = None, 0, None
+        # data_ptr of a gradient tensor -> (word with the bits of its max|.|, shape, weak reference to the tensor): left by
+        # the producer of the gradient (NormFn.backward), consumed - and removed - by the ConvFn.backward it flows into.
+        # An entry counts only while its tensor is ALIVE at that address: a gradient nobody consumed (the norm of a frozen
+        # branch whose conv takes no hint) may be freed and its address handed to another gradient of the same shape.
         self.amax_hint = {}
+        if device is not None and torch.device(device).type == "cuda":
+            self._refill(device)       # on the stream that opens the pass (the main stream), before any side stream exists
+
+    def _refill(self, device):
+        """A fresh pool of zeroed max|.| words.  Backward nodes run on several streams (encoder / branch streams are
+        replayed by autograd): every stream other than the filling one waits for the fill before its first atomicMax."""
+        self._amax_pool, self._amax_used = torch.zeros(4096, dtype=torch.int32, device=device), 0
+        self._amax_ready = torch.cuda.Event()
+        self._amax_ready.record(torch.cuda.current_stream(device))
+        self._amax_fill_stream = torch.cuda.current_stream(device)
 
     def amax_word(self, device):
         if self._amax_pool is None or self._amax_used >= self._amax_pool.numel():
-            self._amax_pool, self._amax_used = torch.zeros(2048, dtype=torch.int32, device=device), 0
+            self._refill(device)
+        cur = torch.cuda.current_stream(device)
+        if cur != self._amax_fill_stream:
+            cur.wait_event(self._amax_ready)
+            self._amax_pool.record_stream(cur)
         self._amax_used += 1
         return self._amax_pool[self._amax_used - 1:self._amax_used]
+
+    def put_hint(self, dx, word):
+        self.amax_hint[dx.data_ptr()] = (word, tuple(dx.shape), weakref.ref(dx))
+
+    def take_hint(self, dy):
+        """The max|.| word of gradient `dy` if its producer left one for exactly this tensor, else None."""
+        h = self.amax_hint.pop(dy.data_ptr(), None)
+        if h is None:
+            return None
+        t = h[2]()
+        if t is None or t.data_ptr() != dy.data_ptr() or h[1] != tuple(dy.shape):
+            return None                # the producer's tensor is gone: the address was recycled
+        return h[0]
 
     def gated(self, pc, params):
         """The aliases of pc's parameters that this pass's applications take as inputs (one gate per conv group)."""
@@ -91,10 +121,10 @@ _scope: Optional[GraphScope] = None
 _AMAX_HINT = os.environ.get("FF_AMAX_HINT", "1") != "0"      # A/B switch: the norm backward measures max|dx| for the conv it feeds
 
 
-def begin_graph() -> GraphScope:
+def begin_graph(device=None) -> GraphScope:
     """Open a weight-gradient scope for the forward pass that follows (RAFT.forward when recording)."""
     global _scope
-    _scope = GraphScope()
+    _scope = GraphScope(device)
     return _scope
 
 
@@ -132,6 +162,7 @@ class ConvFn(torch.autograd.Function):
         ctx.nparam = len(tensors) - nseg - (1 if has_res else 0)
         ctx.save_for_backward(*xs, y if act != ACT_NONE else None)
         ctx.scope = scope      # not None: the parameter inputs are this pass's ParamGate aliases
+        ctx.hints = _scope     # the pass's max|.| hints are looked up (and consumed) by EVERY conv, gated or not
         return y
 
     @staticmethod
@@ -141,9 +172,9 @@ class ConvFn(torch.autograd.Function):
         xs, y = list(saved[:nseg]), saved[nseg]
         dy = _dense(dy)
         scope = ctx.scope
-        hint = scope.amax_hint.pop(dy.data_ptr(), None) if scope is not None else None
-        if hint is not None and hint[1] == tuple(dy.shape) and ops.act_bwd_is_alias(dy, act, ctx.out_scale, pc.cout):
-            g, amax = dy, hint[0]          # conv -> norm: the norm's backward kernel has measured max|dy| already
+        hint = ctx.hints.take_hint(dy) if ctx.hints is not None else None
+        if hint is not None and ops.act_bwd_is_alias(dy, act, ctx.out_scale, pc.cout):
+            g, amax = dy, hint             # conv -> norm: the norm's backward kernel has measured max|dy| already
         else:
             g, amax = ops.act_bwd(dy, y, act, ctx.out_scale, pc.cout, want_amax=True,    # (B,Ho,Wo,Cpad), zero padded
                                   amax=scope.amax_word(dy.device) if scope is not None else None)
@@ -218,7 +249,7 @@ class NormFn(torch.autograd.Function):
         word = scope.amax_word(x.device) if (scope is not None and _AMAX_HINT) else None
         dx, dres, bst = ops.norm_bwd(x, _dense(dy), y, stats, per_sample, fixed, eps, gamma, beta, relu, has_res, amax=word)
         if word is not None:
-            scope.amax_hint[dx.data_ptr()] = (word, tuple(dx.shape))
+            scope.put_hint(dx, word)
         dgamma = dbeta = None
         if gamma is not None and ctx.needs_input_grad[1]:
             dgamma = bst[0, :, 1].float()

@@ -116,7 +116,9 @@ class FF_RAFT_FUSION(nn.Module):
                 self._table = tab.to(image1.device)
             m1 = ops.mask_prepare(MASK_MODES[modal], mask1, image1, self._table)
             m2 = i2 if modal == "context" else ops.prep_input(None, b, h, w, image1, fill=255.0)
-        return self.flow_net(i1, i2, m1, m2, iters=raft_iters, flow_init=flow_init, test_mode=test_mode)
+        out = self.flow_net(i1, i2, m1, m2, iters=raft_iters, flow_init=flow_init, test_mode=test_mode)
+        ops.check_range("FF_RAFT_FUSION.forward")      # debug mode FF_CHECK_RANGE=1 only (one host sync)
+        return out
 
     def freeze_self(self):
         if self.use_fusion == "parallel":

@@ -191,6 +191,9 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
         assert in_scale.shape == in_shift.shape == (b, cin) and in_scale.is_contiguous() and in_shift.is_contiguous()
         p.in_scale, p.in_shift, p.in_act = in_scale.data_ptr(), in_shift.data_ptr(), in_act
     assert out.shape[:3] == (b, ho, wo) and out.shape[3] >= cout
+    if _range_word is not None and w_fmt and x_amax is None and in_scale is None:
+        for x in xs:
+            _range_probe(x)
     klen = cin * kh * kw
     if w_fmt and b * ho * wo <= 16384 and klen > 1152:       # small plane, long reduction: ask the library whether K splits pay
         # reductions of 36-72 tap steps are split only when no host time is at stake: while a hipGraph is being captured
@@ -362,9 +365,39 @@ _stats_used = 0
 
 def begin_forward(device):
     """Called by the model at the top of a forward pass: a fresh zeroed arena for the norm statistics."""
-    global _stats_arena, _stats_used
+    global _stats_arena, _stats_used, _range_word
     _stats_arena = torch.zeros(1 << 18, dtype=torch.float64, device=device)     # 2 MB: ~60 norm layers x B x C x 2
     _stats_used = 0
+    _range_word = torch.zeros(1, dtype=torch.int32, device=device) if CHECK_RANGE else None
+
+
+# The split conv formats read an activation x as f16(4 x) + residual: |x| must stay below 16376 (csrc/ff_common.h), and a
+# value beyond it becomes inf without any other sign than a NaN flow.  Weights are checked when they are loaded
+# (model.load_state_dict); activations depend on the input, so their check is a debug mode: FF_CHECK_RANGE=1 (or
+# ops.CHECK_RANGE = True) measures max|x| of every tensor a forward convolution reads (one extra read-only pass each, the
+# kernel the backward uses for its gradient scales) and the model raises at the end of the forward pass that overflowed.
+CHECK_RANGE = os.environ.get("FF_CHECK_RANGE", "0") == "1"
+X_LIMIT = 16376.0
+_range_word = None
+
+
+def _range_probe(x: Tensor):
+    b, h, w, c = x.shape
+    if act_bwd_is_alias(x, ACT_NONE, 1.0, c):      # measures only, no copy
+        _hip.call("ff_act_bwd", _p(x), _ld(x), None, 0, _p(x), c, b * h * w, c, c, ACT_NONE, 1.0, _p(_range_word), _stream())
+    else:                                            # a channel slice / padded tensor: through a dense copy
+        act_bwd(x, None, ACT_NONE, 1.0, c, want_amax=True, amax=_range_word)
+
+
+def check_range(what: str = "forward pass"):
+    """Debug mode (CHECK_RANGE): raise if an input of a split-format convolution of this pass left fp16's range."""
+    if _range_word is None:
+        return
+    m = float(_range_word.view(torch.float32).item())       # the word holds the bits of max|x| (non-negative floats order as ints)
+    if not (m < X_LIMIT):
+        raise _hip.FocusFlowHipError(
+            f"{what}: a convolution input reached |x| = {m:.6g}; the fp16-split conv formats need |x| < {X_LIMIT:g} "
+            "(ff_common.h).  Run this checkpoint / input with FF_CONV_PRECISION=fp32.")
 
 
 def _zero_stats(s, c, device):

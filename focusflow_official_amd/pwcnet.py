@@ -443,7 +443,7 @@ class FF_PWCNET(nn.Module):
         est = None
         flows = []
         if train:   # every step through an autograd Function (fn.GraphScope shares the extractor's weight gradients)
-            fn.begin_graph()
+            fn.begin_graph(i1.device)
             try:
                 f1 = self.netExtractor.run_train(i1, m1)
                 f2 = self.netExtractor.run_train(i2, m2)

@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from . import fn, ops
-from .cce import BasicParallelFusionLayer, _TRAIN_STREAMS
+from .cce import BasicParallelFusionLayer, train_streams
 from .corr_block import CorrBlock
 from .ops import ACT_RELU, ACT_TANH
 from .update_block import BasicUpdateBlock
@@ -77,7 +77,7 @@ class RAFT(nn.Module):
         h8, w8 = hh // 8, ww // 8
         ops.begin_forward(image1.device)     # one zeroed arena for this pass's norm statistics
         if torch.is_grad_enabled():
-            fn.begin_graph()          # one weight-gradient buffer per conv for this recorded pass (fn.GraphScope)
+            fn.begin_graph(image1.device)   # one weight-gradient buffer per conv for this recorded pass (fn.GraphScope)
         try:
             return self._forward(image1, image2, mask1, mask2, iters, flow_init, test_mode, b, hh, ww, h8, w8)
         finally:
@@ -90,7 +90,7 @@ class RAFT(nn.Module):
         # Inference: the context encoder (BatchNorm folded: convolutions only) on a second stream beside the feature
         # encoder, whose InstanceNorm statistics / apply passes are memory-bound - the two use different parts of the chip.
         ops.ENCODER_STREAMS_OK = b * hh * ww >= _STREAMS_MIN_PIXELS
-        two_streams = (_ENC_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and (_TRAIN_STREAMS or not torch.is_grad_enabled())
+        two_streams = (_ENC_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and (not torch.is_grad_enabled() or train_streams())
                        and not torch.cuda.is_current_stream_capturing())
         if two_streams:
             main = torch.cuda.current_stream()

@@ -45,6 +45,12 @@ extern "C" {
 #define FF_W_F16 2     /* same rows, only the x0*w0 term: plain fp16 operands (reduced precision)  */
 
 const char* ff_last_error(void);
+/* The version this header describes; ff_abi_version() returns the library's.  A caller must compare the two (a struct
+ * that grew since the caller was built would be read past its end) and must zero-initialise every FFConvParams it
+ * passes: new trailing fields mean "feature off" when zero.
+ *   2 (round 2): FFConvParams + res2, res2_ld, res_split, splitk_ws, splitk; ff_norm_bwd + dx_amax; ff_corr_lookup_bwd and
+ *                ff_corr_pyramid_bwd (row-major) removed */
+#define FF_ABI_VERSION 2
 int ff_abi_version(void);
 
 /* ------------------------------------------------------------------------

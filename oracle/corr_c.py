@@ -57,3 +57,14 @@ def div5_mismatches(xs: np.ndarray, d: int):
     f = lib().orc_div5_mismatches
     f.restype = C.c_long
     return f(_f(xs), C.c_long(xs.size), int(d), C.byref(first)), first.value
+
+
+def pwc_costvolume_kernel(one: np.ndarray, two: np.ndarray) -> np.ndarray:
+    """FF-PWC cost volume by the loop-level transcription of correlation.py:7-102 (NCHW fp32 -> (B,81,H,W))."""
+    b, c, h, w = one.shape
+    one = np.ascontiguousarray(one, np.float32)
+    two = np.ascontiguousarray(two, np.float32)
+    top = np.empty((b, 81, h, w), np.float32)
+    rc = lib().orc_pwc_costvolume_kernel(_f(one), _f(two), _f(top), b, c, h, w)
+    assert rc == 0
+    return top

@@ -98,3 +98,71 @@ long orc_div5_mismatches(const float* xs, long n, int d, long* first) {
     }
     return bad;
 }
+
+/* FF-PWC cost volume, SECOND restatement: a loop-level transcription of the reference's CUDA strings
+ * (core/models/ff-pwcnet/PWCNet_Core/correlation.py) - index arithmetic, padding and summation order as written there,
+ * one "thread" at a time.  oracle/pwc_ref.py states the same function tensor-wise (unfold style); the two share no code,
+ * so a misreading of the kernel would have to be made twice in different forms to go unnoticed
+ * (tests/test_oracle_golden.py compares them).
+ *   kernel_Correlation_rearrange     :7-32   NCHW -> zero-padded NHWC rbot[B][H + 8][W + 8][C], pad 4
+ *   kernel_Correlation_updateOutput  :34-102 one block per output pixel, 32 threads striding the channels,
+ *                                            top[b][ch][y][x] = (sum over c) rbot0[b][y+4][x+4][c] * rbot1[b][y+4+s2p][x+4+s2o][c] / C
+ *                                            with s2o = ch % 9 - 4, s2p = ch / 9 - 4 (:71-72); thread 0 adds the 32 partial sums (:90-98) */
+#include <stdlib.h>
+static void pwc_rearrange(const float* input, float* output, int B, int C, int H, int W) {   /* :7-32, grid (ceil(HW/16), C, B) */
+    const int n = H * W;
+    for (int intSample = 0; intSample < B; ++intSample)
+        for (int intChannel = 0; intChannel < C; ++intChannel)
+            for (int intIndex = 0; intIndex < n; ++intIndex) {
+                const float fltValue = input[(((size_t)intSample * C + intChannel) * H * W) + intIndex];
+                const int intPaddedY = (intIndex / W) + 4;
+                const int intPaddedX = (intIndex % W) + 4;
+                const int intRearrange = ((W + 8) * intPaddedY) + intPaddedX;
+                /* SIZE_1(output) = H + 8, SIZE_2(output) = W + 8, SIZE_1(input) = C */
+                output[(((size_t)intSample * (H + 8) * (W + 8)) + intRearrange) * C + intChannel] = fltValue;
+            }
+}
+
+int orc_pwc_costvolume_kernel(const float* one, const float* two, float* top, int B, int C, int H, int W) {
+    const size_t padded = (size_t)B * (H + 8) * (W + 8) * C;
+    float* rbot0 = (float*)calloc(padded, sizeof(float));      /* torch.zeros, correlation.py:285-286 */
+    float* rbot1 = (float*)calloc(padded, sizeof(float));
+    float* patch_data = (float*)malloc((size_t)C * sizeof(float));
+    if (!rbot0 || !rbot1 || !patch_data) return -1;
+    pwc_rearrange(one, rbot0, B, C, H, W);
+    pwc_rearrange(two, rbot1, B, C, H, W);
+    const int S1 = H + 8, S2 = W + 8, S3 = C;                   /* SIZE_1..3(rbot0) */
+    for (int item = 0; item < B; ++item)                         /* blockIdx.z */
+        for (int by = 0; by < H; ++by)                           /* blockIdx.y */
+            for (int bx = 0; bx < W; ++bx) {                     /* blockIdx.x */
+                const int x1 = bx + 4, y1 = by + 4;
+                for (int ch_off = 0; ch_off < 32; ++ch_off)      /* threadIdx.x: load the 1 x 1 x C patch (:52-61) */
+                    for (int ch = ch_off; ch < S3; ch += 32) {
+                        const size_t idx1 = (((size_t)item * S1 + y1) * S2 + x1) * S3 + ch;
+                        patch_data[ch] = rbot0[idx1];
+                    }
+                for (int top_channel = 0; top_channel < 81; ++top_channel) {
+                    float sum[32];
+                    const int s2o = top_channel % 9 - 4;
+                    const int s2p = top_channel / 9 - 4;
+                    for (int ch_off = 0; ch_off < 32; ++ch_off) {
+                        sum[ch_off] = 0;
+                        for (int ch = ch_off; ch < S3; ch += 32) {
+                            const int x2 = x1 + s2o;
+                            const int y2 = y1 + s2p;
+                            const size_t idx2 = (((size_t)item * S1 + y2) * S2 + x2) * S3 + ch;
+                            sum[ch_off] += patch_data[ch] * rbot1[idx2];
+                        }
+                    }
+                    float total_sum = 0;
+                    for (int idx = 0; idx < 32; ++idx) total_sum += sum[idx];
+                    const int sumelems = S3;
+                    const size_t index = (((size_t)top_channel * H + by) * W) + bx;      /* SIZE_2(top) = H, SIZE_3(top) = W */
+                    top[index + (size_t)item * 81 * H * W] = total_sum / (float)sumelems;
+                }
+            }
+    free(rbot0);
+    free(rbot1);
+    free(patch_data);
+    return 0;
+}

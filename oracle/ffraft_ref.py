@@ -32,8 +32,26 @@ BN_MOMENTUM = 0.1
 # ----------------------------------------------------------------------------
 # layer helpers
 # ----------------------------------------------------------------------------
+# None, or a callable applied to BOTH operands of every convolution and of the correlation matmul: lets the tests measure
+# what the reference's own GPU arithmetic does to the flow (common.py:25-27 turns TF32 on for cudnn and matmul; every
+# shipped config sets ALLOW_TF32: true) - see round_tf32() and tests/golden/make_golden_tf32.py.
+OPERAND_ROUND = None
+
+
+def round_tf32(t: Tensor) -> Tensor:
+    """fp32 -> TF32 (10 explicit mantissa bits, round to nearest even) -> fp32, as the tensor cores read their operands."""
+    if t.dtype != torch.float32:
+        return t
+    i = t.contiguous().view(torch.int32)
+    r = (i + 0xFFF + ((i >> 13) & 1)) & ~0x1FFF
+    return r.view(torch.float32)
+
+
 def _conv(sd, name, x, stride=1, padding=0):
-    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=stride, padding=padding)   # SA convs: no bias
+    w = sd[name + ".weight"]
+    if OPERAND_ROUND is not None:
+        x, w = OPERAND_ROUND(x), OPERAND_ROUND(w)
+    return F.conv2d(x, w, sd.get(name + ".bias"), stride=stride, padding=padding)   # SA convs: no bias
 
 
 def _norm(sd, name, x, kind, training):
@@ -131,6 +149,8 @@ def cce_encoder(sd, p, x, mask, kind, training=False, fusion_type="1x1conv"):
 def corr_volume(fmap1: Tensor, fmap2: Tensor) -> Tensor:
     """corr.py:52-60 → (B, Q, H, W) with Q = H*W, scaled by 1/sqrt(C)."""
     b, c, h, w = fmap1.shape
+    if OPERAND_ROUND is not None:
+        fmap1, fmap2 = OPERAND_ROUND(fmap1), OPERAND_ROUND(fmap2)
     vol = torch.matmul(fmap1.view(b, c, h * w).transpose(1, 2), fmap2.view(b, c, h * w))
     return (vol / torch.sqrt(torch.tensor(c).float()).to(vol.dtype)).view(b, h * w, h, w)
 

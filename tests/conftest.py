@@ -12,8 +12,22 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _host_cores() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup quota (a GPU box shows every core of
+    the host but grants 16: torch's default thread count would oversubscribe them many times over)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    torch.set_num_threads(_host_cores())      # the CPU oracle runs beside every GPU test
 
 
 def pytest_collection_modifyitems(config, items):

@@ -35,7 +35,8 @@ def test_library_exports_every_declared_symbol(lib_path):
     from focusflow_official_amd import _hip
     assert set(_hip.EXPORTS) == declared, "ctypes table and header disagree"
     lib.ff_abi_version.restype = ctypes.c_int
-    assert lib.ff_abi_version() == 1
+    ver = int(re.search(r"#define FF_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.ff_abi_version() == ver == _hip.ABI_VERSION == 2
 
 
 def test_conv_params_struct_layout(lib_path):

@@ -47,6 +47,49 @@ def test_config3_training_step_8x368x496_it12(det_sd):
     assert torch.isfinite(gn) and gn > 0
 
 
+def test_full_resolution_backward_1x368x496_it12_against_cpu_autograd(det_sd):
+    """The backward at FULL resolution (one FlyingChairs-sized pair, 12 iterations, frozen BatchNorm as train.py:192-193
+    runs the later stages): loss, last prediction and sampled parameter gradients against CPU autograd through the oracle
+    in fp32 AND fp64.  The 46 x 62 planes of 1/8 resolution (odd multiples of nothing: 23 x 31, 11 x 15, 5 x 7 below) and
+    the ragged last tiles of every tiled backward kernel only exist at this size; the small-shape gradient tests cannot
+    see an indexing slip there.  Bound per tensor: 8 x the oracle's own fp32-vs-fp64 spread, at least 5e-3 of the tensor's
+    maximum (the rule of test_hip_backward._check_grad_spread, where it is derived)."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    from test_hip_backward import _cfg, _check_grad_spread, _oracle_grads
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg())
+    m.load_state_dict(det_sd, strict=True)
+    m = m.to(DEV).train()
+    m.flow_net.freeze_bn()
+    h, w, iters = 368, 496, 12
+    inp = orc.shifted_pair(1, h, w, seed=51)
+    gen = torch.Generator().manual_seed(52)
+    flow_gt = (torch.randn(1, 2, h, w, generator=gen) * 5).clamp(-400, 400)
+    valid = torch.ones(1, h, w)
+    loss_fn = lambda preds: orc.sequence_l1(preds, flow_gt.to(preds[0]), valid.to(preds[0]))[0]  # noqa: E731
+    preds = m(*[t.to(DEV) for t in inp], raft_iters=iters)
+    loss = loss_fn(preds)
+    loss.backward()
+    torch.cuda.synchronize()
+    g32, last32 = _oracle_grads(det_sd, inp, iters, loss_fn, torch.float32)
+    g64, last64 = _oracle_grads(det_sd, inp, iters, loss_fn, torch.float64)
+    with torch.no_grad():
+        ref_loss = float(loss_fn([p.float() for p in orc.ffraft_forward(det_sd, *inp, raft_iters=iters, training=False)]))
+    assert abs(loss.item() - ref_loss) <= 2e-4 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
+    err = float((preds[-1].detach().cpu() - last32).abs().max())
+    spread = float((last32.double() - last64).abs().max())
+    assert err <= max(1e-3, 4 * spread), f"last prediction: {err:.3e} px from the oracle (its own fp32-vs-fp64 spread {spread:.3e})"
+    params = dict(m.named_parameters(remove_duplicate=False))
+    assert not [k for k, p in params.items() if p.requires_grad and p.grad is None]
+    names = ["flow_net.fnet.conv1.weight", "flow_net.fnet.mask_conv1.weight", "flow_net.fnet.layer1.0.conv1.weight",
+             "flow_net.fnet.layer2.0.conv2.weight", "flow_net.fnet.layer3.1.conv2.weight", "flow_net.fnet.conv2.weight",
+             "flow_net.fnet.fusion3.img2mask.conv.weight", "flow_net.cnet.layer2.0.downsample.0.weight", "flow_net.cnet.norm1.weight",
+             "flow_net.cnet.mask_layer3.0.conv1.weight", "flow_net.update_block.encoder.convc1.weight", "flow_net.update_block.encoder.convf1.weight",
+             "flow_net.update_block.gru.convq1.weight", "flow_net.update_block.gru.convz2.weight", "flow_net.update_block.flow_head.conv2.weight",
+             "flow_net.update_block.mask.2.weight", "flow_net.update_block.mask.0.bias"]
+    for name in names:
+        _check_grad_spread(params[name].grad.cpu(), g32[name], g64[name], name)
+
+
 def test_config4_ffpwcnet_1x448x1024_vs_oracle():
     from focusflow_official_amd.pwcnet import FF_PWCNET
     from oracle import pwc_ref

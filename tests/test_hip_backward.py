@@ -435,6 +435,49 @@ def test_frozen_bn_training_step_gives_gradients(det_sd):
     _check_grad_population(params, g32, g64)
 
 
+def test_frozen_frame_branch_training_step_against_fp64(det_sd):
+    """freeze_self() (FREEZE_MODULE: ablation/train/ffraft_prompt_tune.yaml, parallel_fusion.py:249-267, raft.py:109-113):
+    the frame branch of both encoders and the update block are frozen, the condition branch and the fusion units train.
+    Frozen convs sit between trainable ones, so gradients flow THROUGH them: their norms publish max|dx| hints that a
+    frozen conv may never consume (fn.GraphScope.take_hint must not hand a recycled address to another gradient).  Every
+    trainable parameter - and only those - gets a gradient, compared with CPU autograd of the oracle in fp32 and fp64."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg())
+    m.load_state_dict(det_sd, strict=True)
+    m = m.to(DEV).train()
+    m.flow_net.freeze_bn()
+    m.flow_net.freeze_self("parallel")
+    inp = orc.shifted_pair(2, 128, 128, seed=13)
+    preds = m(*[t.to(DEV) for t in inp], raft_iters=3)
+    sum(p.abs().mean() for p in preds).backward()
+    torch.cuda.synchronize()
+    loss_fn = lambda ref: sum(r.abs().mean() for r in ref)  # noqa: E731
+    g32, last32 = _oracle_grads(det_sd, inp, 3, loss_fn, torch.float32)
+    g64, _ = _oracle_grads(det_sd, inp, 3, loss_fn, torch.float64)
+    close(preds[-1].detach().cpu(), last32, rtol=0, atol_rel=2e-4, what="pred")
+    params = dict(m.named_parameters(remove_duplicate=False))
+    frozen = [k for k, p in params.items() if not p.requires_grad]
+    trainable = [k for k, p in params.items() if p.requires_grad]
+    assert len(frozen) > 50 and len(trainable) > 50
+    assert all(params[k].grad is None for k in frozen)
+    assert not [k for k in trainable if params[k].grad is None]
+    assert all(bool(torch.isfinite(params[k].grad).all()) for k in trainable)
+    for name in ["flow_net.fnet.mask_conv1.weight", "flow_net.fnet.mask_layer1.0.conv1.weight", "flow_net.fnet.fusion1.mask2img.conv.weight",
+                 "flow_net.fnet.fusion3.img2mask.conv.weight", "flow_net.cnet.mask_layer2.0.conv2.weight", "flow_net.cnet.fusion2.mask2img.conv.bias",
+                 "flow_net.fnet.mask_layer3.1.conv1.weight", "flow_net.cnet.mask_conv2.weight"]:
+        _check_grad_spread(params[name].grad.cpu(), g32[name], g64[name], name)
+    hip, cpu = [], []
+    for k in trainable:
+        if k not in g64 or float(g64[k].abs().max()) < 1e-7:      # norm3 of a stride-2 block is registered twice (downsample.1)
+            continue
+        s = float(g64[k].abs().max())
+        hip.append(float((params[k].grad.cpu().double() - g64[k]).abs().max()) / s)
+        cpu.append(float((g32[k].double() - g64[k]).abs().max()) / s)
+    hip, cpu = np.array(hip), np.array(cpu)
+    assert np.median(hip) <= max(4 * np.median(cpu), 3e-3), (np.median(hip), np.median(cpu))
+    assert hip.max() <= 0.1, hip.max()
+
+
 @pytest.mark.parametrize("partial", [False, True])
 def test_shared_weight_gradient_scope_matches_immediate_mode(det_sd, partial, monkeypatch):
     """fn.GraphScope (one weight-gradient buffer per conv and per recorded pass, delivered once per backward pass by

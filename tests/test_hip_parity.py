@@ -5,6 +5,7 @@ Tolerances: fp32 activations rtol 2e-5 (fp32 MFMA is an exact fma chain; the
 summation order differs from oneDNN's); final flow max-abs 1e-3 (BASELINE.json
 north_star); lookup tap indices bit-exact.
 """
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -445,6 +446,63 @@ def test_config1_384x512_and_batch_consistency(det_sd):
     for i in range(8):
         close(fu8[i].cpu(), flow_up[0].cpu(), rtol=0, atol=5e-4, what=f"batch sample {i}")
         assert torch.equal(fu8[i], fu8[0])
+
+
+def test_reduced_precision_mode_end_to_end_epe_against_the_references_tf32_level(det_sd):
+    """BASELINE configs[1] as literally written: reduced-precision arithmetic "vs reference EPE".  The throughput mode
+    FF_CONV_PRECISION=f16 (one MFMA term: operands with 10 mantissa bits, fp32 accumulation) is the analogue of what the
+    reference itself runs on a GPU - TF32, common.py:25-27 / ALLOW_TF32: true - whose cost in flow accuracy
+    tests/golden/make_golden_tf32.py measured on the pinned oracle: 0.022 px mean / 0.21 px max end-point error against the
+    fp32 reference on this input.  The HIP mode must stay within 3 x that, for one pair and for a batch of eight."""
+    import json
+    from focusflow_official_amd import ops as hops
+    with open(os.path.join(os.path.dirname(__file__), "golden", "tf32_epe_384x512.json")) as f:
+        tf32 = json.load(f)
+    g = load_golden("fwd_shift_384x512_b1_it12")
+    inp = [t.to(DEV) for t in orc.shifted_pair(1, 384, 512, seed=6)]
+    prev = hops.conv_precision()
+    hops.set_conv_precision("f16")
+    try:
+        m = _model(det_sd)
+        with torch.no_grad():
+            fl1, fu1 = m(*inp, raft_iters=12, test_mode=True)
+            fl8, fu8 = m(*[t.repeat(8, 1, 1, 1) for t in inp], raft_iters=12, test_mode=True)
+    finally:
+        hops.set_conv_precision(prev)
+    ref_up, ref_low = torch.from_numpy(g["flow_up_sub"]), torch.from_numpy(g["flow_low"])
+
+    def epe(a, b):
+        return torch.sqrt(((a - b) ** 2).sum(1))
+    for what, fu, fl in [("1 pair", fu1, fl1)] + [(f"sample {i} of 8", fu8[i:i + 1], fl8[i:i + 1]) for i in range(8)]:
+        e_up, e_low = epe(fu.cpu()[:, :, ::4, ::4], ref_up), epe(fl.cpu(), ref_low)
+        print(f"{what}: f16 mode EPE up mean {e_up.mean():.4f} max {e_up.max():.4f}, low mean {e_low.mean():.4f} max {e_low.max():.4f} px "
+              f"(TF32 oracle: {tf32['epe_up_mean_px']:.4f} / {tf32['epe_up_max_px']:.4f})")
+        assert torch.isfinite(fu).all()
+        assert float(e_up.mean()) <= 3 * tf32["epe_up_mean_px"], what
+        assert float(e_up.max()) <= 3 * tf32["epe_up_max_px"], what
+        assert float(e_low.mean()) <= 3 * tf32["epe_low_mean_px"], what
+
+
+def test_check_range_debug_mode_reports_activations_beyond_the_split_format(det_sd):
+    """FF_CHECK_RANGE=1 / ops.CHECK_RANGE: the fp16-split conv formats read x as f16(4 x) + residual, so |x| >= 16376
+    becomes inf - silently, apart from a NaN flow.  The debug mode measures max|x| of every forward conv input and the model
+    raises at the end of the pass; the same weights pass cleanly, and with the check off nothing is measured."""
+    from focusflow_official_amd import _hip, ops as hops
+    m = _model(det_sd)
+    inp = [t.to(DEV) for t in orc.shifted_pair(1, 128, 160, seed=2)]
+    hops.CHECK_RANGE = True
+    try:
+        with torch.no_grad():
+            m(*inp, raft_iters=2, test_mode=True)                      # in range: no error
+            with torch.no_grad():
+                m.flow_net.cnet.norm1.weight.mul_(2.0e4)                # folded BatchNorm scale: activations of ~1e4 .. 1e5
+            m.invalidate_packed()
+            with pytest.raises(_hip.FocusFlowHipError, match="16376"):
+                m(*inp, raft_iters=2, test_mode=True)
+    finally:
+        hops.CHECK_RANGE = False
+    with torch.no_grad():
+        m(*inp, raft_iters=2, test_mode=True)                          # check off: nothing is measured, nothing raised
 
 
 def test_skip_unused_upsample_is_bit_identical(det_sd):

@@ -345,3 +345,22 @@ def test_division_by_plane_size_in_five_fused_operations_is_the_true_quotient():
         tie = (d * (m + rng.choice([-0.5, 0.5], m.size)) / 2 * 2.0 ** -20).astype(np.float32)
         bad, first = corr_c.div5_mismatches(np.concatenate(xs + [tie]), int(d))
         assert bad == 0, (d, bad, first)
+
+
+@pytest.mark.parametrize("b,c,h,w", [(2, 37, 9, 11), (1, 196, 7, 16), (1, 32, 14, 32), (1, 16, 5, 6)])
+def test_pwc_cost_volume_two_independent_restatements_agree(b, c, h, w):
+    """The FF-PWC cost volume has no reference run to pin it (CuPy kernels: no CUDA here).  Two restatements that share
+    no code - the tensor-wise one in oracle/pwc_ref.py and the loop-level transcription of correlation.py:7-102 in
+    oracle/corr_oracle.c (padded NHWC rbot, ch % 9 - 4 on x, ch / 9 - 4 on y, 32 striding partial sums) - must agree."""
+    from oracle import corr_c, pwc_ref
+    g = torch.Generator().manual_seed(b * 1000 + c)
+    one, two = torch.randn(b, c, h, w, generator=g), torch.randn(b, c, h, w, generator=g)
+    a = pwc_ref.cost_volume(one, two).numpy()
+    k = corr_c.pwc_costvolume_kernel(one.numpy(), two.numpy())
+    assert a.shape == k.shape == (b, 81, h, w)
+    np.testing.assert_allclose(k, a, rtol=0, atol=2e-6 * max(1.0, float(np.abs(a).max())))
+    # displacement (0, 0) is channel 40 and nothing else: <one, two> / C
+    np.testing.assert_allclose(k[:, 40], (one * two).sum(1).numpy() / c, rtol=0, atol=2e-6 * max(1.0, float(np.abs(a).max())))
+    # the volume is not symmetric in its arguments: swapping them mirrors the displacement
+    k2 = corr_c.pwc_costvolume_kernel(two.numpy(), one.numpy())
+    assert np.abs(k2 - k).max() > 1e-3
