@@ -488,7 +488,7 @@ def test_shared_weight_gradient_scope_matches_immediate_mode(det_sd, partial, mo
     results = []
     for use_scope in (True, False):
         if not use_scope:
-            monkeypatch.setattr(fn, "begin_graph", lambda: None)
+            monkeypatch.setattr(fn, "begin_graph", lambda device=None: None)
         m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg())
         m.load_state_dict(det_sd, strict=True)
         m = m.to(DEV).train()
