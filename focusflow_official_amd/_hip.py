@@ -30,6 +30,7 @@ class FFConvParams(C.Structure):
         ("in_scale", _fp), ("in_shift", _fp), ("in_act", C.c_int),
         ("res2", _fp), ("res2_ld", C.c_int), ("res_split", C.c_int),
         ("splitk_ws", _fp), ("splitk", C.c_int),
+        ("ep_mode", C.c_int), ("ep_split", C.c_int), ("ep_a", _fp), ("ep_a_ld", C.c_int), ("ep_b", _fp), ("ep_b_ld", C.c_int),
     ]
 
 
@@ -108,7 +109,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint"])
 
-ABI_VERSION = 2      # include/focusflow_hip.h: FF_ABI_VERSION
+ABI_VERSION = 3      # include/focusflow_hip.h: FF_ABI_VERSION
 _lib = None
 
 

@@ -9,7 +9,7 @@ char* err_buf() {
 }  // namespace ff
 
 extern "C" const char* ff_last_error(void) { return ff::err_buf(); }
-// 2: FFConvParams grew res2 / res2_ld / res_split / splitk_ws / splitk, ff_norm_bwd gained dx_amax, the row-major corr
+// 3: FFConvParams + ep_mode ... ep_b_ld (GRU steps in the conv epilogue).  2: FFConvParams grew res2 / res2_ld / res_split / splitk_ws / splitk, ff_norm_bwd gained dx_amax, the row-major corr
 // backward entry points went away (round 2).  Callers zero-initialise the WHOLE FFConvParams and check this number.
 extern "C" int ff_abi_version(void) { return FF_ABI_VERSION; }
 

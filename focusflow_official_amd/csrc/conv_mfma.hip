@@ -295,6 +295,17 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     FF_REQUIRE(!p.res2 || (p.res && p.w_format != FF_W_F32 && p.KH == 1 && p.KW == 1 && p.groups == 1 && p.res_split > 0 &&
                            p.res_split < p.Cout && p.res2_ld >= p.Cout - p.res_split && !getenv("FF_WS_CONV")),
                "ff_conv2d_fwd: res2 needs res, a split weight format and a 1x1 kernel (0 < res_split < Cout)");
+    FF_REQUIRE(p.ep_mode >= FF_EP_NONE && p.ep_mode <= FF_EP_GRU_BLEND, "ff_conv2d_fwd: bad ep_mode %d", p.ep_mode);
+    if (p.ep_mode) {
+        FF_REQUIRE(p.w_format == FF_W_F16X3 && p.groups == 1 && p.stride == 1 && cin % 32 == 0 && p.KH * p.KW >= 3 && !p.res2 && !p.in_scale &&
+                   p.Cout % 4 == 0 && p.y_ld % 4 == 0 && ff::aligned16(p.y),
+                   "ff_conv2d_fwd: ep_mode needs the f16x3 patch kernel (stride 1, Cin %% 32 == 0, 3x3 / 1x5 / 5x1) and a 16-byte aligned output");
+        FF_REQUIRE(p.ep_a && ff::aligned16(p.ep_a) && p.ep_a_ld % 4 == 0, "ff_conv2d_fwd: ep_a null or misaligned");
+        if (p.ep_mode == FF_EP_GRU_RH)
+            FF_REQUIRE(p.ep_split > 0 && p.ep_split < p.Cout && p.ep_split % 4 == 0 && p.ep_a_ld >= p.Cout - p.ep_split, "ff_conv2d_fwd: FF_EP_GRU_RH: bad ep_split %d / ep_a_ld %d", p.ep_split, p.ep_a_ld);
+        else
+            FF_REQUIRE(p.ep_b && ff::aligned16(p.ep_b) && p.ep_b_ld % 4 == 0 && p.ep_a_ld >= p.Cout && p.ep_b_ld >= p.Cout, "ff_conv2d_fwd: FF_EP_GRU_BLEND: ep_b null / misaligned or ld < Cout");
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (p.w_format != FF_W_F32) return ff::conv2d_fwd_split(p, (int)M, cin, s);
     if (const int rc = ff::conv2d_fwd_small(p, cin, s); rc != 1) return rc;    // 1- and 2-channel 3x3 heads: vector ALU

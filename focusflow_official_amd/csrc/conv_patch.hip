@@ -64,7 +64,8 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {   
 // 15, k-group g = lane >> 4); the instruction serves lanes {0-3,12-15} of one k-group together with {4-11} of the next):
 // the 16-byte k-groups of a term sit in the order 0, 2, 1, 3, and MFMA rows 4..11 read the even rows of a tile,
 // rows 0..3 / 12..15 the odd ones (a weight row's place in LDS, a pixel's column in the tile: PI16).
-template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false, bool INORM = false, bool SPLITK = false, bool MF16 = false>   // WB = weight buffers in LDS
+// EPI (MF16 only): FFConvParams.ep_mode - a GRU step applied to the finished value (FF_EP_GRU_RH / FF_EP_GRU_BLEND)
+template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false, bool INORM = false, bool SPLITK = false, bool MF16 = false, int EPI = 0>   // WB = weight buffers in LDS
 __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
     constexpr int TH = 4 * TM, BN = 64 * TN, NW = 2 * TN;       // NW = 16-byte weight pieces per thread and tap
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -297,6 +298,29 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vv[u][r] = ff::apply_act(vv[u][r] + rr[u][r], p.act_res);
             }
+            if constexpr (EPI == FF_EP_GRU_RH) {          // [z | r] -> [z | r * h]: channels >= ep_split times ep_a (update.py:47-48)
+                if (n4 >= p.ep_split) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) rr[u] = po[u] >= 0 ? *reinterpret_cast<const f32x4*>(p.ep_a + po[u] * p.ep_a_ld + (n4 - p.ep_split)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < NU; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vv[u][r] = __fmul_rn(vv[u][r], rr[u][r]);
+                }
+            }
+            if constexpr (EPI == FF_EP_GRU_BLEND) {       // v = tanh(q) -> (1 - z) h + z v (update.py:49), z = ep_a, h = ep_b
+                f32x4 zz[NU];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    zz[u] = po[u] >= 0 ? *reinterpret_cast<const f32x4*>(p.ep_a + po[u] * p.ep_a_ld + n4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    rr[u] = po[u] >= 0 ? *reinterpret_cast<const f32x4*>(p.ep_b + po[u] * p.ep_b_ld + n4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        vv[u][r] = __fadd_rn(__fmul_rn(__fsub_rn(1.f, zz[u][r]), rr[u][r]), __fmul_rn(zz[u][r], vv[u][r]));
+            }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 if (po[u] < 0) continue;
@@ -471,8 +495,8 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, WB>(a); }
 // one weight buffer: 35 KB of LDS, so four blocks fit a CU if the registers allow four waves per SIMD
-template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0, bool INORM = false, bool SPLITK = false, bool MF16 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN, INORM, SPLITK, MF16>(a); }
+template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0, bool INORM = false, bool SPLITK = false, bool MF16 = false, int EPI = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN, INORM, SPLITK, MF16, EPI>(a); }
 
 // sum of the K splits in a fixed order, then the epilogue of conv_patch_body (same operations in the same order)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const FFConvParams p, int splits, long long npix) {
@@ -499,6 +523,11 @@ int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
     // loop: per-layer times are equal within 1 % (12.70 vs 12.73 ms of convolutions per step) and the normalise-on-load
     // variant spills (+13 % on its layers).
     static const bool mf16 = getenv("FF_MFMA16") && atoi(getenv("FF_MFMA16")) == 1;
+    if (a.p.ep_mode) {           // GRU step in the epilogue: the 16x16x32 variants carry it (four channels per lane: 16-byte operand loads)
+        if (a.p.ep_mode == FF_EP_GRU_RH) conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, false, true, FF_EP_GRU_RH><<<(unsigned)blocks, 256, lds, s>>>(a);
+        else conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, false, true, FF_EP_GRU_BLEND><<<(unsigned)blocks, 256, lds, s>>>(a);
+        return ff::check_launch("ff_conv2d_fwd(patch, GRU epilogue)");
+    }
     if (mf16 && !getenv("FF_PATCH_ABLATE")) {
         if (a.p.splitk > 1) {
             const int splits = (a.nci + a.nci_split - 1) / a.nci_split;
@@ -611,6 +640,9 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     // split-K (FFConvParams.splitk, see conv2d_splitk_hint): the 4-row high-occupancy variant only
     if (!(occ && th == 4 && p.splitk > 1 && p.splitk_ws && !p.in_scale && !p.res2)) a.p.splitk = 0;
     a.nci_split = a.p.splitk > 1 ? (a.nci + a.p.splitk - 1) / a.p.splitk : a.nci;
+    if (p.ep_mode) {             // validated by ff_conv2d_fwd; the high-occupancy variants carry the GRU epilogues
+        if (!occ || a.p.splitk > 1 || p.in_scale || p.Cout % 4) return ff::fail(FF_EINVAL, "ff_conv2d_fwd: ep_mode needs the f16x3 patch kernel's 8x16 / 4x16 tiles (got %dx%d kernel, Cin %d, Cout %d)", p.KH, p.KW, cin, p.Cout);
+    }
     if (occ) return th == 8 ? launch_occ<3, 6, 2, 1, 4>(a, lds, s) : launch_occ<3, 4, 1, 1, 5>(a, lds, s);
     if (p.in_scale) return 1;            // only the two variants above normalise while loading (the caller fails loudly)
 #define FF_PATCH_CASE(TH_, TN_, NI_) \

@@ -146,7 +146,8 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
            res: Optional[Tensor] = None, act_res: int = ACT_NONE, ch_scale: Optional[Tensor] = None,
            ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0, dilation: int = 1,
            x_amax: Optional[Tensor] = None, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None,
-           in_act: int = ACT_NONE, res2: Optional[Tensor] = None, res_split: int = 0) -> Tensor:
+           in_act: int = ACT_NONE, res2: Optional[Tensor] = None, res_split: int = 0,
+           ep_rh: Optional[Tensor] = None, ep_split: int = 0, ep_blend=None) -> Tensor:
     """Convolution over the channel-concatenation of `xs` (see FFConvParams).  res2 / res_split: output channels
     >= res_split take their residual from `res2` (paired 1x1 fusion convs).  `wpack` is fp32
     [Cout][K] (w_fmt 0) or the split rows of pack_split (w_fmt 1/2).  x_amax: device word holding the bits of
@@ -181,6 +182,11 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     p.res_ld = _ld(res) if res is not None else 0
     if res2 is not None:
         p.res2, p.res2_ld, p.res_split = res2.data_ptr(), _ld(res2), res_split
+    if ep_rh is not None:       # FF_EP_GRU_RH: output channels >= ep_split leave multiplied by ep_rh (the z|r conv writes [z | r*h])
+        p.ep_mode, p.ep_split, p.ep_a, p.ep_a_ld = 1, ep_split, ep_rh.data_ptr(), _ld(ep_rh)
+    elif ep_blend is not None:  # FF_EP_GRU_BLEND: (z, h) -> the output is (1 - z) h + z v (the q conv writes the new state)
+        z, hprev = ep_blend
+        p.ep_mode, p.ep_a, p.ep_a_ld, p.ep_b, p.ep_b_ld = 2, z.data_ptr(), _ld(z), hprev.data_ptr(), _ld(hprev)
     p.y, p.y_ld, p.y_gstride = out.data_ptr(), _ld(out), 0
     p.Ho, p.Wo, p.Cout = ho, wo, cout
     p.KH, p.KW, p.stride, p.pad_h, p.pad_w = kh, kw, stride, pad[0], pad[1]

@@ -12,12 +12,13 @@ import os
 import torch
 import torch.nn as nn
 
-from . import fn, ops
+from . import _hip, fn, ops
 from .cce import PackedConv
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 
 
 _SIDE_STREAM = os.environ.get("FF_SIDE_STREAM", "1") != "0"      # measurement switch (BasicMotionEncoder.run)
+_GRU_EPILOGUE = os.environ.get("FF_GRU_EPILOGUE", "1") != "0"    # r*h and the state blend in the conv epilogues (inference); 0: ff_gru_rh / ff_gru_blend launches
 _side_streams = {}
 
 
@@ -69,7 +70,15 @@ class SepConvGRU(nn.Module):
         xs[0] itself is not read again."""
         c = self.hidden_dim
         if pre is not None:
+            fused = _GRU_EPILOGUE and ops.w_format() == _hip.W_F16X3
             for zr_conv, q_conv, (zr_pre, q_pre) in zip(self._zr_hm, self._q_hm, pre):
+                if fused:
+                    # the two element-wise steps ride in the epilogues of the convolutions that precede them (FFConvParams
+                    # ep_mode; same roundings as ff_gru_rh / ff_gru_blend: bit-identical states): the z|r convolution
+                    # writes [z | r * h], the q convolution writes (1 - z) h + z tanh(.) - 48 launches less per 12 iterations
+                    zr = zr_conv([h] + xs[1:], res=zr_pre, act_res=ACT_SIGMOID, ep_rh=h, ep_split=c)
+                    h = q_conv([zr[..., c:]] + xs[1:], res=q_pre, act_res=ACT_TANH, ep_blend=(zr[..., :c], h))
+                    continue
                 zr = zr_conv([h] + xs[1:], res=zr_pre, act_res=ACT_SIGMOID)     # sigmoid(conv([h, motion]) + b + pre)
                 rh = ops.gru_rh(zr[..., c:], h)
                 q = q_conv([rh] + xs[1:], res=q_pre, act_res=ACT_TANH)

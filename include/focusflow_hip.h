@@ -49,8 +49,9 @@ const char* ff_last_error(void);
  * that grew since the caller was built would be read past its end) and must zero-initialise every FFConvParams it
  * passes: new trailing fields mean "feature off" when zero.
  *   2 (round 2): FFConvParams + res2, res2_ld, res_split, splitk_ws, splitk; ff_norm_bwd + dx_amax; ff_corr_lookup_bwd and
- *                ff_corr_pyramid_bwd (row-major) removed */
-#define FF_ABI_VERSION 2
+ *                ff_corr_pyramid_bwd (row-major) removed
+ *   3 (round 3): FFConvParams + ep_mode, ep_split, ep_a, ep_a_ld, ep_b, ep_b_ld */
+#define FF_ABI_VERSION 3
 int ff_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -106,7 +107,19 @@ typedef struct FFConvParams {
     int splitk;                        /* input channels is cut into `splitk` ranges computed by separate blocks, summed   */
                                        /* in a fixed order by a second launch (deterministic).  Use ff_conv2d_splitk_hint: */
                                        /* it pays for small planes with long reductions (FF-PWC decoders, 7x16..56x128).   */
+    int ep_mode;                       /* FF_EP_*: an element-wise step of SepConvGRU (update.py:45-60) applied to the      */
+    int ep_split;                      /* finished output value v = act_res(act(conv) + res) before it is stored:           */
+    const float* ep_a;                 /*   FF_EP_GRU_RH    channels n >= ep_split: v * ep_a[m][n - ep_split]  (r * h: the  */
+    int ep_a_ld;                       /*                   z|r convolution writes [z | r*h], update.py:47-48)              */
+    const float* ep_b;                 /*   FF_EP_GRU_BLEND (1 - ep_a[m][n]) * ep_b[m][n] + ep_a[m][n] * v  (the new state  */
+    int ep_b_ld;                       /*                   from the q convolution: a = z, b = h, update.py:49)             */
+                                       /* Same roundings as ff_gru_rh / ff_gru_blend.  Split-format stride-1 convolutions   */
+                                       /* with Cin % 32 == 0 and a 3x3 / 1x5 / 5x1 kernel (the patch kernel); ep_a / ep_b    */
+                                       /* NHWC, 16-byte aligned, ld % 4 == 0.                                               */
 } FFConvParams;
+#define FF_EP_NONE 0
+#define FF_EP_GRU_RH 1
+#define FF_EP_GRU_BLEND 2
 
 int ff_conv2d_fwd(const FFConvParams* p, void* stream);
 

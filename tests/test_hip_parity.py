@@ -505,6 +505,42 @@ def test_check_range_debug_mode_reports_activations_beyond_the_split_format(det_
         m(*inp, raft_iters=2, test_mode=True)                          # check off: nothing is measured, nothing raised
 
 
+def test_gru_steps_in_the_conv_epilogues_are_bit_identical(det_sd, monkeypatch):
+    """Inference folds r * h into the epilogue of the z|r convolution and the state blend (1 - z) h + z tanh(q) into the q
+    convolution's (FFConvParams.ep_mode; update.py:47-49).  The element-wise arithmetic is the same sequence of separately
+    rounded operations as ff_gru_rh / ff_gru_blend, but the fused launches run the 16x16x32 variant of the patch kernel
+    (another summation order inside the convolution than the 32x32x16 one the unfused path uses): flows equal to fp32
+    rounding, and the fused op itself - same convolution kernel, epilogue on or off - bit for bit."""
+    from focusflow_official_amd import update_block
+    m = _model(det_sd)
+    inp = [t.to(DEV) for t in orc.shifted_pair(2, 128, 192, seed=4)]
+    with torch.no_grad():
+        monkeypatch.setattr(update_block, "_GRU_EPILOGUE", False)
+        fl0, fu0 = m(*inp, raft_iters=6, test_mode=True)
+        monkeypatch.setattr(update_block, "_GRU_EPILOGUE", True)
+        fl1, fu1 = m(*inp, raft_iters=6, test_mode=True)
+    close(fu1.cpu(), fu0.cpu(), rtol=0, atol=2e-4, what="flow_up, GRU epilogues on vs off")
+    # the op against the element-wise kernels applied to the outputs of the un-fused convolutions
+    from focusflow_official_amd import ops as hops
+    gru = m.flow_net.update_block.gru
+    g = torch.Generator().manual_seed(3)
+    h = torch.tanh(torch.randn(2, 16, 24, 128, generator=g)).to(DEV)
+    motion = torch.randn(2, 16, 24, 128, generator=g).to(DEV)
+    ctx = torch.relu(torch.randn(2, 16, 24, 128, generator=g)).to(DEV)
+    with torch.no_grad():
+        (zr_pre, q_pre), _ = gru.prepare(ctx)
+        zr_conv, q_conv = gru._zr_hm[0], gru._q_hm[0]
+        zr_f = zr_conv([h, motion], res=zr_pre, act_res=hops.ACT_SIGMOID, ep_rh=h, ep_split=128)
+        zr_u = zr_conv([h, motion], res=zr_pre, act_res=hops.ACT_SIGMOID)
+        rh_u = hops.gru_rh(zr_u[..., 128:], h)
+        h_f = q_conv([zr_f[..., 128:], motion], res=q_pre, act_res=hops.ACT_TANH, ep_blend=(zr_f[..., :128], h))
+        q_u = q_conv([rh_u, motion], res=q_pre, act_res=hops.ACT_TANH)
+        h_u = hops.gru_blend(zr_u[..., :128], q_u, h)
+    close(zr_f[..., :128].cpu(), zr_u[..., :128].cpu(), rtol=0, atol=2e-6, what="z")
+    close(zr_f[..., 128:].cpu(), rh_u.cpu(), rtol=0, atol=2e-6, what="r * h")
+    close(h_f.cpu(), h_u.cpu(), rtol=0, atol=2e-6, what="new state")
+
+
 def test_skip_unused_upsample_is_bit_identical(det_sd):
     """Opt-in inference shortcut: mask head + convex up-sampling for the last iteration only (the reference throws
     the other results away in test_mode, raft.py:226-236) must not change a single bit of either output."""
