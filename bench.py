@@ -495,28 +495,34 @@ def main():
         step()
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
-    ops.profile_begin("lookup", "corr_volume")       # HIP events around every lookup / corr-build launch
+    # HIP events bound to every lookup / corr-build dispatch of the timed region (ff_launch_timing_begin: the library hands
+    # an event pair to hipExtLaunchKernelGGL on the stream it launches on - the kernels' own execution times)
+    ops.launch_timing_begin(ops.TIME_LOOKUP, ops.TIME_CORR_BUILD)
     elapsed, out = timed_region(step, args.steps, world, torch.cuda.synchronize, device)
     log(f"{args.steps} timed steps in {elapsed:.3f} s")
-    prof = ops.profile_end()
-    lookup_ms, vol_ms = prof["lookup"], prof["corr_volume"]
+    lk, vb = ops.launch_timing_end(ops.TIME_LOOKUP), ops.launch_timing_end(ops.TIME_CORR_BUILD)
     assert torch.isfinite(out[1]).all()
 
     if rank == 0:
         pairs = args.batch * world * args.steps
         q = (hi - lo) * (args.height // 8) * (args.width // 8)
-        if args.graph:   # per-launch events cannot be recorded inside a replayed graph: time the kernels eagerly
-            ops.profile_begin("lookup", "corr_volume")
+        if args.graph:   # a replayed graph launches no kernels through the library: time one eager forward instead
+            ops.launch_timing_begin(ops.TIME_LOOKUP, ops.TIME_CORR_BUILD)
             with torch.no_grad():
                 model(*batch, raft_iters=args.iters, test_mode=True)
-            prof = ops.profile_end()
-            lookup_ms, vol_ms = prof["lookup"], prof["corr_volume"]
-        per_launch_ms = sum(lookup_ms) / max(1, len(lookup_ms))
+            lk, vb = ops.launch_timing_end(ops.TIME_LOOKUP), ops.launch_timing_end(ops.TIME_CORR_BUILD)
+        # the same launches bracketed by event pairs recorded around them (one extra untimed step): adds the dispatch gaps
+        ops.profile_begin("lookup")
+        with torch.no_grad():
+            model(*batch, raft_iters=args.iters, test_mode=True)
+        bracketed = ops.profile_end()["lookup"]
+        n_lookups = lk[0]
+        per_launch_ms = lk[1] / max(1, n_lookups) * 1e-3
         per_q = LOOKUP_BYTES_PER_QUERY[args.pyramid]
         # queries per LAUNCH from the launches actually seen: one lookup per iteration covers the rank's whole batch,
         # unless the opt-in FF_UPDATE_SPLIT runs the loop on batch slices (then every launch covers a slice)
         timed_steps = 1 if args.graph else args.steps
-        q = int(round(q * args.iters * timed_steps / max(1, len(lookup_ms))))
+        q = int(round(q * args.iters * timed_steps / max(1, n_lookups)))
         achieved = per_q * q / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         c2 = (args.height, args.width, args.iters, args.batch) == (384, 512, 12, 8) and args.pyramid == "fp32"
         line = {
@@ -533,13 +539,16 @@ def main():
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(q, args.pyramid)[0],
                          "traffic_source": pmc_traffic(q, args.pyramid)[1],
-                         "launches": len(lookup_ms), "avg_launch_us": round(per_launch_ms * 1e3, 2),
+                         "launches": n_lookups, "avg_launch_us": round(per_launch_ms * 1e3, 2),
+                         "min_launch_us": round(lk[2], 2), "max_launch_us": round(lk[3], 2),
+                         "timing": "HIP events bound to each dispatch of the timed region (hipExtLaunchKernelGGL start/stop events on the launching stream)",
+                         "avg_launch_us_bracketed": round(sum(bracketed) / max(1, len(bracketed)) * 1e3, 2),
                          "algorithmic_bytes_per_query": per_q, "algorithmic_bytes_per_launch": per_q * q},
         }
         # corr-volume build (BASELINE.md "also reported"): dense HWxC x CxHW contraction on the matrix pipe
         q1 = (args.height // 8) * (args.width // 8)
         vol_flop = 2.0 * (hi - lo) * q1 * q1 * 256
-        vol_avg_ms = sum(vol_ms) / max(1, len(vol_ms))
+        vol_avg_ms = vb[1] / max(1, vb[0]) * 1e-3
         terms = {"f16x3": 3, "f16": 1, "fp32": 1}[ops.conv_precision()]
         peak = MFMA_PEAK_TFLOPS["fp32" if ops.conv_precision() == "fp32" else "f16"]
         issued = vol_flop * terms / (vol_avg_ms * 1e-3) / 1e12 if vol_avg_ms > 0 else 0.0
@@ -551,7 +560,7 @@ def main():
             "note": f"{terms} MFMA term(s) per fp32-accurate product; useful rate {vol_flop / (vol_avg_ms * 1e-3) / 1e12:.1f} TFLOP/s; "
                     f"the launch also writes the whole pyramid once ({pyr_bytes / 1e6:.1f} MB)",
             "write_gbs": round(pyr_bytes / (vol_avg_ms * 1e-3) / 1e9, 1) if vol_avg_ms > 0 else 0.0, "write_bytes": pyr_bytes,
-            "launches": len(vol_ms), "avg_launch_us": round(vol_avg_ms * 1e3, 1)}
+            "launches": vb[0], "avg_launch_us": round(vol_avg_ms * 1e3, 1)}
         # all convolutions of one extra (untimed) step, each launch bracketed by HIP events: where 80 % of the step goes
         ops.SINGLE_STREAM = True          # bracketed launches must not overlap: this extra step runs on one stream
         try:

@@ -31,6 +31,7 @@ class FFConvParams(C.Structure):
         ("res2", _fp), ("res2_ld", C.c_int), ("res_split", C.c_int),
         ("splitk_ws", _fp), ("splitk", C.c_int),
         ("ep_mode", C.c_int), ("ep_split", C.c_int), ("ep_a", _fp), ("ep_a_ld", C.c_int), ("ep_b", _fp), ("ep_b_ld", C.c_int),
+        ("stats_part", _fp),
     ]
 
 
@@ -40,6 +41,9 @@ _SIGS = {
     "ff_pack_conv_weight": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp],
     "ff_pack_split_f16": [_fp, _fp, _ll, C.c_int, _fp],
     "ff_norm_stats": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
+    "ff_norm_stats_finish": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
+    "ff_launch_timing_begin": [C.c_int],
+    "ff_launch_timing_end": [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "ff_norm_apply": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_float,
                       _fp, _fp, C.c_int, _fp, C.c_int, _fp],
     "ff_norm_coeffs": [_fp, C.c_int, C.c_int, _ll, C.c_float, _fp, _fp, _fp, _fp, _fp],
@@ -107,7 +111,7 @@ _SIGS = {
     "ff_scale_add_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int,
                          C.c_int, _fp],
 }
-EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint"])
+EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint", "ff_conv2d_stats_parts"])
 
 ABI_VERSION = 3      # include/focusflow_hip.h: FF_ABI_VERSION
 _lib = None
@@ -139,6 +143,8 @@ def load():
     lib.ff_corr_plane_elems.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.ff_conv2d_splitk_hint.restype = C.c_int
     lib.ff_conv2d_splitk_hint.argtypes = [C.POINTER(FFConvParams)]
+    lib.ff_conv2d_stats_parts.restype = C.c_int
+    lib.ff_conv2d_stats_parts.argtypes = [C.POINTER(FFConvParams)]
     got = lib.ff_abi_version()
     if got != ABI_VERSION:
         raise FocusFlowHipError(f"{LIB_PATH} speaks ABI version {got}, these bindings (FFConvParams layout, argument lists) "

@@ -358,6 +358,9 @@ class BasicParallelFusionLayer(nn.Module):
             params += [norm.weight, norm.bias]
         taped = fn.recording(x, res, *params)
         if self.norm_fn == "instance":
+            if not taped:
+                y, st = pc(x, want_stats=True)       # the statistics come out of the conv's epilogue where it can
+                return ops.norm_apply(y, st, True, EPS, act=act, res=res, out=y)
             y = fn.conv(pc, x)
             st = ops.norm_stats(y.detach(), per_sample=True)
             if taped:
@@ -391,13 +394,11 @@ class BasicParallelFusionLayer(nn.Module):
                 and p2.cin % 32 == 0 and (p2.kh, p2.kw, p2.stride) == (3, 3, 1)):
             # inference: conv2 applies relu(norm1(.)) while it loads conv1's raw output - one full read + write of the
             # activation less per block (same coefficients, same arithmetic as ff_norm_apply: bit-identical results)
-            t1 = blk._p1(x)
-            st = ops.norm_stats(t1, per_sample=True)
+            t1, st = blk._p1(x, want_stats=True)
             sc, sh = ops.norm_coeffs(st, t1.shape[1] * t1.shape[2], EPS)
             if blk.downsample is not None:
                 x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
-            t2 = p2(t1, in_scale=sc, in_shift=sh, in_act=ACT_RELU)
-            st2 = ops.norm_stats(t2, per_sample=True)
+            t2, st2 = p2(t1, in_scale=sc, in_shift=sh, in_act=ACT_RELU, want_stats=True)
             return ops.norm_apply(t2, st2, True, EPS, act=ACT_RELU, res=x, out=t2)
         y = self._conv_norm(x, blk._p1, blk.norm1, ACT_RELU)
         if blk.downsample is not None:

@@ -254,6 +254,13 @@ extern "C" int ff_conv2d_splitk_hint(const FFConvParams* pp) {
     return cin > 0 ? ff::conv2d_splitk_hint(*pp, cin) : 0;
 }
 
+extern "C" int ff_conv2d_stats_parts(const FFConvParams* pp) {
+    if (!pp || pp->groups != 1 || pp->w_format != FF_W_F16X3 || !ff::aligned16(pp->y) || pp->y_ld % 4) return 0;
+    int cin = 0;
+    for (int s = 0; s < FF_MAX_SEG && pp->x_c[s]; ++s) cin += pp->x_c[s];
+    return cin > 0 ? ff::conv2d_stats_parts(*pp, cin) : 0;
+}
+
 extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     FF_REQUIRE(pp != nullptr, "ff_conv2d_fwd: null params");
     const FFConvParams& p = *pp;
@@ -295,6 +302,8 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     FF_REQUIRE(!p.res2 || (p.res && p.w_format != FF_W_F32 && p.KH == 1 && p.KW == 1 && p.groups == 1 && p.res_split > 0 &&
                            p.res_split < p.Cout && p.res2_ld >= p.Cout - p.res_split && !getenv("FF_WS_CONV")),
                "ff_conv2d_fwd: res2 needs res, a split weight format and a 1x1 kernel (0 < res_split < Cout)");
+    FF_REQUIRE(!p.stats_part || (ff::aligned16(p.stats_part) && ff_conv2d_stats_parts(pp) > 0),
+               "ff_conv2d_fwd: stats_part: this convolution cannot produce statistics (ff_conv2d_stats_parts returned 0) or the buffer is misaligned");
     FF_REQUIRE(p.ep_mode >= FF_EP_NONE && p.ep_mode <= FF_EP_GRU_BLEND, "ff_conv2d_fwd: bad ep_mode %d", p.ep_mode);
     if (p.ep_mode) {
         FF_REQUIRE(p.w_format == FF_W_F16X3 && p.groups == 1 && p.stride == 1 && cin % 32 == 0 && p.KH * p.KW >= 3 && !p.res2 && !p.in_scale &&

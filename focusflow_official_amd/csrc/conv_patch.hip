@@ -65,7 +65,11 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& h0, f16x4& h1) {   
 // the 16-byte k-groups of a term sit in the order 0, 2, 1, 3, and MFMA rows 4..11 read the even rows of a tile,
 // rows 0..3 / 12..15 the odd ones (a weight row's place in LDS, a pixel's column in the tile: PI16).
 // EPI (MF16 only): FFConvParams.ep_mode - a GRU step applied to the finished value (FF_EP_GRU_RH / FF_EP_GRU_BLEND)
-template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false, bool INORM = false, bool SPLITK = false, bool MF16 = false, int EPI = 0>   // WB = weight buffers in LDS
+// STATS: FFConvParams.stats_part - every lane also reduces the values it stores to {pivot, sum(v - pivot), sum((v - pivot)^2),
+// count} and writes them as one 16-byte entry [image][part][channel]; ff_norm_stats_finish adds the parts up in double.
+// The pivot (the lane's first value) keeps the fp32 sums of a nearly constant plane - the condition branch of frame 2 -
+// free of cancellation; the InstanceNorm statistics pass that re-read every convolution output is gone.
+template <int TERMS, int NITEM, int TM, int TN, int ABL, int WB, bool PIN = false, bool INORM = false, bool SPLITK = false, bool MF16 = false, int EPI = 0, bool STATS = false>   // WB = weight buffers in LDS
 __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
     constexpr int TH = 4 * TM, BN = 64 * TN, NW = 2 * TN;       // NW = 16-byte weight pieces per thread and tap
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -457,6 +461,7 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
         const float bias = p.bias ? p.bias[n] : 0.f;
         const float cs = p.ch_scale ? p.ch_scale[n] : 1.f;
         const float ct = p.ch_scale ? p.ch_shift[n] : 0.f;
+        float st_p = 0.f, st_s1 = 0.f, st_s2 = 0.f, st_n = 0.f;      // STATS: this lane's channel over its TM x 16 pixels
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             // Three passes per tile: values first, then ALL residual loads of the tile together (res may alias y as
@@ -488,6 +493,45 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
                 if (y >= H || x >= W) continue;
                 p.y[(((long long)bimg * H + y) * W + x) * p.y_ld + n] = vv[r];
             }
+            if constexpr (STATS) {
+                if (y0 + TH <= H && x0 + TW <= W) {      // block-uniform: every pixel of the tile is inside the image
+                    if (t == 0) st_p = vv[0];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = vv[r] - st_p;
+                        st_s1 += d;
+                        st_s2 = fmaf(d, d, st_s2);
+                    }
+                    st_n += 16.f;
+                } else {                                  // ragged tile: the pivot is the lane's first value inside the image
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + ((pi - (pi >> 4) * rot) & 15);
+                        if (y >= H || x >= W) continue;
+                        if (st_n == 0.f) st_p = vv[r];
+                        const float d = vv[r] - st_p;
+                        st_s1 += d;
+                        st_s2 = fmaf(d, d, st_s2);
+                        st_n += 1.f;
+                    }
+                }
+            }
+        }
+        if constexpr (STATS) {
+            // the upper half-wave holds the same channel over other pixels: fold it into the lower one, re-centred on the
+            // lower pivot (d is a difference of two outputs - small against the values when it matters):
+            //   sum(v - p) = s + n d,  sum((v - p)^2) = q + 2 d s + n d^2   for entries around p + d
+            const float p2 = __shfl_xor(st_p, 32), s2 = __shfl_xor(st_s1, 32), q2 = __shfl_xor(st_s2, 32), n2 = __shfl_xor(st_n, 32);
+            if (lh == 0) {
+                const float pv = st_n > 0.f ? st_p : p2, d = p2 - pv;
+                const float s1 = st_s1 + s2 + n2 * d;
+                const float q1 = st_s2 + q2 + 2.f * d * s2 + n2 * d * d;
+                // entry [image][part = (tile, wm)][channel]: 32 lanes write 512 contiguous bytes
+                const int part = (ty * a.tiles_x + tx) * 2 + wm;
+                const int nparts = a.tiles_y * a.tiles_x * 2;
+                *reinterpret_cast<f32x4*>(p.stats_part + (((long long)bimg * nparts + part) * p.Cout + n) * 4) = (f32x4){pv, s1, q1, st_n + n2};
+            }
         }
     }
 }
@@ -495,8 +539,8 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
 template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, WB>(a); }
 // one weight buffer: 35 KB of LDS, so four blocks fit a CU if the registers allow four waves per SIMD
-template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0, bool INORM = false, bool SPLITK = false, bool MF16 = false, int EPI = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN, INORM, SPLITK, MF16, EPI>(a); }
+template <int TERMS, int NITEM, int TM, int TN, int OCC, bool PIN = true, int ABL = 0, bool INORM = false, bool SPLITK = false, bool MF16 = false, int EPI = 0, bool STATS = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_patch_kernel_occ(const PArgs a) { conv_patch_body<TERMS, NITEM, TM, TN, ABL, 1, PIN, INORM, SPLITK, MF16, EPI, STATS>(a); }
 
 // sum of the K splits in a fixed order, then the epilogue of conv_patch_body (same operations in the same order)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const FFConvParams p, int splits, long long npix) {
@@ -523,6 +567,11 @@ int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
     // loop: per-layer times are equal within 1 % (12.70 vs 12.73 ms of convolutions per step) and the normalise-on-load
     // variant spills (+13 % on its layers).
     static const bool mf16 = getenv("FF_MFMA16") && atoi(getenv("FF_MFMA16")) == 1;
+    if (a.p.stats_part) {        // partial InstanceNorm statistics of the output from the epilogue (validated by the caller)
+        if (a.p.in_scale) conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, true, false, false, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+        else conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, false, false, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+        return ff::check_launch("ff_conv2d_fwd(patch, statistics)");
+    }
     if (a.p.ep_mode) {           // GRU step in the epilogue: the 16x16x32 variants carry it (four channels per lane: 16-byte operand loads)
         if (a.p.ep_mode == FF_EP_GRU_RH) conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, false, true, FF_EP_GRU_RH><<<(unsigned)blocks, 256, lds, s>>>(a);
         else conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, false, true, FF_EP_GRU_BLEND><<<(unsigned)blocks, 256, lds, s>>>(a);
@@ -640,6 +689,8 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     // split-K (FFConvParams.splitk, see conv2d_splitk_hint): the 4-row high-occupancy variant only
     if (!(occ && th == 4 && p.splitk > 1 && p.splitk_ws && !p.in_scale && !p.res2)) a.p.splitk = 0;
     a.nci_split = a.p.splitk > 1 ? (a.nci + a.p.splitk - 1) / a.p.splitk : a.nci;
+    if (p.stats_part && (!occ || a.p.splitk > 1 || p.ep_mode))
+        return ff::fail(FF_EINVAL, "ff_conv2d_fwd: stats_part: ask ff_conv2d_stats_parts first (this convolution cannot produce statistics)");
     if (p.ep_mode) {             // validated by ff_conv2d_fwd; the high-occupancy variants carry the GRU epilogues
         if (!occ || a.p.splitk > 1 || p.in_scale || p.Cout % 4) return ff::fail(FF_EINVAL, "ff_conv2d_fwd: ep_mode needs the f16x3 patch kernel's 8x16 / 4x16 tiles (got %dx%d kernel, Cin %d, Cout %d)", p.KH, p.KW, cin, p.Cout);
     }
@@ -654,6 +705,31 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     FF_PATCH_CASE(16, 1, 11) FF_PATCH_CASE(16, 1, 16)
 #undef FF_PATCH_CASE
     return 1;
+}
+
+// Entries per image and channel of FFConvParams.stats_part for this convolution (0: it cannot produce statistics - the
+// caller runs ff_norm_stats over the output instead).  Same eligibility and tile choice as conv2d_fwd_patch's
+// high-occupancy variants: 2 entries (one per wave row) per 8x16 / 4x16 tile.
+int conv2d_stats_parts(const FFConvParams& p, int cin) {
+    static const bool enabled = !getenv("FF_NO_PATCH_CONV") && !(getenv("FF_CONV_STATS") && atoi(getenv("FF_CONV_STATS")) == 0);
+    if (!enabled || p.w_format != FF_W_F16X3 || p.res2 || p.ep_mode || p.x_amax) return 0;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
+    if (p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1) return 0;
+    if (p.KH % 2 == 0 || p.KW % 2 == 0 || p.pad_h != p.KH / 2 || p.pad_w != p.KW / 2 || p.KH > 7 || p.KW > 7 || p.KH * p.KW < 3) return 0;
+    if (cin % 32) return 0;
+    for (int i = 0; i < FF_MAX_SEG; ++i)
+        if (p.x_c[i] % 32) return 0;
+    if (getenv("FF_PATCH_TH") || getenv("FF_PATCH_TN") || getenv("FF_PATCH_WB1") || getenv("FF_PATCH_ABLATE")) return 0;
+    long long max_bytes = (long long)p.Cout * ((p.KH * p.KW * cin + 31) / 32) * ROWB;
+    for (int i = 0; i < FF_MAX_SEG; ++i)
+        if (p.x_c[i]) max_bytes = std::max(max_bytes, (long long)p.B * p.H * p.W * p.x_ld[i] * 4);
+    if (max_bytes >= (1ll << 31)) return 0;
+    const int tiles_x = (p.W + TW - 1) / TW, n_tiles = (p.Cout + 63) / 64;
+    const int th = (long long)p.B * ((p.H + 7) / 8) * tiles_x * n_tiles < 512 ? 4 : 8;
+    const int npix = (th + p.KH - 1) * (TW + p.KW - 1), nitem = (npix * 8 + 255) / 256;
+    if (!((th == 8 && nitem <= 6) || (th == 4 && nitem <= 4))) return 0;
+    if (th == 4 && p.splitk > 1 && p.splitk_ws) return 0;
+    return ((p.H + th - 1) / th) * tiles_x * 2;
 }
 
 // How many K splits ff_conv2d_fwd would use for this convolution if given a workspace (0: none).  Same eligibility as

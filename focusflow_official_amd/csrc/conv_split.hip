@@ -442,12 +442,13 @@ __global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __res
 namespace ff {
 // called from ff_conv2d_fwd after argument validation
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s) {
-    int rc = p.ep_mode ? 1 : conv2d_fwd_ws(p, cin, s);   // stride-1 "same" convs: wave-specialised patch kernel (no GRU epilogues)
+    int rc = (p.ep_mode || p.stats_part) ? 1 : conv2d_fwd_ws(p, cin, s);   // stride-1 "same" convs: wave-specialised patch kernel (no epilogue extras)
     if (rc != 1) return rc;
     rc = conv2d_fwd_patch(p, cin, s);                // same shapes, single-role waves (small grids / FF_WS_CONV=0)
     if (rc != 1) return rc;
     if (p.in_scale) return fail(FF_EINVAL, "ff_conv2d_fwd: in_scale/in_shift: the patch kernel declined this shape");
     if (p.ep_mode) return fail(FF_EINVAL, "ff_conv2d_fwd: ep_mode: the patch kernel declined this shape");
+    if (p.stats_part) return fail(FF_EINVAL, "ff_conv2d_fwd: stats_part: the patch kernel declined this shape (ff_conv2d_stats_parts says which convolutions qualify)");
     KernArgs a;
     a.p = p;
     a.M = M;

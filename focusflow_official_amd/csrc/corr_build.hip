@@ -435,8 +435,10 @@ extern "C" int ff_corr_build(const void* f1_split, const void* f2_split, void* c
             if (e != hipSuccess) return ff::fail(FF_EHIP, "ff_corr_build: memset: %s", hipGetErrorString(e));
         }
     }
-    if (half) corr_build_kernel<true><<<(unsigned)nblk, 256, 2 * STAGE, s>>>(a);
-    else corr_build_kernel<false><<<(unsigned)nblk, 256, 2 * STAGE, s>>>(a);
+    hipEvent_t ev0, ev1;          // null unless ff_launch_timing_begin(FF_TIME_CORR_BUILD) is in effect
+    ff::launch_timing_events(FF_TIME_CORR_BUILD, &ev0, &ev1);
+    if (half) hipExtLaunchKernelGGL(corr_build_kernel<true>, dim3((unsigned)nblk), dim3(256), 2 * STAGE, s, ev0, ev1, 0, a);
+    else hipExtLaunchKernelGGL(corr_build_kernel<false>, dim3((unsigned)nblk), dim3(256), 2 * STAGE, s, ev0, ev1, 0, a);
     return ff::check_launch("ff_corr_build");
 }
 

@@ -401,7 +401,9 @@ int lookup_dma_fwd(const void* const* levels, int half, const float* coords, lon
     a.qdiv = (unsigned)(queries / waves);
     a.qrem = (unsigned)(queries % waves);
 #define FF_LAUNCH(H_, D_) FF_LAUNCH3(H_, D_, 0)
-#define FF_LAUNCH3(H_, D_, A_) lookup_dma_kernel<H_, D_, A_><<<blocks, 64, WAVE_LDS, s>>>(a)
+    hipEvent_t ev0, ev1;          // null unless ff_launch_timing_begin(FF_TIME_LOOKUP) is in effect
+    launch_timing_events(FF_TIME_LOOKUP, &ev0, &ev1);
+#define FF_LAUNCH3(H_, D_, A_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, D_, A_>), dim3(blocks), dim3(64), WAVE_LDS, s, ev0, ev1, 0, a)
     const char* abl_s = getenv("FF_LOOKUP_ABLATE3");
     const int abl = abl_s ? atoi(abl_s) : 0;
 #define FF_ABL(V_) if (abl == V_ && !half) { FF_LAUNCH3(false, false, V_); return check_launch("ff_corr_lookup_tiled_fwd (dma, ablated)"); }

@@ -1,6 +1,7 @@
 // Shared helpers for libfocusflow_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdio>
 #include "focusflow_hip.h"
@@ -21,6 +22,12 @@ inline int fail(int code, const char* fmt, ...) {
     do {                                                        \
         if (!(cond)) return ff::fail(FF_EINVAL, __VA_ARGS__);   \
     } while (0)
+
+// ff_launch_timing_begin / _end (api.hip): while a class of launches is being timed, its launch site asks for an event pair
+// and hands it to hipExtLaunchKernelGGL, which binds both events to the dispatch itself - their distance is the kernel's
+// execution time as the command processor stamps it (what rocprofv3 --kernel-trace reports), without the dispatch gaps
+// an event pair recorded around the launch adds.  Both stay null when timing is off: an ordinary launch.
+void launch_timing_events(int which, hipEvent_t* start, hipEvent_t* stop);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
@@ -54,6 +61,7 @@ int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int c
 int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hipStream_t s);          // conv_wgrad_patch.hip; 1 = not eligible
 int conv2d_fwd_small(const FFConvParams& p, int cin, hipStream_t s);         // conv_small.hip (Cout <= 2, 3x3); 1 = not eligible
 int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s);         // conv_patch.hip; 1 = not eligible
+int conv2d_stats_parts(const FFConvParams& p, int cin);                       // conv_patch.hip; entries per (image, channel), 0 = cannot
 int conv2d_splitk_hint(const FFConvParams& p, int cin);                       // conv_patch.hip; K splits worth using, 0 = none
 int conv2d_fwd_ws(const FFConvParams& p, int cin, hipStream_t s);            // conv_ws.hip (wave-specialised); 1 = not eligible
 // corr_lookup_dma.hip: the LDS-DMA lookup; 1 = not eligible (levels more than 4 GB apart)

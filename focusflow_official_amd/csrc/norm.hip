@@ -5,6 +5,7 @@
 //                   and merged with fp64 atomics into stats[s][c] = {sum, sumsq}.
 //   ff_norm_apply : y = act((x-mean)*rstd*gamma+beta), optional residual+relu.
 #include "ff_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -114,6 +115,38 @@ __global__ void norm_coeffs_kernel(const double* __restrict__ stats, int total, 
     shift[i] = bt - (float)mean * rstd * gm;
 }
 
+// Partial statistics left by a convolution's epilogue (FFConvParams.stats_part: {pivot p, s1 = sum(v - p), s2 = sum((v - p)^2),
+// count n} per entry) -> added into the {sum, sum of squares} table of ff_norm_stats, in double:
+//   sum v = n p + s1,   sum v^2 = s2 + 2 p s1 + n p^2.
+// One block per (image, 64 channels, slice of the parts): 4 sub-slices per channel merged through LDS, then one fp64 atomic
+// pair per channel and block (as norm_stats_kernel ends).
+__global__ __launch_bounds__(256) void norm_stats_finish_kernel(const float* __restrict__ parts, int nparts, int per_block, int C,
+                                                               double* __restrict__ stats) {
+    __shared__ double sh[2][4][64];
+    const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int lo = blockIdx.z * per_block, hi = min(nparts, lo + per_block);
+    double a1 = 0, a2 = 0;
+    if (c < C) {
+        const f32x4* e = reinterpret_cast<const f32x4*>(parts) + (long long)b * nparts * C + c;
+#pragma unroll 4
+        for (int i = lo + sl; i < hi; i += 4) {
+            const f32x4 v = e[(long long)i * C];
+            const double p = v[0], s1 = v[1], s2 = v[2], n = v[3];
+            a1 += n * p + s1;
+            a2 += s2 + 2.0 * p * s1 + n * p * p;
+        }
+    }
+    sh[0][sl][threadIdx.x & 63] = a1;
+    sh[1][sl][threadIdx.x & 63] = a2;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        const int l = threadIdx.x;
+        const long long i = (long long)b * C + c;
+        atomicAdd(stats + i * 2, (sh[0][0][l] + sh[0][1][l]) + (sh[0][2][l] + sh[0][3][l]));
+        atomicAdd(stats + i * 2 + 1, (sh[1][0][l] + sh[1][1][l]) + (sh[1][2][l] + sh[1][3][l]));
+    }
+}
+
 __global__ void bn_fold_kernel(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
                                float* sc, float* sh, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,6 +177,15 @@ extern "C" int ff_norm_stats(const float* x, int ld, int B, int HW, int C, int p
     dim3 grid((HW + SLAB - 1) / SLAB, B);
     norm_stats_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(x, ld, HW, C, per_sample, stats);
     return ff::check_launch("ff_norm_stats");
+}
+
+extern "C" int ff_norm_stats_finish(const float* parts, int B, int nparts, int C, double* stats, void* stream) {
+    FF_REQUIRE(parts && stats && B > 0 && nparts > 0 && C > 0, "ff_norm_stats_finish: bad arguments");
+    FF_REQUIRE(ff::aligned16(parts), "ff_norm_stats_finish: parts must be 16-byte aligned");
+    const int slices = std::max(1, std::min(64, nparts / 32));        // >= 8 entries per thread
+    const int per_block = (nparts + slices - 1) / slices;
+    norm_stats_finish_kernel<<<dim3(B, (C + 63) / 64, (nparts + per_block - 1) / per_block), 256, 0, (hipStream_t)stream>>>(parts, nparts, per_block, C, stats);
+    return ff::check_launch("ff_norm_stats_finish");
 }
 
 extern "C" int ff_norm_apply(const float* x, int ld, float* y, int y_ld, int B, int HW, int C, const double* stats,

@@ -94,6 +94,23 @@ def profile_notes(label):
     return list(_prof_notes.get(label, []))
 
 
+TIME_LOOKUP, TIME_CORR_BUILD = 1, 2          # include/focusflow_hip.h: FF_TIME_*
+
+
+def launch_timing_begin(*which: int):
+    """Kernel-timestamp timing of the library's lookup / corr-build launches (ff_launch_timing_begin): HIP events bound
+    to the dispatch itself, on whatever stream the launch goes to."""
+    for w in which:
+        _hip.call("ff_launch_timing_begin", w)
+
+
+def launch_timing_end(which: int):
+    """-> (launches, total_us, min_us, max_us) since launch_timing_begin; waits for the launches."""
+    n, tot, lo, hi = C.c_longlong(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    _hip.call("ff_launch_timing_end", which, C.byref(n), C.byref(tot), C.byref(lo), C.byref(hi))
+    return n.value, tot.value, lo.value, hi.value
+
+
 def _timed_call(label, name, *args, note=None):
     if _prof_on and label in _prof_events:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -147,8 +164,10 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
            ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0, dilation: int = 1,
            x_amax: Optional[Tensor] = None, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None,
            in_act: int = ACT_NONE, res2: Optional[Tensor] = None, res_split: int = 0,
-           ep_rh: Optional[Tensor] = None, ep_split: int = 0, ep_blend=None) -> Tensor:
-    """Convolution over the channel-concatenation of `xs` (see FFConvParams).  res2 / res_split: output channels
+           ep_rh: Optional[Tensor] = None, ep_split: int = 0, ep_blend=None, want_stats: bool = False):
+    """Convolution over the channel-concatenation of `xs` (see FFConvParams).  want_stats: -> (out, stats) with the
+    per-sample {sum, sum of squares} table of the output (what norm_stats(out, True) returns): from the convolution's own
+    epilogue where the kernel can (FFConvParams.stats_part), else from a norm_stats pass.  res2 / res_split: output channels
     >= res_split take their residual from `res2` (paired 1x1 fusion convs).  `wpack` is fp32
     [Cout][K] (w_fmt 0) or the split rows of pack_split (w_fmt 1/2).  x_amax: device word holding the bits of
     max|x| (act_bwd): the split formats then scale the input by a power of two so that gradients fit fp16."""
@@ -211,7 +230,17 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
             if nsplit > 1:
                 ws = torch.empty(nsplit * b * ho * wo * cout, dtype=torch.float32, device=x0.device)
                 p.splitk_ws, p.splitk = ws.data_ptr(), nsplit
+    nparts = _hip.load().ff_conv2d_stats_parts(C.byref(p)) if want_stats and CONV_STATS and not p.splitk else 0
+    if nparts:
+        parts = torch.empty(b * nparts * cout * 4, dtype=torch.float32, device=x0.device)
+        p.stats_part = parts.data_ptr()
+        _timed_call("conv", "ff_conv2d_fwd", C.byref(p), _stream(), note=(2.0 * b * ho * wo * cout * kh * kw * cin, w_fmt))
+        stats = _zero_stats(b, cout, x0.device)
+        _hip.call("ff_norm_stats_finish", _p(parts), b, nparts, cout, _p(stats), _stream())
+        return out, stats
     _timed_call("conv", "ff_conv2d_fwd", C.byref(p), _stream(), note=(2.0 * b * ho * wo * cout * kh * kw * cin, w_fmt))
+    if want_stats:
+        return out, norm_stats(out, per_sample=True)
     return out
 
 
@@ -383,6 +412,8 @@ def begin_forward(device):
 # ops.CHECK_RANGE = True) measures max|x| of every tensor a forward convolution reads (one extra read-only pass each, the
 # kernel the backward uses for its gradient scales) and the model raises at the end of the forward pass that overflowed.
 CHECK_RANGE = os.environ.get("FF_CHECK_RANGE", "0") == "1"
+# InstanceNorm statistics from the producing convolution's epilogue (FFConvParams.stats_part) instead of a pass over its output
+CONV_STATS = os.environ.get("FF_CONV_STATS", "1") != "0"
 X_LIMIT = 16376.0
 _range_word = None
 

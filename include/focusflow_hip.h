@@ -50,9 +50,22 @@ const char* ff_last_error(void);
  * passes: new trailing fields mean "feature off" when zero.
  *   2 (round 2): FFConvParams + res2, res2_ld, res_split, splitk_ws, splitk; ff_norm_bwd + dx_amax; ff_corr_lookup_bwd and
  *                ff_corr_pyramid_bwd (row-major) removed
- *   3 (round 3): FFConvParams + ep_mode, ep_split, ep_a, ep_a_ld, ep_b, ep_b_ld */
+ *   3 (round 3): FFConvParams + ep_mode, ep_split, ep_a, ep_a_ld, ep_b, ep_b_ld, stats_part; + ff_conv2d_stats_parts,
+ *                ff_norm_stats_finish, ff_launch_timing_begin / _end */
 #define FF_ABI_VERSION 3
 int ff_abi_version(void);
+
+/* Kernel-timestamp timing of one class of the library's launches (measurement only; bench.py's roofline uses it).
+ * Between _begin and _end every launch of the class is made through hipExtLaunchKernelGGL with a start/stop event pair
+ * bound to the dispatch, so the distance is the kernel's own execution time - what rocprofv3 --kernel-trace reports -
+ * on whatever stream the caller launches on.  _end waits for the launches, returns their count, summed / shortest /
+ * longest duration in microseconds (min_us / max_us may be NULL) and switches the timing off again.  Not for use
+ * while a stream is being captured into a hipGraph. */
+#define FF_TIME_LOOKUP 1        /* ff_corr_lookup_tiled_fwd's kernel */
+#define FF_TIME_CORR_BUILD 2    /* ff_corr_build's kernel            */
+#define FF_TIME_KINDS 2
+int ff_launch_timing_begin(int which);
+int ff_launch_timing_end(int which, long long* launches, double* total_us, double* min_us, double* max_us);
 
 /* ------------------------------------------------------------------------
  * Convolution (implicit GEMM on fp32 MFMA), replaces every nn.Conv2d call of
@@ -116,6 +129,11 @@ typedef struct FFConvParams {
                                        /* Same roundings as ff_gru_rh / ff_gru_blend.  Split-format stride-1 convolutions   */
                                        /* with Cin % 32 == 0 and a 3x3 / 1x5 / 5x1 kernel (the patch kernel); ep_a / ep_b    */
                                        /* NHWC, 16-byte aligned, ld % 4 == 0.                                               */
+    float* stats_part;                 /* NULL, or [B][parts][Cout][4] floats that receive partial statistics of the OUTPUT    */
+                                       /* ({pivot, sum(v - pivot), sum((v - pivot)^2), count} per entry; parts =                */
+                                       /* ff_conv2d_stats_parts(p) > 0): the convolution's epilogue replaces the ff_norm_stats  */
+                                       /* pass over its output (extractor.py:48-56: every conv of the encoder is followed by a  */
+                                       /* norm); ff_norm_stats_finish turns the parts into the {sum, sum of squares} table.    */
 } FFConvParams;
 #define FF_EP_NONE 0
 #define FF_EP_GRU_RH 1
@@ -136,6 +154,9 @@ int ff_pack_split_f16(const float* src_rows, void* dst, long long rows, int K, v
 /* Number of K splits ff_conv2d_fwd would put to use for this convolution (0: none - leave splitk_ws NULL).  A plain
  * return value, not a status.  Does not launch anything. */
 int ff_conv2d_splitk_hint(const FFConvParams* p);
+/* Entries per (image, channel) that ff_conv2d_fwd writes to FFConvParams.stats_part for this convolution; 0 = it cannot
+ * (run ff_norm_stats over the output).  A plain return value, not a status. */
+int ff_conv2d_stats_parts(const FFConvParams* p);
 
 /* ------------------------------------------------------------------------
  * Normalisation: nn.InstanceNorm2d (extractor.py:28-32, per-sample statistics,
@@ -152,6 +173,9 @@ int ff_conv2d_splitk_hint(const FFConvParams* p);
  * ---------------------------------------------------------------------- */
 int ff_norm_stats(const float* x, int ld, int B, int HW, int C, int per_sample,
                   double* stats, void* stream);
+/* stats[b][c] += {sum, sum of squares} (fp64; zero the table first, as for ff_norm_stats) from the partial entries a
+ * convolution left in FFConvParams.stats_part ([B][parts][C][4]); per-sample statistics (InstanceNorm). */
+int ff_norm_stats_finish(const float* parts, int B, int nparts, int C, double* stats, void* stream);
 int ff_norm_apply(const float* x, int ld, float* y, int y_ld, int B, int HW, int C,
                   const double* stats, int per_sample, float eps,
                   const float* gamma, const float* beta, int act,

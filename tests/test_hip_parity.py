@@ -541,6 +541,61 @@ def test_gru_steps_in_the_conv_epilogues_are_bit_identical(det_sd, monkeypatch):
     close(h_f.cpu(), h_u.cpu(), rtol=0, atol=2e-6, what="new state")
 
 
+def test_instance_norm_statistics_from_the_conv_epilogue(det_sd, monkeypatch):
+    """Inference takes the InstanceNorm statistics of a convolution's output from that convolution's own epilogue
+    (FFConvParams.stats_part -> ff_norm_stats_finish) instead of re-reading the output (extractor.py:48-56: every conv
+    of the encoder feeds a norm).  The fused numbers - fp32 partial sums around a per-lane pivot, added up in double -
+    must give the mean and variance of the double-precision pass over the same output, on whole and ragged tiles, on
+    8-row and 4-row tile grids, with normalise-on-load inputs, and on a plane that is constant up to noise six
+    orders of magnitude smaller (the case a one-pass sum of squares in fp32 gets wrong)."""
+    from focusflow_official_amd import ops as hops, cce
+    m = _model(det_sd)
+    enc = m.flow_net.fnet
+    blk = enc.layer1[0]
+    g = torch.Generator().manual_seed(11)
+    for (b, h, w) in [(2, 24, 40), (8, 64, 128), (1, 13, 21)]:
+        x = torch.randn(b, h, w, 64, generator=g).to(DEV)
+        with torch.no_grad():
+            y, st = blk._p1(x, want_stats=True)
+            ref = hops.norm_stats(y, per_sample=True)
+            n = h * w
+            mean, mean_r = st[..., 0] / n, ref[..., 0] / n
+            var, var_r = st[..., 1] / n - mean ** 2, ref[..., 1] / n - mean_r ** 2
+            close(mean.cpu(), mean_r.cpu(), rtol=1e-6, atol=1e-7, what=f"mean {b}x{h}x{w}")
+            close(var.cpu(), var_r.cpu(), rtol=2e-6, atol=1e-9, what=f"variance {b}x{h}x{w}")
+            # same statistics with the input normalised while loading
+            sc, sh = hops.norm_coeffs(ref, n, 1e-5)
+            y2, st2 = blk._p2(y, in_scale=sc, in_shift=sh, in_act=hops.ACT_RELU, want_stats=True)
+            ref2 = hops.norm_stats(y2, per_sample=True)
+            close((st2[..., 0] / n).cpu(), (ref2[..., 0] / n).cpu(), rtol=1e-6, atol=1e-7, what="mean, normalise-on-load")
+            close((st2[..., 1] / n - (st2[..., 0] / n) ** 2).cpu(), (ref2[..., 1] / n - (ref2[..., 0] / n) ** 2).cpu(), rtol=2e-6, atol=1e-9,
+                  what="variance, normalise-on-load")
+    # nearly constant plane: a large bias over tiny variation
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.mul_(1e-4)
+        conv.bias.fill_(100.0)
+    pc = cce.PackedConv([conv.to(DEV)])
+    x = torch.randn(2, 32, 48, 64, generator=g).to(DEV)
+    with torch.no_grad():
+        y, st = pc(x, want_stats=True)
+        yd = y.double()
+        var_true = yd.var(dim=(1, 2), unbiased=False)
+        n = 32 * 48
+        var = st[..., 1] / n - (st[..., 0] / n) ** 2
+        assert float(var_true.max()) < 1e-4 and float(yd.mean()) > 99
+        # E[x^2] - E[x]^2 in double from exact-enough partials: the cancellation costs ~1e4 * 2^-52 relative, nothing more
+        close(var.cpu(), var_true.cpu(), rtol=0, atol=2e-11, what="variance of a nearly constant plane")   # 2^-52 * mean^2
+    # end to end: on vs off
+    inp = [t.to(DEV) for t in orc.shifted_pair(2, 128, 192, seed=4)]
+    with torch.no_grad():
+        monkeypatch.setattr(hops, "CONV_STATS", False)
+        _, fu0 = m(*inp, raft_iters=4, test_mode=True)
+        monkeypatch.setattr(hops, "CONV_STATS", True)
+        _, fu1 = m(*inp, raft_iters=4, test_mode=True)
+    close(fu1.cpu(), fu0.cpu(), rtol=0, atol=2e-4, what="flow_up, statistics from the conv epilogue vs the statistics pass")
+
+
 def test_skip_unused_upsample_is_bit_identical(det_sd):
     """Opt-in inference shortcut: mask head + convex up-sampling for the last iteration only (the reference throws
     the other results away in test_mode, raft.py:226-236) must not change a single bit of either output."""

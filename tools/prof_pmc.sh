@@ -20,6 +20,7 @@ groups=(
 i=0
 for g in "${groups[@]}"; do
   i=$((i+1))
+  if [ -n "${PASSES:-}" ] && [[ " $PASSES " != *" $i "* ]]; then continue; fi     # PASSES="4 6 7": only these groups
   rocprofv3 --pmc $g --output-format csv -d "$out/pmc$i" -- python3 "$GRAFT_REPO_ROOT/$1" "${@:2}" > "$out/pmc$i.log" 2>&1 || echo "pass $i failed (see pmc$i.log)"
   f=$(find "$out/pmc$i" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$out/pmc${i}.csv" && rm -rf "$out/pmc$i"
