@@ -33,7 +33,8 @@ class PackedConv:
                  cin_slices: Optional[Sequence[Tuple[int, int]]] = None, use_bias: bool = True):
         """cin_slices: take only these input-channel ranges of the weights, in this order (a convolution is linear
         in its input channels: the GRU splits off the part that meets the loop-invariant context features);
-        use_bias=False leaves the bias to the other part.  Sliced groups are forward-only."""
+        use_bias=False leaves the bias to the other part (and its gradient: params() then
+        holds None in the bias position)."""
         self.convs = list(convs)
         c0 = self.convs[0]
         self.kh, self.kw = c0.kernel_size
@@ -52,6 +53,7 @@ class PackedConv:
         self.b = None
         self._dkey = None
         self.wd = None
+        self._w_raw = self._wd_raw = None
 
     def get(self):
         key = (ops.conv_precision(),) + tuple(
@@ -59,8 +61,10 @@ class PackedConv:
             for c in self.convs)
         if key != self._key:
             dev = self.convs[0].weight.device
-            self.w = torch.empty((self.cout, self.kh * self.kw * self.cin_pad), dtype=torch.float32, device=dev)
-            self.b = torch.zeros(self.cout, dtype=torch.float32, device=dev)   # bias=False convs (SA) keep zeros
+            if self._w_raw is None or self._w_raw.device != dev:     # re-packed every training step: the buffers stay
+                self._w_raw = torch.empty((self.cout, self.kh * self.kw * self.cin_pad), dtype=torch.float32, device=dev)
+                self.b = torch.zeros(self.cout, dtype=torch.float32, device=dev)   # bias=False convs (SA) keep zeros
+            self.w = self._w_raw
             off = 0
             for c in self.convs:
                 wt = c.weight.detach()
@@ -83,15 +87,19 @@ class PackedConv:
         """Weights of the input-gradient convolution: [cin_pad][KH][KW][cout_pad], flipped + transposed, in the
         active conv format (fp32 rows, or fp16-split rows: the dgrad then runs on the f16 matrix pipe with the
         gradient scaled by a power of two, see FFConvParams.x_amax).  Returns (rows, format)."""
-        assert self.cin_slices is None, "channel-sliced conv groups are forward-only"
         key = (ops.conv_precision(),) + tuple((c.weight._version, c.weight.data_ptr()) for c in self.convs)
         if key != self._dkey:
             cout_pad = (self.cout + 3) // 4 * 4
-            self.wd = torch.zeros((self.cin_pad, self.kh * self.kw * cout_pad), dtype=torch.float32,
-                                  device=self.convs[0].weight.device)
+            dev = self.convs[0].weight.device
+            if self._wd_raw is None or self._wd_raw.device != dev:   # zeroed once: the padding positions are never written
+                self._wd_raw = torch.zeros((self.cin_pad, self.kh * self.kw * cout_pad), dtype=torch.float32, device=dev)
+            self.wd = self._wd_raw
             off = 0
             for c in self.convs:
-                ops.pack_conv_weight_dgrad(c.weight.detach(), self.wd, cout_pad, off)
+                wt = c.weight.detach()
+                if self.cin_slices is not None:
+                    wt = torch.cat([wt[:, lo:hi] for lo, hi in self.cin_slices], 1).contiguous()
+                ops.pack_conv_weight_dgrad(wt, self.wd, cout_pad, off)
                 off += c.out_channels
             self.dfmt = ops.w_format()
             if self.dfmt != 0:
@@ -108,12 +116,20 @@ class PackedConv:
 
     def params(self):
         """Parameter tensors in the order ConvFn receives (and returns gradients for) them."""
-        return [t for cv in self.convs for t in (cv.weight, cv.bias)]
+        return [t for cv in self.convs for t in (cv.weight, cv.bias if self.use_bias else None)]
 
     def unpack_wgrad(self, dwp, j, off):
-        """Packed weight gradient rows [off, off + Cout_j) -> gradient of convs[j].weight."""
+        """Packed weight gradient rows [off, off + Cout_j) -> gradient of convs[j].weight (zero outside cin_slices)."""
         cv = self.convs[j]
-        return ops.unpack_conv_wgrad(dwp, cv.out_channels, self.cin, self.kh, self.kw, self.cin_pad, off)
+        part = ops.unpack_conv_wgrad(dwp, cv.out_channels, self.cin, self.kh, self.kw, self.cin_pad, off)
+        if self.cin_slices is None:
+            return part
+        full = torch.zeros_like(cv.weight)
+        o = 0
+        for lo, hi in self.cin_slices:
+            full[:, lo:hi] = part[:, o:o + hi - lo]
+            o += hi - lo
+        return full
 
 
 def train_streams() -> bool:
@@ -361,11 +377,12 @@ class BasicParallelFusionLayer(nn.Module):
             if not taped:
                 y, st = pc(x, want_stats=True)       # the statistics come out of the conv's epilogue where it can
                 return ops.norm_apply(y, st, True, EPS, act=act, res=res, out=y)
-            y = fn.conv(pc, x)
-            st = ops.norm_stats(y.detach(), per_sample=True)
-            if taped:
-                return fn.NormFn.apply(y, None, None, res, True, False, EPS, relu, st)
-            return ops.norm_apply(y, st, True, EPS, act=act, res=res, out=y)
+            if ops.CONV_STATS_TRAIN:
+                y, st = fn.conv(pc, x, want_stats=True)
+            else:
+                y = fn.conv(pc, x)
+                st = ops.norm_stats(y.detach(), per_sample=True)
+            return fn.NormFn.apply(y, None, None, res, True, False, EPS, relu, st)
         if self.norm_fn == "batch":
             if norm.training:
                 y = fn.conv(pc, x)

@@ -39,9 +39,12 @@ class GraphScope:
     see exactly one gradient per parameter, also when the loss reaches only some of the applications, and a second
     backward over a retained graph starts from an empty buffer again."""
 
+    _arena_hint = 0      # bytes of zeroed scratch the last pass asked for (weight-gradient buffers, norm-backward sums)
+
     def __init__(self, device=None):
         self.acc, self.gates = {}, {}
         self._amax_pool, self._amax_used, self._amax_ready = None, 0, None
+        self._arena, self._arena_used, self._arena_req = None, 0, 0
         # data_ptr of a gradient tensor -> (word with the bits of its max|.|, shape, weak reference to the tensor): left by
         # the producer of the gradient (NormFn.backward), consumed - and removed - by the ConvFn.backward it flows into.
         # An entry counts only while its tensor is ALIVE at that address: a gradient nobody consumed (the norm of a frozen
@@ -54,6 +57,9 @@ class GraphScope:
         """A fresh pool of zeroed max|.| words.  Backward nodes run on several streams (encoder / branch streams are
         replayed by autograd): every stream other than the filling one waits for the fill before its first atomicMax."""
         self._amax_pool, self._amax_used = torch.zeros(4096, dtype=torch.int32, device=device), 0
+        if self._arena is None and GraphScope._arena_hint:
+            # ONE fill for the ~260 zeroed buffers a backward pass accumulates into, sized by what the previous pass used
+            self._arena = torch.zeros(GraphScope._arena_hint, dtype=torch.uint8, device=device)
         self._amax_ready = torch.cuda.Event()
         self._amax_ready.record(torch.cuda.current_stream(device))
         self._amax_fill_stream = torch.cuda.current_stream(device)
@@ -67,6 +73,25 @@ class GraphScope:
             self._amax_pool.record_stream(cur)
         self._amax_used += 1
         return self._amax_pool[self._amax_used - 1:self._amax_used]
+
+    def zeros(self, shape, dtype, device):
+        """A zeroed buffer for a backward kernel to accumulate into: carved from the pass's arena (filled once, when the
+        pass opened) while it lasts, else a fresh torch.zeros."""
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        off = (self._arena_used + 255) // 256 * 256
+        self._arena_req = (self._arena_req + 255) // 256 * 256 + nbytes
+        GraphScope._arena_hint = max(GraphScope._arena_hint, self._arena_req + 256)
+        if self._arena is None or self._arena.device != torch.device(device) or off + nbytes > self._arena.numel():
+            return torch.zeros(shape, dtype=dtype, device=device)
+        cur = torch.cuda.current_stream(device)
+        if cur != self._amax_fill_stream:
+            cur.wait_event(self._amax_ready)
+            self._arena.record_stream(cur)
+        self._arena_used = off + nbytes
+        return self._arena[off:off + nbytes].view(dtype).view(shape)
 
     def put_hint(self, dx, word):
         self.amax_hint[dx.data_ptr()] = (word, tuple(dx.shape), weakref.ref(dx))
@@ -110,7 +135,7 @@ class ParamGate(torch.autograd.Function):
             co = cv.out_channels
             grads.append(pc.unpack_wgrad(acc[0], j, off) if acc is not None and ctx.needs_input_grad[k] else None)
             k += 1
-            if cv.bias is not None:
+            if cv.bias is not None and pc.use_bias:
                 grads.append(acc[1][off:off + co].clone() if acc is not None and ctx.needs_input_grad[k] else None)
                 k += 1
             off += co
@@ -133,17 +158,18 @@ def end_graph():
     _scope = None
 
 
-NFIX = 8   # non-tensor arguments of ConvFn.forward
+NFIX = 9   # non-tensor arguments of ConvFn.forward
 
 
 class ConvFn(torch.autograd.Function):
-    """y = act(conv(cat(xs)) + bias) * ... (+ res).  tensors = xs..., [res], (w_i, b_i)..."""
+    """y = act(conv(cat(xs)) + bias) * out_scale, or with a residual y = act(conv(cat(xs)) + bias + res) (the activation
+    then follows the sum: the GRU gates over a pre-computed context share).  tensors = xs..., [res], (w_i, b_i)..."""
 
     @staticmethod
-    def forward(ctx, pc, act, out_scale, nseg, has_res, pad_out, fill_tail, scope, *tensors):
+    def forward(ctx, pc, act, out_scale, nseg, has_res, pad_out, fill_tail, scope, stats_out, *tensors):
         xs = list(tensors[:nseg])
         res = tensors[nseg] if has_res else None
-        assert not (has_res and act != ACT_NONE), "residual + activation is only fused on the inference path"
+        assert not (has_res and act != ACT_NONE and out_scale != 1.0), "residual + activation + out_scale: no such layer"
         w, b = pc.get()
         out = None
         if pad_out:  # allocate the channel-padded tensor; the caller owns channels >= Cout (filled by fill_tail)
@@ -152,8 +178,12 @@ class ConvFn(torch.autograd.Function):
             wo = (wd + 2 * pc.pad[1] - pc.kw) // pc.stride + 1
             full = ops.empty_nhwc(bsz, ho, wo, (pc.cout + 3) // 4 * 4, xs[0])
             out = full[..., :pc.cout]
-        y = ops.conv2d(xs, w, b, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, act=act, out=out, res=res,
-                       out_scale=out_scale, w_fmt=pc.fmt, dilation=pc.dil)
+        y = ops.conv2d(xs, w, b, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, act=ACT_NONE if has_res else act, out=out, res=res,
+                       act_res=act if has_res else ACT_NONE, out_scale=out_scale, w_fmt=pc.fmt, dilation=pc.dil,
+                       want_stats=stats_out is not None)
+        if stats_out is not None:      # per-sample {sum, sum of squares} of y for the InstanceNorm that follows (a constant
+            y, st = y                  # of the graph: NormFn's backward differentiates through the statistics itself)
+            stats_out.append(st)
         if pad_out:
             if fill_tail is not None:
                 fill_tail(full)
@@ -201,7 +231,7 @@ class ConvFn(torch.autograd.Function):
                 off += x.shape[3]
         grads += dxs
         if ctx.has_res:
-            grads.append(dy)                                           # y = conv + res
+            grads.append(dy if act == ACT_NONE else g[..., :pc.cout])  # y = act(conv + res): the pre-activation gradient
         # parameter gradients
         base = NFIX + nseg + (1 if ctx.has_res else 0)
         need_w = any(ctx.needs_input_grad[base:])
@@ -210,7 +240,7 @@ class ConvFn(torch.autograd.Function):
             acc = scope.acc.get(pc)
             if acc is None:
                 kdim = pc.kh * pc.kw * sum(x.shape[3] for x in xs)
-                z = torch.zeros(pc.cout * kdim + pc.cout, dtype=torch.float32, device=g.device)
+                z = scope.zeros((pc.cout * kdim + pc.cout,), torch.float32, g.device)
                 acc = scope.acc[pc] = (z[:pc.cout * kdim].view(pc.cout, kdim), z[pc.cout * kdim:])
             ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=amax, want_db=True, dw=acc[0], db=acc[1],
                              dilation=pc.dil)
@@ -247,7 +277,8 @@ class NormFn(torch.autograd.Function):
         x, gamma, beta, y, stats = ctx.saved_tensors
         scope = ctx.scope
         word = scope.amax_word(x.device) if (scope is not None and _AMAX_HINT) else None
-        dx, dres, bst = ops.norm_bwd(x, _dense(dy), y, stats, per_sample, fixed, eps, gamma, beta, relu, has_res, amax=word)
+        bst = scope.zeros((x.shape[0] if per_sample else 1, x.shape[3], 2), torch.float64, x.device) if scope is not None else None
+        dx, dres, bst = ops.norm_bwd(x, _dense(dy), y, stats, per_sample, fixed, eps, gamma, beta, relu, has_res, amax=word, bstats=bst)
         if word is not None:
             scope.put_hint(dx, word)
         dgamma = dbeta = None
@@ -420,8 +451,9 @@ def recording(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail=None):
-    """Convolution through a PackedConv group.  pad_out: return the channel-padded tensor."""
+def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail=None, want_stats=False):
+    """Convolution through a PackedConv group.  pad_out: return the channel-padded tensor.  want_stats: -> (y, stats),
+    the per-sample {sum, sum of squares} table of y (ops.conv2d: from the convolution's epilogue where it can)."""
     if not isinstance(xs, (list, tuple)):
         xs = [xs]
     params = pc.params()
@@ -430,7 +462,9 @@ def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail
         if _scope is not None and ops.w_format() and recording(*params):
             scope, params = _scope, _scope.gated(pc, params)
         args = list(xs) + ([res] if res is not None else []) + params
-        return ConvFn.apply(pc, act, out_scale, len(xs), res is not None, pad_out, fill_tail, scope, *args)
+        holder = [] if want_stats else None
+        y = ConvFn.apply(pc, act, out_scale, len(xs), res is not None, pad_out, fill_tail, scope, holder, *args)
+        return (y, holder[0]) if want_stats else y
     if pad_out:
         b, h, w, _ = xs[0].shape
         ho = (h + 2 * pc.pad[0] - pc.kh) // pc.stride + 1
@@ -440,7 +474,7 @@ def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail
         if fill_tail is not None:
             fill_tail(full)
         return full
-    return pc(xs, act=act, res=res, out_scale=out_scale)
+    return pc(xs, act=act, res=res, out_scale=out_scale, want_stats=want_stats)
 
 
 def chan_stats(x):

@@ -414,6 +414,9 @@ def begin_forward(device):
 CHECK_RANGE = os.environ.get("FF_CHECK_RANGE", "0") == "1"
 # InstanceNorm statistics from the producing convolution's epilogue (FFConvParams.stats_part) instead of a pass over its output
 CONV_STATS = os.environ.get("FF_CONV_STATS", "1") != "0"
+# ... and in recorded (training) passes: off - at the 46 x 62 planes of the training crop most tiles are ragged (the slow
+# per-pixel branch of the epilogue) and the statistics pass it replaces is short: 70.3 vs 69.6 ms per step (A/B, round 3)
+CONV_STATS_TRAIN = os.environ.get("FF_CONV_STATS_TRAIN", "0") == "1"
 X_LIMIT = 16376.0
 _range_word = None
 
@@ -759,10 +762,14 @@ def act_bwd_is_alias(dy: Tensor, act: int, scale: float, c: int) -> bool:
     return act == ACT_NONE and scale == 1.0 and dy.shape[3] == c == (c + 3) // 4 * 4 and _ld(dy) == c and dy.data_ptr() % 16 == 0
 
 
-def norm_bwd(x, dy, y, fstats, per_sample, fixed_stats, eps, gamma, beta, relu, want_dres, amax: Optional[Tensor] = None):
-    """amax: a zeroed int32 word that receives the bits of max|dx| (saves the consumer conv's measuring pass)."""
+def norm_bwd(x, dy, y, fstats, per_sample, fixed_stats, eps, gamma, beta, relu, want_dres, amax: Optional[Tensor] = None,
+             bstats: Optional[Tensor] = None):
+    """amax: a zeroed int32 word that receives the bits of max|dx| (saves the consumer conv's measuring pass);
+    bstats: a zeroed fp64 (S, C, 2) buffer for the two backward sums (allocated here when omitted)."""
     b, h, w, c = x.shape
-    bstats = torch.zeros((b if per_sample else 1, c, 2), dtype=torch.float64, device=x.device)
+    if bstats is None:
+        bstats = torch.zeros((b if per_sample else 1, c, 2), dtype=torch.float64, device=x.device)
+    assert bstats.shape == (b if per_sample else 1, c, 2) and bstats.dtype == torch.float64
     dx = empty_nhwc(b, h, w, c, x)
     dres = empty_nhwc(b, h, w, c, x) if want_dres else None
     _hip.call("ff_norm_bwd", _p(x), _ld(x), _p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(fstats),

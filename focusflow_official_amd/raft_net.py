@@ -125,7 +125,7 @@ class RAFT(nn.Module):
             ops.act_copy(cnet[..., 128:], inp, ACT_RELU)
         coords1 = ops.coords_init(b, h8, w8, cnet, flow_init)      # never differentiated (raft.py:216)
         # the context features' share of the GRU gate convolutions does not change over the iterations
-        gru_pre = None if (taped or torch.is_grad_enabled() or not _GRU_CTX_ONCE) else self.update_block.gru.prepare(inp)
+        gru_pre = self.update_block.gru.prepare(inp) if _GRU_CTX_ONCE and (taped or not torch.is_grad_enabled()) else None
         if (_UPDATE_SPLIT > 1 and test_mode and not taped and not torch.is_grad_enabled() and b % _UPDATE_SPLIT == 0
                 and not ops.SINGLE_STREAM and not torch.cuda.is_current_stream_capturing()):
             # Opt-in (FF_UPDATE_SPLIT=2): the update loop of n batch slices on n streams, the iterations issued alternately.

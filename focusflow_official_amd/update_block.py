@@ -61,14 +61,23 @@ class SepConvGRU(nn.Module):
         self._q_ctx = [PackedConv(g.convs, cin_slices=ctx, use_bias=False) for g in self._q]
 
     def prepare(self, inp):
-        """Inference: the context features' contribution to z|r and q of both passes, [(zr_pre, q_pre)] x 2."""
+        """The context features' contribution to z|r and q of both passes, [(zr_pre, q_pre)] x 2.  Recorded passes too:
+        autograd then sums the twelve pre-activation gradients that reach each share and runs the share's weight and
+        input gradient ONCE (sum_t inp (x) g_t = inp (x) sum_t g_t)."""
         assert inp.shape[3] == 128
-        return [(zc(inp), qc(inp)) for zc, qc in zip(self._zr_ctx, self._q_ctx)]
+        return [(fn.conv(zc, inp), fn.conv(qc, inp)) for zc, qc in zip(self._zr_ctx, self._q_ctx)]
 
     def run(self, h, xs, pre=None):
         """h: (B,H,W,128); xs: list of NHWC segments forming x.  update.py:45-60.  pre: prepare(xs[0]) - then
         xs[0] itself is not read again."""
         c = self.hidden_dim
+        if pre is not None and fn.recording(h, *xs, *[t for p in pre for t in p], *self.parameters()):
+            for zr_conv, q_conv, (zr_pre, q_pre) in zip(self._zr_hm, self._q_hm, pre):
+                zr = fn.conv(zr_conv, [h] + xs[1:], act=ACT_SIGMOID, res=zr_pre)
+                rh = fn.GruRhFn.apply(zr[..., c:], h)
+                q = fn.conv(q_conv, [rh] + xs[1:], act=ACT_TANH, res=q_pre)
+                h = fn.GruBlendFn.apply(zr[..., :c], q, h)
+            return h
         if pre is not None:
             fused = _GRU_EPILOGUE and ops.w_format() == _hip.W_F16X3
             for zr_conv, q_conv, (zr_pre, q_pre) in zip(self._zr_hm, self._q_hm, pre):
