@@ -135,7 +135,7 @@ class ParamGate(torch.autograd.Function):
             co = cv.out_channels
             grads.append(pc.unpack_wgrad(acc[0], j, off) if acc is not None and ctx.needs_input_grad[k] else None)
             k += 1
-            if cv.bias is not None and pc.use_bias:
+            if cv.bias is not None and getattr(pc, "use_bias", True):
                 grads.append(acc[1][off:off + co].clone() if acc is not None and ctx.needs_input_grad[k] else None)
                 k += 1
             off += co
