@@ -73,15 +73,16 @@ def log(msg):
 def pmc_traffic(queries, pyramid):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r03_lookup_traffic[_fp16].json:
     TCC_EA0_RDREQ x 128 B + WRITE_SIZE), scaled per query, and where the number comes from; (None, reason) if the
-    profile is absent.  PMC passes cannot run inside the timed process, so this is the same kernel on the same shape
-    measured by tools/lookup_lab.cpp under tools/prof_pmc_bin.sh - NOT a counter read in this run."""
+    profile is absent.  PMC passes cannot run inside the timed process: the fp32 profile holds the lookup launches of this
+    very command under rocprofv3 --pmc (tools/prof_pmc.sh ... bench.py), the fp16 one the same kernel on the same shape in
+    tools/lookup_lab.cpp (tools/prof_pmc_bin.sh) - NOT a counter read in this run."""
     name = "r03_lookup_traffic.json" if pyramid == "fp32" else "r03_lookup_traffic_fp16.json"
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
         return (int(d["traffic_bytes_per_launch"] / d["queries_per_launch"] * queries),
-                f"profiles/{name}: rocprofv3 --pmc passes over tools/lookup_lab.cpp (same kernel, {d['queries_per_launch']} queries per "
-                f"launch), scaled per query; not measured in this run")
+                f"profiles/{name}: separate rocprofv3 --pmc passes ({d.get('workload', 'same kernel')}; {d['queries_per_launch']} queries "
+                f"per launch), scaled per query; not measured in this run")
     except (OSError, KeyError, ValueError):
         return None, f"profiles/{name} missing"
 
@@ -320,7 +321,7 @@ def parity_and_reduced_precision(args, device, checker):
 
 def config4_measurements(device):
     """BASELINE configs[4]: FF-RAFT 540x960 (padded to 544x960), 32 iterations, fp16 correlation pyramid; 1 and 4 pairs."""
-    from focusflow_official_amd import FF_RAFT_FUSION
+    from focusflow_official_amd import FF_RAFT_FUSION, ops
     out = {}
     try:
         torch.manual_seed(1234)
@@ -333,19 +334,58 @@ def config4_measurements(device):
                     o = m(*batch, raft_iters=32, test_mode=True)
                 torch.cuda.synchronize()
                 n = 5
+                ops.launch_timing_begin(ops.TIME_LOOKUP)
                 t0 = time.perf_counter()
                 for _ in range(n):
                     o = m(*batch, raft_iters=32, test_mode=True)
                 torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
+            lk = ops.launch_timing_end(ops.TIME_LOOKUP)
+            q = b * 68 * 120
+            us = lk[1] / max(1, lk[0])
             out[f"pairs_{b}"] = {"value": round(b / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n, "warmup": 2,
-                                 "finite": bool(torch.isfinite(o[1]).all())}
+                                 "finite": bool(torch.isfinite(o[1]).all()),
+                                 "lookup": {"queries_per_launch": q, "launches": lk[0], "avg_launch_us": round(us, 2),
+                                            "frac_of_hbm_peak": round(q * LOOKUP_BYTES_PER_QUERY["fp16"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None}}
             del batch
         out["workload"] = "BASELINE configs[4]: FF-RAFT forward 544x960 (540 padded), iters=32, fp16 correlation pyramid, SiLK-free ORB-like mask"
     except Exception as e:          # noqa: BLE001
         out["error"] = f"{type(e).__name__}: {e}"
     torch.cuda.empty_cache()
     return out
+
+
+def batch16_measurement(args, device):
+    """The headline workload at 16 pairs per GPU instead of the 8 that BASELINE configs[1] names: what the per-launch ramps of
+    the update loop cost at batch 8 (every kernel of the loop is a 5-100 us launch at 1/8 resolution)."""
+    from focusflow_official_amd import FF_RAFT_FUSION, ops
+    try:
+        torch.manual_seed(1234)
+        m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
+        batch = synthetic_batch(16, args.height, args.width, 99, device)
+        with torch.no_grad():
+            for _ in range(2):
+                o = m(*batch, raft_iters=args.iters, test_mode=True)
+            torch.cuda.synchronize()
+            n = 5
+            ops.launch_timing_begin(ops.TIME_LOOKUP)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                o = m(*batch, raft_iters=args.iters, test_mode=True)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        lk = ops.launch_timing_end(ops.TIME_LOOKUP)
+        q = 16 * (args.height // 8) * (args.width // 8)
+        us = lk[1] / max(1, lk[0])
+        res = {"value": round(16 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n, "warmup": 2,
+               "finite": bool(torch.isfinite(o[1]).all()),
+               "lookup": {"queries_per_launch": q, "launches": lk[0], "avg_launch_us": round(us, 2),
+                          "frac_of_hbm_peak": round(q * LOOKUP_BYTES_PER_QUERY["fp32"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None},
+               "workload": f"FF-RAFT forward {args.height}x{args.width}, iters={args.iters}, fp32 pyramid, 16 pairs per step (not the headline batch)"}
+    except Exception as e:          # noqa: BLE001
+        res = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    return res
 
 
 def secondary_measurements(args, device):
@@ -406,6 +446,7 @@ def secondary_measurements(args, device):
         out["ff_pwc_forward"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
     out["config4_544x960_it32_fp16_pyramid"] = config4_measurements(device)
+    out["headline_shape_16_pairs"] = batch16_measurement(args, device)
     return out
 
 

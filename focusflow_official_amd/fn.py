@@ -57,7 +57,7 @@ class GraphScope:
         """A fresh pool of zeroed max|.| words.  Backward nodes run on several streams (encoder / branch streams are
         replayed by autograd): every stream other than the filling one waits for the fill before its first atomicMax."""
         self._amax_pool, self._amax_used = torch.zeros(4096, dtype=torch.int32, device=device), 0
-        if self._arena is None and GraphScope._arena_hint:
+        if self._arena is None and GraphScope._arena_hint and _ZERO_ARENA:
             # ONE fill for the ~260 zeroed buffers a backward pass accumulates into, sized by what the previous pass used
             self._arena = torch.zeros(GraphScope._arena_hint, dtype=torch.uint8, device=device)
         self._amax_ready = torch.cuda.Event()
@@ -143,6 +143,7 @@ class ParamGate(torch.autograd.Function):
 
 
 _scope: Optional[GraphScope] = None
+_ZERO_ARENA = os.environ.get("FF_ZERO_ARENA", "1") != "0"    # A/B switch: one zero fill per pass for the backward's accumulation buffers
 _AMAX_HINT = os.environ.get("FF_AMAX_HINT", "1") != "0"      # A/B switch: the norm backward measures max|dx| for the conv it feeds
 
 

@@ -46,6 +46,8 @@ for key, c in calls.items():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
+    if isinstance(out, tuple):      # want_stats: (output, statistics)
+        out = out[0]
     cin = sum(x.shape[3] for x in xs)
     npx = out.shape[0] * out.shape[1] * out.shape[2]
     fl = 2.0 * npx * cout * cin * kh * kw
