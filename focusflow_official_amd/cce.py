@@ -28,6 +28,10 @@ class PackedConv:
     Packed rows are [Cout][KH][KW][cin_pad]; re-packed by ff_pack_conv_weight
     whenever a source parameter changes (version counter) or moves.
     """
+    # defaults for subclasses that build their own state (pwcnet._TrainPacked)
+    cin_slices = None
+    use_bias = True
+    _w_raw = _wd_raw = None
 
     def __init__(self, convs: Sequence[nn.Conv2d], cin_pad: Optional[int] = None,
                  cin_slices: Optional[Sequence[Tuple[int, int]]] = None, use_bias: bool = True):

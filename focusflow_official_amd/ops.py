@@ -220,7 +220,7 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
         for x in xs:
             _range_probe(x)
     klen = cin * kh * kw
-    if w_fmt and b * ho * wo <= 16384 and klen > 1152:       # small plane, long reduction: ask the library whether K splits pay
+    if w_fmt and not p.ep_mode and b * ho * wo <= 16384 and klen > 1152:       # small plane, long reduction: ask the library whether K splits pay
         # reductions of 36-72 tap steps are split only when no host time is at stake: while a hipGraph is being captured
         short = klen <= 2304
         if not short or torch.cuda.is_current_stream_capturing():
