@@ -37,7 +37,8 @@ struct BuildArgs {
     int ntx[4], h[4], w[4];
     int Q, B, npx, npy, mtiles;
     float scale;            // 1/sqrt(C) / (WSPLIT * WSPLIT)
-    int ablate;             // timing experiments only (FF_CORR_BUILD_ABLATE): 1 = no epilogue, 2 = operands loaded once
+    int ablate;             // timing experiments only (FF_CORR_BUILD_ABLATE, bits): 1 no epilogue, 2 operands loaded once, 4 no level-0 stores,
+                            // 8 no stores of levels 1-3, 16 no main loop (epilogue alone)
 };
 
 constexpr int STAGE = 32768;     // J tile 16 KB | I tile 16 KB
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     issue(0, 0);
-    for (int c = 0; c < NCHUNK; ++c) {
+    for (int c = 0; c < ((a.ablate & 16) ? 1 : NCHUNK); ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // chunk c landed for every wave; everybody is done with the other stage
         if (c + 1 < NCHUNK && !(a.ablate & 2)) issue(c + 1, (c + 1) & 1);
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
             const int p = it * 64 + lane, ql = p >> 4, slot = p & 15;      // 16 slots of 16 B per query: 2 tiles
             const f32x4 d = *reinterpret_cast<const f32x4*>(wreg + ql * 256 + ((slot ^ (ql & 7)) * 16));
             const int q = qbase + ql;
-            if (q < a.Q) {
+            if (q < a.Q && !(a.ablate & 4)) {
                 char* dst = a.lvl[0] + (plane0 + q) * a.plane_bytes[0] + (size_t)((py * a.ntx[0] + 2 * px + (slot >> 3)) * 128 + (slot & 7) * 16);
                 *reinterpret_cast<f32x4*>(dst) = d;
             }
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
             const int p = it * 64 + lane, ql = p >> 5, slot = p & 31;      // 32 slots per query: 4 tiles
             const f32x4 d = *reinterpret_cast<const f32x4*>(wreg + ql * 512 + ((slot ^ (ql & 7)) * 16));
             const int q = qbase + ql, t = slot >> 3;
-            if (q < a.Q) {
+            if (q < a.Q && !(a.ablate & 4)) {
                 char* dst = a.lvl[0] + (plane0 + q) * a.plane_bytes[0] +
                             (size_t)(((2 * py + (t >> 1)) * a.ntx[0] + 2 * px + (t & 1)) * 128 + (slot & 7) * 16);
                 *reinterpret_cast<f32x4*>(dst) = d;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (a.ablate & 8) return;
     if (HALF) {
         // level 1: 64 B per query = 4 pieces of 16 B (rows (4py & 7) + 0..3 of the 8 x 8 tile)
 #pragma unroll
