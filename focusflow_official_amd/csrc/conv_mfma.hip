@@ -258,7 +258,9 @@ extern "C" int ff_conv2d_stats_parts(const FFConvParams* pp) {
     if (!pp || pp->groups != 1 || pp->w_format != FF_W_F16X3 || !ff::aligned16(pp->y) || pp->y_ld % 4) return 0;
     int cin = 0;
     for (int s = 0; s < FF_MAX_SEG && pp->x_c[s]; ++s) cin += pp->x_c[s];
-    return cin > 0 ? ff::conv2d_stats_parts(*pp, cin) : 0;
+    if (cin <= 0) return 0;
+    const int stem = ff::conv2d_stem_stats_parts(*pp, cin);
+    return stem ? stem : ff::conv2d_stats_parts(*pp, cin);
 }
 
 extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {

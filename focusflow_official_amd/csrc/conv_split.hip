@@ -442,7 +442,9 @@ __global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __res
 namespace ff {
 // called from ff_conv2d_fwd after argument validation
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s) {
-    int rc = (p.ep_mode || p.stats_part) ? 1 : conv2d_fwd_ws(p, cin, s);   // stride-1 "same" convs: wave-specialised patch kernel (no epilogue extras)
+    int rc = conv2d_fwd_stem(p, cin, s);              // the encoders' 7x7 stride-2 stems over NHWC4 (conv_stem.hip)
+    if (rc != 1) return rc;
+    rc = (p.ep_mode || p.stats_part) ? 1 : conv2d_fwd_ws(p, cin, s);   // stride-1 "same" convs: wave-specialised patch kernel (no epilogue extras)
     if (rc != 1) return rc;
     rc = conv2d_fwd_patch(p, cin, s);                // same shapes, single-role waves (small grids / FF_WS_CONV=0)
     if (rc != 1) return rc;

@@ -61,6 +61,8 @@ int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int c
 int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hipStream_t s);          // conv_wgrad_patch.hip; 1 = not eligible
 int conv2d_fwd_small(const FFConvParams& p, int cin, hipStream_t s);         // conv_small.hip (Cout <= 2, 3x3); 1 = not eligible
 int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s);         // conv_patch.hip; 1 = not eligible
+int conv2d_fwd_stem(const FFConvParams& p, int cin, hipStream_t s);          // conv_stem.hip (7x7 stride-2 stems over NHWC4); 1 = not eligible
+int conv2d_stem_stats_parts(const FFConvParams& p, int cin);                  // conv_stem.hip; entries per (image, channel), 0 = not this route
 int conv2d_stats_parts(const FFConvParams& p, int cin);                       // conv_patch.hip; entries per (image, channel), 0 = cannot
 int conv2d_splitk_hint(const FFConvParams& p, int cin);                       // conv_patch.hip; K splits worth using, 0 = none
 int conv2d_fwd_ws(const FFConvParams& p, int cin, hipStream_t s);            // conv_ws.hip (wave-specialised); 1 = not eligible

@@ -118,6 +118,32 @@ def test_conv2d(ops, case, fmt):
     close(nchw(out), ref, rtol=2e-5 if fmt != "f16" else 4e-3, what=f"conv2d[{fmt}]")
 
 
+@pytest.mark.parametrize("b,h,w,cout", [(2, 40, 56, 64), (1, 41, 57, 64), (3, 96, 128, 64), (1, 384, 512, 64), (2, 30, 34, 48)])
+def test_stem_conv_kernel(ops, b, h, w, cout):
+    """conv_stem.hip: the encoders' Conv2d(3, 64, 7, stride 2, padding 3) (extractor.py:123) over NHWC4 input - persistent
+    blocks, the patch split once, MFMA fragments read straight out of it - against F.conv2d at the fp32 tolerance of the
+    f16x3 arithmetic: whole and ragged tiles, odd sizes, a channel count below the tile, eval-BatchNorm scale/shift +
+    activation in the epilogue, and the InstanceNorm statistics of the output from the same launch."""
+    g = torch.Generator().manual_seed(b * 100 + h)
+    x = torch.randn(b, 3, h, w, generator=g)
+    wt = torch.randn(cout, 3, 7, 7, generator=g) / 147 ** 0.5
+    bias, sc, sh = (torch.randn(cout, generator=g) for _ in range(3))
+    conv = F.conv2d(x, wt, bias, stride=2, padding=3)
+    wp = torch.empty(cout, 49 * 4, device=DEV)
+    ops.pack_conv_weight(wt.to(DEV), wp, 4)
+    wp = ops.pack_split(wp)
+    x4 = torch.zeros(b, h, w, 4, device=DEV)
+    x4[..., :3] = nhwc(x)
+    out, st = ops.conv2d([x4], wp, bias.to(DEV), cout, 7, 7, 2, (3, 3), w_fmt=1, want_stats=True)
+    close(nchw(out), conv, what="stem conv")
+    n = out.shape[1] * out.shape[2]
+    ref = conv.double()
+    close((st[..., 0] / n).cpu(), ref.mean(dim=(2, 3)), rtol=1e-5, atol=1e-6, what="mean from the stem's epilogue")
+    close((st[..., 1] / n - (st[..., 0] / n) ** 2).cpu(), ref.var(dim=(2, 3), unbiased=False), rtol=2e-4, atol=1e-7, what="variance from the stem's epilogue")
+    out2 = ops.conv2d([x4], wp, bias.to(DEV), cout, 7, 7, 2, (3, 3), act=1, ch_scale=sc.to(DEV), ch_shift=sh.to(DEV), w_fmt=1)
+    close(nchw(out2), torch.relu(conv * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), what="stem conv, scale/shift + relu")
+
+
 def test_conv2d_wave_specialised_kernel_opt_in():
     """conv_ws.hip (persistent, wave-specialised) is opt-in via FF_WS_CONV=1, read once per process: run the
     half-precision conv cases through it in ONE child process and require the same tolerances."""
