@@ -352,9 +352,15 @@ def _check_grad_population(params, g32, g64):
         cpu.append(float((g32[k].double() - g64[k]).abs().max()) / s)
     hip, cpu = np.array(hip), np.array(cpu)
     assert len(hip) > 200
-    assert np.median(hip) <= max(4 * np.median(cpu), 3e-3), (np.median(hip), np.median(cpu))
-    assert np.percentile(hip, 90) <= max(6 * np.percentile(cpu, 90), 1e-2), (np.percentile(hip, 90), np.percentile(cpu, 90))
-    assert hip.max() <= 0.1, hip.max()
+    # (round 3: measured HIP median 8e-5 / p90 2e-4..1e-3 / max 1.0e-2..1.6e-2 against the CPU's own 1e-3 / 1.5e-3..3.7e-3 / 2.4e-3..1.0e-2)
+    assert np.median(hip) <= max(np.median(cpu), 1e-3), (np.median(hip), np.median(cpu))
+    assert np.percentile(hip, 90) <= max(2 * np.percentile(cpu, 90), 4e-3), (np.percentile(hip, 90), np.percentile(cpu, 90))
+    # the tail: a flipped ReLU plane / L1 sign lands in a handful of tensors, never in many, and stays a few per cent
+    n_bad = int((hip > 1e-2).sum())
+    print(f"gradient population: {len(hip)} tensors, HIP median {np.median(hip):.2e} p90 {np.percentile(hip, 90):.2e} p97 {np.percentile(hip, 97):.2e} "
+          f"max {hip.max():.2e} ({n_bad} above 1e-2); CPU fp32 median {np.median(cpu):.2e} p90 {np.percentile(cpu, 90):.2e} max {cpu.max():.2e}")
+    assert n_bad <= max(4, int(0.03 * len(hip))), (n_bad, len(hip))
+    assert hip.max() <= max(6e-2, 3 * cpu.max()), (hip.max(), cpu.max())
 
 
 def test_train_step_matches_reference(det_sd):
@@ -475,7 +481,12 @@ def test_frozen_frame_branch_training_step_against_fp64(det_sd):
         cpu.append(float((g32[k].double() - g64[k]).abs().max()) / s)
     hip, cpu = np.array(hip), np.array(cpu)
     assert np.median(hip) <= max(4 * np.median(cpu), 3e-3), (np.median(hip), np.median(cpu))
-    assert hip.max() <= 0.1, hip.max()
+    # the tail: a flipped ReLU plane / L1 sign lands in a handful of tensors, never in many, and stays a few per cent
+    n_bad = int((hip > 1e-2).sum())
+    print(f"gradient population: {len(hip)} tensors, HIP median {np.median(hip):.2e} p90 {np.percentile(hip, 90):.2e} p97 {np.percentile(hip, 97):.2e} "
+          f"max {hip.max():.2e} ({n_bad} above 1e-2); CPU fp32 median {np.median(cpu):.2e} p90 {np.percentile(cpu, 90):.2e} max {cpu.max():.2e}")
+    assert n_bad <= max(4, int(0.03 * len(hip))), (n_bad, len(hip))
+    assert hip.max() <= max(6e-2, 3 * cpu.max()), (hip.max(), cpu.max())
 
 
 @pytest.mark.parametrize("partial", [False, True])
