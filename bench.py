@@ -603,14 +603,14 @@ def main():
             "write_gbs": round(pyr_bytes / (vol_avg_ms * 1e-3) / 1e9, 1) if vol_avg_ms > 0 else 0.0, "write_bytes": pyr_bytes,
             "launches": vb[0], "avg_launch_us": round(vol_avg_ms * 1e3, 1)}
         # all convolutions of one extra (untimed) step, each launch bracketed by HIP events: where 80 % of the step goes
-        ops.SINGLE_STREAM = True          # bracketed launches must not overlap: this extra step runs on one stream
+        ops.policy.single_stream = True          # bracketed launches must not overlap: this extra step runs on one stream
         try:
             ops.profile_begin("conv")
             with torch.no_grad():
                 model(*batch, raft_iters=args.iters, test_mode=True)
             conv_ms = ops.profile_end()["conv"]
         finally:
-            ops.SINGLE_STREAM = False
+            ops.policy.single_stream = False
         notes = ops.profile_notes("conv")
         useful = sum(n[0] for n in notes)
         issued_fl = sum(n[0] * (3 if n[1] == 1 else 1) for n in notes if n[1] != 0)

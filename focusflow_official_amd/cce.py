@@ -434,7 +434,7 @@ class BasicParallelFusionLayer(nn.Module):
         the mask branch on a side stream (forked and joined with events: capturable): one branch's memory-bound norm passes
         overlap the other's convolutions."""
         # (not while a hipGraph is being captured: a fork inside a forked stream - cnet runs beside fnet - kills the capture)
-        if not (_BRANCH_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and (not torch.is_grad_enabled() or train_streams()) and x.is_cuda) or torch.cuda.is_current_stream_capturing():
+        if not (_BRANCH_STREAMS and ops.policy.encoder_streams_ok and not ops.policy.single_stream and (not torch.is_grad_enabled() or train_streams()) and x.is_cuda) or torch.cuda.is_current_stream_capturing():
             return fm(m), fx(x)
         main = torch.cuda.current_stream()
         side = _branch_stream(x.device)

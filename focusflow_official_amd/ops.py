@@ -8,6 +8,7 @@ in libfocusflow_hip.so.
 import ctypes as C
 import math
 import os
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -54,12 +55,17 @@ def pack_split(rows_f32: Tensor) -> Tensor:
     return dst
 
 
-# Set by a caller that brackets single launches with events (bench.py's roofline_conv leg): every forward then runs on
-# ONE stream, so that the bracketed durations add up to wall time instead of overlapping.
-SINGLE_STREAM = False
-# Set per forward by RAFT._forward: below ~3.5 pairs of 384x512 a step is host-bound and the fork / join events of the
-# encoder streams cost more than the overlap gains (BASELINE configs[4] at one pair: 16.4 -> 16.7 ms).
-ENCODER_STREAMS_OK = True
+class _StreamPolicy(threading.local):
+    """Per-THREAD stream policy of the forward passes (two models driven from two threads do not see each other's).
+    single_stream: set by a caller that brackets single launches with events (bench.py's roofline_conv leg) - every
+    forward then runs on ONE stream, so that the bracketed durations add up to wall time instead of overlapping.
+    encoder_streams_ok: set per forward by RAFT._forward - below ~3.5 pairs of 384x512 a step is host-bound and the
+    fork / join events of the encoder streams cost more than the overlap gains (configs[4] at one pair: 16.4 -> 16.7 ms)."""
+    single_stream = False
+    encoder_streams_ok = True
+
+
+policy = _StreamPolicy()
 
 # Optional per-launch timing of ONE entry point with HIP events recorded on the
 # launch stream (bench.py's roofline leg).  Off unless profile_begin() is called.

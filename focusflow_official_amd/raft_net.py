@@ -89,8 +89,8 @@ class RAFT(nn.Module):
         # (fewer ragged last waves of blocks) and half the launches
         # Inference: the context encoder (BatchNorm folded: convolutions only) on a second stream beside the feature
         # encoder, whose InstanceNorm statistics / apply passes are memory-bound - the two use different parts of the chip.
-        ops.ENCODER_STREAMS_OK = b * hh * ww >= _STREAMS_MIN_PIXELS
-        two_streams = (_ENC_STREAMS and ops.ENCODER_STREAMS_OK and not ops.SINGLE_STREAM and (not torch.is_grad_enabled() or train_streams())
+        ops.policy.encoder_streams_ok = b * hh * ww >= _STREAMS_MIN_PIXELS
+        two_streams = (_ENC_STREAMS and ops.policy.encoder_streams_ok and not ops.policy.single_stream and (not torch.is_grad_enabled() or train_streams())
                        and not torch.cuda.is_current_stream_capturing())
         if two_streams:
             main = torch.cuda.current_stream()
@@ -127,7 +127,7 @@ class RAFT(nn.Module):
         # the context features' share of the GRU gate convolutions does not change over the iterations
         gru_pre = self.update_block.gru.prepare(inp) if _GRU_CTX_ONCE and (taped or not torch.is_grad_enabled()) else None
         if (_UPDATE_SPLIT > 1 and test_mode and not taped and not torch.is_grad_enabled() and b % _UPDATE_SPLIT == 0
-                and not ops.SINGLE_STREAM and not torch.cuda.is_current_stream_capturing()):
+                and not ops.policy.single_stream and not torch.cuda.is_current_stream_capturing()):
             # Opt-in (FF_UPDATE_SPLIT=2): the update loop of n batch slices on n streams, the iterations issued alternately.
             # At 1/8 resolution every kernel of the loop is a 5-90 us launch with several us of ramp; two independent
             # chains fill each other's: +3 % at 8 pairs per step.  Not the default: every launch of the loop - the lookup

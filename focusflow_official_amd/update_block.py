@@ -122,7 +122,7 @@ class BasicMotionEncoder(nn.Module):
         """flow4: (B,H,W,4) zero-padded flow.  Returns motion (B,H,W,128): 126 conv channels, and
         `fill_flow(motion)` writes the flow into channels 126:128 (torch.cat([out, flow]), update.py:97)."""
         c1 = self._c1p if corr.shape[3] == self._c1p.cin_pad else self._c1
-        if _SIDE_STREAM and not ops.SINGLE_STREAM and not torch.is_grad_enabled():
+        if _SIDE_STREAM and not ops.policy.single_stream and not torch.is_grad_enabled():
             # Inference: the flow branch (convf1 -> convf2) does not depend on the lookup and neither branch fills the
             # chip at 1/8 resolution (576 and 384 blocks on 1024 slots): run it on a second HIP stream beside
             # convc1 -> convc2.  It starts behind the lookup (event), so the lookup's own timing stays clean.
