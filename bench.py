@@ -598,7 +598,7 @@ def main():
             "kernel": "corr_build_kernel (ff_corr_build: f16x3 volume + 3 pooled levels + tiled store, one launch)" if ops.conv_precision() == "f16x3"
                       else "conv kernel, groups=B (ff_conv2d_fwd) + pooling pass + retile", "bound": "mfma",
             "achieved": round(issued, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(issued / peak, 4),
-            "note": f"{terms} MFMA term(s) per fp32-accurate product; useful rate {vol_flop / (vol_avg_ms * 1e-3) / 1e12:.1f} TFLOP/s; "
+            "note": f"{terms} MFMA term(s) per fp32-accurate product; useful rate {(vol_flop / (vol_avg_ms * 1e-3) / 1e12 if vol_avg_ms > 0 else 0.0):.1f} TFLOP/s; "
                     f"the launch also writes the whole pyramid once ({pyr_bytes / 1e6:.1f} MB)",
             "write_gbs": round(pyr_bytes / (vol_avg_ms * 1e-3) / 1e9, 1) if vol_avg_ms > 0 else 0.0, "write_bytes": pyr_bytes,
             "launches": vb[0], "avg_launch_us": round(vol_avg_ms * 1e3, 1)}

@@ -411,7 +411,7 @@ class BasicParallelFusionLayer(nn.Module):
 
     def _block(self, blk: ResidualBlock, x):
         p2 = blk._p2
-        if (_NORM_ON_LOAD and self.norm_fn == "instance" and not torch.is_grad_enabled() and ops.w_format() == _hip.W_F16X3
+        if (_NORM_ON_LOAD and self.norm_fn == "instance" and not torch.is_grad_enabled() and ops.w_format() in (_hip.W_F16X3, _hip.W_F16)
                 and p2.cin % 32 == 0 and (p2.kh, p2.kw, p2.stride) == (3, 3, 1)):
             # inference: conv2 applies relu(norm1(.)) while it loads conv1's raw output - one full read + write of the
             # activation less per block (same coefficients, same arithmetic as ff_norm_apply: bit-identical results)

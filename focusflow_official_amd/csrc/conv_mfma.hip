@@ -255,7 +255,7 @@ extern "C" int ff_conv2d_splitk_hint(const FFConvParams* pp) {
 }
 
 extern "C" int ff_conv2d_stats_parts(const FFConvParams* pp) {
-    if (!pp || pp->groups != 1 || pp->w_format != FF_W_F16X3 || !ff::aligned16(pp->y) || pp->y_ld % 4) return 0;
+    if (!pp || pp->groups != 1 || (pp->w_format != FF_W_F16X3 && pp->w_format != FF_W_F16) || !ff::aligned16(pp->y) || pp->y_ld % 4) return 0;
     int cin = 0;
     for (int s = 0; s < FF_MAX_SEG && pp->x_c[s]; ++s) cin += pp->x_c[s];
     if (cin <= 0) return 0;
@@ -297,10 +297,10 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
 
     FF_REQUIRE(p.w_format >= FF_W_F32 && p.w_format <= FF_W_F16, "ff_conv2d_fwd: bad w_format %d", p.w_format);
     FF_REQUIRE((p.in_scale == nullptr) == (p.in_shift == nullptr), "ff_conv2d_fwd: in_scale/in_shift must come together");
-    FF_REQUIRE(!p.in_scale || (p.w_format == FF_W_F16X3 && p.groups == 1 && p.x_c[1] == 0 && !p.x_amax && p.KH == 3 && p.KW == 3 &&
+    FF_REQUIRE(!p.in_scale || ((p.w_format == FF_W_F16X3 || p.w_format == FF_W_F16) && p.groups == 1 && p.x_c[1] == 0 && !p.x_amax && p.KH == 3 && p.KW == 3 &&
                                p.stride == 1 && cin % 32 == 0 && (p.in_act == FF_ACT_NONE || p.in_act == FF_ACT_RELU) &&
                                ff::aligned16(p.in_scale) && ff::aligned16(p.in_shift)),
-               "ff_conv2d_fwd: in_scale needs the f16x3 patch kernel (one segment, 3x3, stride 1, Cin %% 32 == 0)");
+               "ff_conv2d_fwd: in_scale needs the patch kernel (a split weight format, one segment, 3x3, stride 1, Cin %% 32 == 0)");
     FF_REQUIRE(!p.res2 || (p.res && p.w_format != FF_W_F32 && p.KH == 1 && p.KW == 1 && p.groups == 1 && p.res_split > 0 &&
                            p.res_split < p.Cout && p.res2_ld >= p.Cout - p.res_split && !getenv("FF_WS_CONV")),
                "ff_conv2d_fwd: res2 needs res, a split weight format and a 1x1 kernel (0 < res_split < Cout)");

@@ -617,6 +617,28 @@ int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
     return ff::check_launch("ff_conv2d_fwd(patch)");
 }
 
+// The same high-occupancy variants for the one-term reduced-precision mode (FF_W_F16): plain, normalise-on-load, statistics,
+// split-K - no ablations, no GRU epilogues.
+template <int NITEM, int TM, int TN, int OCC>
+int launch_occ_f16(const PArgs& a, size_t lds, hipStream_t s) {
+    const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    if (a.p.stats_part) {
+        if (a.p.in_scale) conv_patch_kernel_occ<1, NITEM, TM, TN, OCC, true, 0, true, false, false, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+        else conv_patch_kernel_occ<1, NITEM, TM, TN, OCC, true, 0, false, false, false, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+        return ff::check_launch("ff_conv2d_fwd(patch, f16, statistics)");
+    }
+    if (a.p.splitk > 1) {
+        const int splits = (a.nci + a.nci_split - 1) / a.nci_split;
+        conv_patch_kernel_occ<1, NITEM, TM, TN, OCC, true, 0, false, true><<<dim3((unsigned)blocks, splits), 256, lds, s>>>(a);
+        const long long npix = (long long)a.p.B * a.p.H * a.p.W, total = npix * a.p.Cout;
+        splitk_finish_kernel<<<(unsigned)std::min<long long>((total + 255) / 256, 2048), 256, 0, s>>>(a.p, splits, npix);
+        return ff::check_launch("ff_conv2d_fwd(patch, f16, split-K)");
+    }
+    if (a.p.in_scale) conv_patch_kernel_occ<1, NITEM, TM, TN, OCC, true, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+    else conv_patch_kernel_occ<1, NITEM, TM, TN, OCC><<<(unsigned)blocks, 256, lds, s>>>(a);
+    return ff::check_launch("ff_conv2d_fwd(patch, f16)");
+}
+
 template <int TERMS, int NITEM, int TM, int TN, int ABL = 0, int WB = 2>
 int launch(const PArgs& a, size_t lds, hipStream_t s) {
     static bool once = false;
@@ -677,7 +699,8 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     // buffer (a second barrier per tap instead) the 8-row tile needs 35 KB of LDS and the 4-row tile 25 KB, so 4 / 5
     // blocks fit a CU once the registers are capped to match (amdgpu_waves_per_eu).
     static const int wb1 = getenv("FF_PATCH_WB1") ? atoi(getenv("FF_PATCH_WB1")) : 3;   // bit 0: 8-row tiles, bit 1: 4-row tiles
-    const bool occ = t3 && tn == 1 && ((th == 8 && nitem <= 6 && (wb1 & 1)) || (th == 4 && nitem <= 4 && (wb1 & 2)));
+    // (the one-term reduced-precision mode runs the same high-occupancy variants: 496 -> 559 pairs/s end to end)
+    const bool occ = (t3 || (p.w_format == FF_W_F16 && !p.ep_mode)) && tn == 1 && ((th == 8 && nitem <= 6 && (wb1 & 1)) || (th == 4 && nitem <= 4 && (wb1 & 2)));
     const size_t lds = ((npix * ROWP + 255) & ~255) + (occ ? 1 : 2) * 64 * tn * ROWP + lds_pad;
     if (lds > 96 * 1024) return 1;
     static const int abl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;   // timing experiments (wrong results!)
@@ -694,6 +717,7 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     if (p.ep_mode) {             // validated by ff_conv2d_fwd; the high-occupancy variants carry the GRU epilogues
         if (!occ || a.p.splitk > 1 || p.in_scale || p.Cout % 4) return ff::fail(FF_EINVAL, "ff_conv2d_fwd: ep_mode needs the f16x3 patch kernel's 8x16 / 4x16 tiles (got %dx%d kernel, Cin %d, Cout %d)", p.KH, p.KW, cin, p.Cout);
     }
+    if (occ && !t3) return th == 8 ? launch_occ_f16<6, 2, 1, 4>(a, lds, s) : launch_occ_f16<4, 1, 1, 5>(a, lds, s);
     if (occ) return th == 8 ? launch_occ<3, 6, 2, 1, 4>(a, lds, s) : launch_occ<3, 4, 1, 1, 5>(a, lds, s);
     if (p.in_scale) return 1;            // only the two variants above normalise while loading (the caller fails loudly)
 #define FF_PATCH_CASE(TH_, TN_, NI_) \
@@ -712,7 +736,7 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
 // high-occupancy variants: 2 entries (one per wave row) per 8x16 / 4x16 tile.
 int conv2d_stats_parts(const FFConvParams& p, int cin) {
     static const bool enabled = !getenv("FF_NO_PATCH_CONV") && !(getenv("FF_CONV_STATS") && atoi(getenv("FF_CONV_STATS")) == 0);
-    if (!enabled || p.w_format != FF_W_F16X3 || p.res2 || p.ep_mode || p.x_amax) return 0;
+    if (!enabled || (p.w_format != FF_W_F16X3 && p.w_format != FF_W_F16) || p.res2 || p.ep_mode || p.x_amax) return 0;
     const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
     if (p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1) return 0;
     if (p.KH % 2 == 0 || p.KW % 2 == 0 || p.pad_h != p.KH / 2 || p.pad_w != p.KW / 2 || p.KH > 7 || p.KW > 7 || p.KH * p.KW < 3) return 0;
