@@ -308,7 +308,7 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
                "ff_conv2d_fwd: stats_part: this convolution cannot produce statistics (ff_conv2d_stats_parts returned 0) or the buffer is misaligned");
     FF_REQUIRE(p.ep_mode >= FF_EP_NONE && p.ep_mode <= FF_EP_GRU_BLEND, "ff_conv2d_fwd: bad ep_mode %d", p.ep_mode);
     if (p.ep_mode) {
-        FF_REQUIRE(p.w_format == FF_W_F16X3 && p.groups == 1 && p.stride == 1 && cin % 32 == 0 && p.KH * p.KW >= 3 && !p.res2 && !p.in_scale &&
+        FF_REQUIRE((p.w_format == FF_W_F16X3 || p.w_format == FF_W_F16) && p.groups == 1 && p.stride == 1 && cin % 32 == 0 && p.KH * p.KW >= 3 && !p.res2 && !p.in_scale &&
                    p.Cout % 4 == 0 && p.y_ld % 4 == 0 && ff::aligned16(p.y),
                    "ff_conv2d_fwd: ep_mode needs the f16x3 patch kernel (stride 1, Cin %% 32 == 0, 3x3 / 1x5 / 5x1) and a 16-byte aligned output");
         FF_REQUIRE(p.ep_a && ff::aligned16(p.ep_a) && p.ep_a_ld % 4 == 0, "ff_conv2d_fwd: ep_a null or misaligned");

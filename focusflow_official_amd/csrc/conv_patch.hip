@@ -618,7 +618,7 @@ int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
 }
 
 // The same high-occupancy variants for the one-term reduced-precision mode (FF_W_F16): plain, normalise-on-load, statistics,
-// split-K - no ablations, no GRU epilogues.
+// GRU epilogues, split-K - no ablations.
 template <int NITEM, int TM, int TN, int OCC>
 int launch_occ_f16(const PArgs& a, size_t lds, hipStream_t s) {
     const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
@@ -626,6 +626,11 @@ int launch_occ_f16(const PArgs& a, size_t lds, hipStream_t s) {
         if (a.p.in_scale) conv_patch_kernel_occ<1, NITEM, TM, TN, OCC, true, 0, true, false, false, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
         else conv_patch_kernel_occ<1, NITEM, TM, TN, OCC, true, 0, false, false, false, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
         return ff::check_launch("ff_conv2d_fwd(patch, f16, statistics)");
+    }
+    if (a.p.ep_mode) {
+        if (a.p.ep_mode == FF_EP_GRU_RH) conv_patch_kernel_occ<1, NITEM, TM, TN, OCC, true, 0, false, false, true, FF_EP_GRU_RH><<<(unsigned)blocks, 256, lds, s>>>(a);
+        else conv_patch_kernel_occ<1, NITEM, TM, TN, OCC, true, 0, false, false, true, FF_EP_GRU_BLEND><<<(unsigned)blocks, 256, lds, s>>>(a);
+        return ff::check_launch("ff_conv2d_fwd(patch, f16, GRU epilogue)");
     }
     if (a.p.splitk > 1) {
         const int splits = (a.nci + a.nci_split - 1) / a.nci_split;
@@ -700,7 +705,7 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     // blocks fit a CU once the registers are capped to match (amdgpu_waves_per_eu).
     static const int wb1 = getenv("FF_PATCH_WB1") ? atoi(getenv("FF_PATCH_WB1")) : 3;   // bit 0: 8-row tiles, bit 1: 4-row tiles
     // (the one-term reduced-precision mode runs the same high-occupancy variants: 496 -> 559 pairs/s end to end)
-    const bool occ = (t3 || (p.w_format == FF_W_F16 && !p.ep_mode)) && tn == 1 && ((th == 8 && nitem <= 6 && (wb1 & 1)) || (th == 4 && nitem <= 4 && (wb1 & 2)));
+    const bool occ = (t3 || p.w_format == FF_W_F16) && tn == 1 && ((th == 8 && nitem <= 6 && (wb1 & 1)) || (th == 4 && nitem <= 4 && (wb1 & 2)));
     const size_t lds = ((npix * ROWP + 255) & ~255) + (occ ? 1 : 2) * 64 * tn * ROWP + lds_pad;
     if (lds > 96 * 1024) return 1;
     static const int abl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;   // timing experiments (wrong results!)

@@ -340,13 +340,13 @@ int launch_u(const KernArgs& a, hipStream_t s) {
     k.n_tiles = (a.p.Cout + BN - 1) / BN;
     dim3 grid(k.m_tiles * k.n_tiles, a.p.groups);
     static const int occ = getenv("FF_SPLIT_OCC") ? atoi(getenv("FF_SPLIT_OCC")) : 1;
-    if constexpr (NST == 1 && TERMS == 3 && WM == 2 && TM == 2 && TN == 1) {
+    if constexpr (NST == 1 && WM == 2 && TM == 2 && TN == 1) {
         if (occ) {
             conv_split_kernel_occ<WM, WN, TM, TN, TERMS, UNI, 4><<<grid, 256, lds / 2, s>>>(k);
             return ff::check_launch("ff_conv2d_fwd(split)");
         }
     }
-    if constexpr (NST == 1 && TERMS == 3 && WM == 4 && TN == 3) {      // 128 x 96 (Cout = 96 layers): 56 KB -> 28 KB, 2 -> 3 blocks
+    if constexpr (NST == 1 && WM == 4 && TN == 3) {      // 128 x 96 (Cout = 96 layers): 56 KB -> 28 KB, 2 -> 3 blocks
         if (occ) {
             conv_split_kernel_occ<WM, WN, TM, TN, TERMS, UNI, 3><<<grid, 256, lds / 2, s>>>(k);
             return ff::check_launch("ff_conv2d_fwd(split)");
@@ -394,7 +394,8 @@ int dispatch(const KernArgs& a, hipStream_t s) {
     // (blocks per CU) beats tile size: the 128x128 three-term tile needs 270 registers = 1 block/CU and
     // measured 1.8x slower end to end than 128x64 (3 blocks/CU).  Keep 128x128 for the 1-term mode only.
     auto blocks = [&](int bm, int bn) { return g * ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
-    if (TERMS == 1 && p.Cout > 96 && (p.Cout % 128 == 0 || p.Cout > 192) && blocks(128, 128) >= 512) return launch<2, 2, 2, 2, TERMS>(a, s);
+    static const bool big1 = getenv("FF_SPLIT_F16_128") && atoi(getenv("FF_SPLIT_F16_128")) == 1;     // one-term mode: the 128 x 128 tile lost to 128 x 64 at 4 blocks per CU (391 vs 224 us on the 1x1 fusion convs)
+    if (big1 && TERMS == 1 && p.Cout > 96 && (p.Cout % 128 == 0 || p.Cout > 192) && blocks(128, 128) >= 512) return launch<2, 2, 2, 2, TERMS>(a, s);
     if (p.Cout > 64 && p.Cout <= 96 && blocks(128, 96) >= 512) return launch<4, 1, 1, 3, TERMS>(a, s);
     if (blocks(128, 64) >= 512) return launch<2, 2, 2, 1, TERMS>(a, s);
     return launch<2, 2, 1, 1, TERMS>(a, s);

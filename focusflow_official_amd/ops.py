@@ -305,13 +305,13 @@ class TiledPyramid:
 def corr_build(fmap1: Tensor, fmap2: Tensor, half: bool = False) -> TiledPyramid:
     """CorrBlock.__init__ (corr.py:12-27, :52-60) in one launch: all-pairs volume / sqrt(C) on the f16 matrix pipe with
     fp16-split operands, the three 2x2 average-pooling levels from the accumulators, everything written once in the
-    tiled layout (fp32, or fp16 storage = BASELINE configs[4]).  Other conv precisions (exact fp32 MFMA, plain f16) go
-    through the grouped-conv volume + pooling pass and are re-tiled."""
+    tiled layout (fp32, or fp16 storage = BASELINE configs[4]).  The exact-fp32 MFMA precision goes through the
+    grouped-conv volume + pooling pass and is re-tiled."""
     b, h, w, c = fmap1.shape
     q = h * w
     assert fmap1.is_contiguous() and fmap2.is_contiguous() and fmap2.shape == fmap1.shape
     _require_gpu(fmap1)
-    if w_format() != _hip.W_F16X3 or c != 256:
+    if w_format() == _hip.W_F32 or c != 256:       # (the one-term f16 mode builds the volume with the three-term kernel too)
         return TiledPyramid.from_rowmajor(corr_pyramid(corr_volume(fmap1, fmap2), h, w), half)
     esz = fmap1.element_size()
     if fmap2.data_ptr() == fmap1.data_ptr() + b * q * c * esz and fmap1.untyped_storage().data_ptr() == fmap2.untyped_storage().data_ptr():

@@ -81,7 +81,7 @@ class SepConvGRU(nn.Module):
         if pre is not None:
             # (not while a hipGraph is being captured: there the K splits of these short reductions pay more, and the
             # split partial sums cannot carry an epilogue)
-            fused = _GRU_EPILOGUE and ops.w_format() == _hip.W_F16X3 and not torch.cuda.is_current_stream_capturing()
+            fused = _GRU_EPILOGUE and ops.w_format() in (_hip.W_F16X3, _hip.W_F16) and not torch.cuda.is_current_stream_capturing()
             for zr_conv, q_conv, (zr_pre, q_pre) in zip(self._zr_hm, self._q_hm, pre):
                 if fused:
                     # the two element-wise steps ride in the epilogues of the convolutions that precede them (FFConvParams
