@@ -158,17 +158,26 @@ class BasicUpdateBlock(nn.Module):
         self._flow2 = PackedConv([self.flow_head.conv2])
         self._mask2 = PackedConv([self.mask[2]])
 
-    def run(self, net, inp, corr, flow4, fill_flow, need_mask=True, gru_pre=None):
+    def run(self, net, inp, corr, flow4, fill_flow, need_mask=True, gru_pre=None, defer_mask=False):
         """-> (net, up_mask, delta_flow), all NHWC.  update.py:126-135.  need_mask=False (inference only, opt-in)
-        leaves out the up-sampling mask head when the caller is going to discard it."""
+        leaves out the up-sampling mask head when the caller is going to discard it.  defer_mask (inference): up_mask
+        comes back as the mask head's HIDDEN tensor (B,H,W,256) - the caller finishes it with upsample() below (the
+        second mask convolution and the convex up-sampling as one launch)."""
         motion = self.encoder.run(flow4, corr, fill_flow)
         net = self.gru.run(net, [inp, motion], gru_pre)
         if not need_mask:
             return net, None, fn.conv(self._flow2, fn.conv(self._head1, net, act=ACT_RELU))
         hid = fn.conv(self._heads, net, act=ACT_RELU)                      # [flow-head 256 | mask-head 256]
         delta = fn.conv(self._flow2, hid[..., :256])
+        if defer_mask:
+            return net, hid[..., 256:], delta
         up_mask = fn.conv(self._mask2, hid[..., 256:], out_scale=0.25)     # ".25 * self.mask(net)"
         return net, up_mask, delta
+
+    def upsample(self, mask_hidden, flow4):
+        """run(defer_mask=True)'s hidden tensor + the flow -> flow_up (B,2,8H,8W): ops.mask_upsample."""
+        w, b = self._mask2.get()
+        return ops.mask_upsample(mask_hidden, w, self._mask2.fmt, b, flow4, 0.25)
 
     def freeze_self(self, mode):
         if mode == "parallel":  # update.py:137-146

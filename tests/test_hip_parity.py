@@ -622,6 +622,36 @@ def test_instance_norm_statistics_from_the_conv_epilogue(det_sd, monkeypatch):
     close(fu1.cpu(), fu0.cpu(), rtol=0, atol=2e-4, what="flow_up, statistics from the conv epilogue vs the statistics pass")
 
 
+@pytest.mark.parametrize("b,h,w", [(2, 16, 24), (1, 13, 21), (8, 48, 64)])
+def test_mask_conv_and_convex_upsampling_as_one_kernel(ops, b, h, w):
+    """ff_mask_upsample_fwd: mask[2] (1x1 256 -> 576, x 0.25; update.py:121-124, :133), the soft-max over the nine
+    neighbours and the convex combination (raft.py:159-170) in one launch, against the two launches it replaces
+    (ff_conv2d_fwd + ff_upsample_flow - themselves pinned by reference vectors) and against torch: block-ragged pixel
+    counts, image borders (zero-padded unfold), both split weight formats."""
+    from focusflow_official_amd import cce
+    g = torch.Generator().manual_seed(b * 10 + h)
+    conv = torch.nn.Conv2d(256, 576, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(576, 256, 1, 1, generator=g) / 8)
+        conv.bias.copy_(torch.randn(576, generator=g))
+    hid = torch.relu(torch.randn(b, h, w, 512, generator=g)).to(DEV)
+    flow = torch.randn(b, h, w, 4, generator=g).to(DEV) * 3
+    flow[..., 2:] = 0
+    pc = cce.PackedConv([conv.to(DEV)])
+    with torch.no_grad():
+        mask = pc(hid[..., 256:], out_scale=0.25)
+        two = ops.upsample_flow(flow, mask)
+        wq, bq = pc.get()
+        one = ops.mask_upsample(hid[..., 256:], wq, pc.fmt, bq, flow, 0.25)
+        # torch: raft.py:159-170 on the fp32 convolution
+        m = 0.25 * F.conv2d(nchw(hid[..., 256:].contiguous()).cpu(), conv.weight.cpu(), conv.bias.cpu())
+        m = torch.softmax(m.view(b, 1, 9, 8, 8, h, w), dim=2)
+        uf = F.unfold(8 * nchw(flow[..., :2].contiguous()).cpu(), [3, 3], padding=1).view(b, 2, 9, 1, 1, h, w)
+        ref = torch.sum(m * uf, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(b, 2, 8 * h, 8 * w)
+    close(one.cpu(), two.cpu(), rtol=0, atol=1e-4, what="one launch vs conv + upsample")
+    close(one.cpu(), ref, rtol=0, atol=2e-4, what="one launch vs torch")
+
+
 def test_skip_unused_upsample_is_bit_identical(det_sd):
     """Opt-in inference shortcut: mask head + convex up-sampling for the last iteration only (the reference throws
     the other results away in test_mode, raft.py:226-236) must not change a single bit of either output."""
