@@ -306,8 +306,12 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
                "ff_conv2d_fwd: res2 needs res, a split weight format and a 1x1 kernel (0 < res_split < Cout)");
     FF_REQUIRE(!p.stats_part || (ff::aligned16(p.stats_part) && ff_conv2d_stats_parts(pp) > 0),
                "ff_conv2d_fwd: stats_part: this convolution cannot produce statistics (ff_conv2d_stats_parts returned 0) or the buffer is misaligned");
-    FF_REQUIRE(p.ep_mode >= FF_EP_NONE && p.ep_mode <= FF_EP_GRU_BLEND, "ff_conv2d_fwd: bad ep_mode %d", p.ep_mode);
-    if (p.ep_mode) {
+    FF_REQUIRE(p.ep_mode >= FF_EP_NONE && p.ep_mode <= FF_EP_COORDS, "ff_conv2d_fwd: bad ep_mode %d", p.ep_mode);
+    if (p.ep_mode == FF_EP_COORDS) {
+        FF_REQUIRE(p.w_format == FF_W_F32 && p.Cout == 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 && p.groups == 1 &&
+                   p.act == FF_ACT_NONE && !p.res && p.ep_a && p.ep_b && ff::aligned16(p.ep_b) && (reinterpret_cast<uintptr_t>(p.ep_a) & 7) == 0,
+                   "ff_conv2d_fwd: FF_EP_COORDS belongs to the 2-channel 3x3 flow head in fp32 rows (ep_a = coords1, ep_b = flow4)");
+    } else if (p.ep_mode) {
         FF_REQUIRE((p.w_format == FF_W_F16X3 || p.w_format == FF_W_F16) && p.groups == 1 && p.stride == 1 && cin % 32 == 0 && p.KH * p.KW >= 3 && !p.res2 && !p.in_scale &&
                    p.Cout % 4 == 0 && p.y_ld % 4 == 0 && ff::aligned16(p.y),
                    "ff_conv2d_fwd: ep_mode needs the f16x3 patch kernel (stride 1, Cin %% 32 == 0, 3x3 / 1x5 / 5x1) and a 16-byte aligned output");

@@ -98,6 +98,16 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SArgs a) {
             v = ff::apply_act(v, p.act);
             if (p.res) v = ff::apply_act(v + p.res[m * p.res_ld + c], p.act_res);
             p.y[m * p.y_ld + c] = v;
+            mine[c] = v;
+        }
+        if constexpr (COUT == 2) {
+            if (p.ep_mode == FF_EP_COORDS) {      // raft.py:223 coords1 = coords1 + delta_flow, :219 flow = coords1 - coords0 (ff_coords_step's roundings)
+                float* c1 = const_cast<float*>(p.ep_a) + m * 2;
+                const float cx = __fadd_rn(c1[0], mine[0]), cy = __fadd_rn(c1[1], mine[1]);
+                c1[0] = cx;
+                c1[1] = cy;
+                *reinterpret_cast<f32x4*>(const_cast<float*>(p.ep_b) + m * 4) = (f32x4){__fsub_rn(cx, (float)x), __fsub_rn(cy, (float)y), 0.f, 0.f};
+            }
         }
     }
 }

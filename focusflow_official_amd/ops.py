@@ -170,7 +170,7 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
            ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0, dilation: int = 1,
            x_amax: Optional[Tensor] = None, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None,
            in_act: int = ACT_NONE, res2: Optional[Tensor] = None, res_split: int = 0,
-           ep_rh: Optional[Tensor] = None, ep_split: int = 0, ep_blend=None, want_stats: bool = False):
+           ep_rh: Optional[Tensor] = None, ep_split: int = 0, ep_blend=None, want_stats: bool = False, ep_coords=None):
     """Convolution over the channel-concatenation of `xs` (see FFConvParams).  want_stats: -> (out, stats) with the
     per-sample {sum, sum of squares} table of the output (what norm_stats(out, True) returns): from the convolution's own
     epilogue where the kernel can (FFConvParams.stats_part), else from a norm_stats pass.  res2 / res_split: output channels
@@ -209,6 +209,10 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
         p.res2, p.res2_ld, p.res_split = res2.data_ptr(), _ld(res2), res_split
     if ep_rh is not None:       # FF_EP_GRU_RH: output channels >= ep_split leave multiplied by ep_rh (the z|r conv writes [z | r*h])
         p.ep_mode, p.ep_split, p.ep_a, p.ep_a_ld = 1, ep_split, ep_rh.data_ptr(), _ld(ep_rh)
+    elif ep_coords is not None:  # FF_EP_COORDS: (coords1, flow4) - the flow head also takes the coordinate step
+        c1, f4 = ep_coords
+        assert c1.is_contiguous() and c1.shape == (b, ho, wo, 2) and f4.is_contiguous() and f4.shape == (b, ho, wo, 4)
+        p.ep_mode, p.ep_a, p.ep_b = 3, c1.data_ptr(), f4.data_ptr()
     elif ep_blend is not None:  # FF_EP_GRU_BLEND: (z, h) -> the output is (1 - z) h + z v (the q conv writes the new state)
         z, hprev = ep_blend
         p.ep_mode, p.ep_a, p.ep_a_ld, p.ep_b, p.ep_b_ld = 2, z.data_ptr(), _ld(z), hprev.data_ptr(), _ld(hprev)

@@ -10,6 +10,7 @@ from .corr_block import CorrBlock
 from .ops import ACT_RELU, ACT_TANH
 from .update_block import BasicUpdateBlock
 
+_COORDS_EPILOGUE = os.environ.get("FF_COORDS_EPILOGUE", "1") != "0"   # A/B switch: coords1 += delta inside the flow head's last convolution (inference)
 _MASK_UPSAMPLE = os.environ.get("FF_MASK_UPSAMPLE", "1") != "0"   # A/B switch: mask conv 2 + convex up-sampling as one kernel (inference)
 _GRU_CTX_ONCE = os.environ.get("FF_GRU_CTX_ONCE", "1") != "0"      # measurement switch (see SepConvGRU.prepare)
 _STREAMS_MIN_PIXELS = int(os.environ.get("FF_STREAMS_MIN_PIXELS", "700000"))   # below: host-bound, the fork / join events cost more than they gain
@@ -159,6 +160,7 @@ class RAFT(nn.Module):
         # the mask head + convex up-sampling for the last iteration only; flow_low / flow_up are bit-identical.
         lazy = bool(getattr(self, "skip_unused_upsample", False)) and test_mode and not taped
         # inference: the mask head's 1x1 convolution and the convex up-sampling run as one kernel (no 576-channel mask tensor)
+        fused_coords = _COORDS_EPILOGUE and not taped and not torch.is_grad_enabled() and coords1.is_contiguous()
         fused_up = _MASK_UPSAMPLE and not taped and not torch.is_grad_enabled() and ops.w_format() in (_hip.W_F16X3, _hip.W_F16)
         for it in range(iters):
             # coords1 is advanced in place by ff_coords_step (raw pointer: autograd cannot see it), so a
@@ -169,9 +171,14 @@ class RAFT(nn.Module):
                 ops.coords_step(coords1, None, flow4, None)               # flow = coords1 - coords0
             fill = lambda motion, c=coords1: ops.coords_step(c, None, None, motion[..., 126:])  # noqa: E731
             need_mask = not lazy or it == iters - 1
-            net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre, defer_mask=fused_up)
-            flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
-            ops.coords_step(coords1, delta.detach(), flow4, None)         # coords1 += delta
+            if fused_coords and need_mask:      # the flow head's last convolution takes the coordinate step with it
+                nflow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
+                net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre, defer_mask=fused_up, coords_out=(coords1, nflow4))
+                flow4 = nflow4
+            else:
+                net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre, defer_mask=fused_up)
+                flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
+                ops.coords_step(coords1, delta.detach(), flow4, None)         # coords1 += delta
             if need_mask:
                 if fused_up:
                     flow_up = self.update_block.upsample(up_mask, flow4)

@@ -158,17 +158,21 @@ class BasicUpdateBlock(nn.Module):
         self._flow2 = PackedConv([self.flow_head.conv2])
         self._mask2 = PackedConv([self.mask[2]])
 
-    def run(self, net, inp, corr, flow4, fill_flow, need_mask=True, gru_pre=None, defer_mask=False):
+    def run(self, net, inp, corr, flow4, fill_flow, need_mask=True, gru_pre=None, defer_mask=False, coords_out=None):
         """-> (net, up_mask, delta_flow), all NHWC.  update.py:126-135.  need_mask=False (inference only, opt-in)
         leaves out the up-sampling mask head when the caller is going to discard it.  defer_mask (inference): up_mask
         comes back as the mask head's HIDDEN tensor (B,H,W,256) - the caller finishes it with upsample() below (the
-        second mask convolution and the convex up-sampling as one launch)."""
+        second mask convolution and the convex up-sampling as one launch).  coords_out = (coords1, flow4_next) (inference):
+        the flow head's last convolution also takes the coordinate step coords1 += delta, flow4_next = coords1 - grid."""
         motion = self.encoder.run(flow4, corr, fill_flow)
         net = self.gru.run(net, [inp, motion], gru_pre)
         if not need_mask:
             return net, None, fn.conv(self._flow2, fn.conv(self._head1, net, act=ACT_RELU))
         hid = fn.conv(self._heads, net, act=ACT_RELU)                      # [flow-head 256 | mask-head 256]
-        delta = fn.conv(self._flow2, hid[..., :256])
+        if coords_out is not None:
+            delta = self._flow2(hid[..., :256], ep_coords=coords_out)
+        else:
+            delta = fn.conv(self._flow2, hid[..., :256])
         if defer_mask:
             return net, hid[..., 256:], delta
         up_mask = fn.conv(self._mask2, hid[..., 256:], out_scale=0.25)     # ".25 * self.mask(net)"

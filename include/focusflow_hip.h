@@ -129,6 +129,11 @@ typedef struct FFConvParams {
                                        /* Same roundings as ff_gru_rh / ff_gru_blend.  Split-format stride-1 convolutions   */
                                        /* with Cin % 32 == 0 and a 3x3 / 1x5 / 5x1 kernel (the patch kernel); ep_a / ep_b    */
                                        /* NHWC, 16-byte aligned, ld % 4 == 0.                                               */
+                                       /*   FF_EP_COORDS    the flow head's 2-channel 3x3 convolution (fp32 rows, update.py:13-14)*/
+                                       /*                   also takes RAFT's coordinate step (raft.py:219-223): ep_a = coords1 */
+                                       /*                   [B][H][W][2], READ AND WRITTEN through the pointer (coords1 += v),  */
+                                       /*                   ep_b = flow4 [B][H][W][4], WRITTEN: (coords1 - pixel grid, 0, 0) -  */
+                                       /*                   the two launches of ff_coords_step that follow the flow head.       */
     float* stats_part;                 /* NULL, or [B][parts][Cout][4] floats that receive partial statistics of the OUTPUT    */
                                        /* ({pivot, sum(v - pivot), sum((v - pivot)^2), count} per entry; parts =                */
                                        /* ff_conv2d_stats_parts(p) > 0): the convolution's epilogue replaces the ff_norm_stats  */
@@ -138,6 +143,7 @@ typedef struct FFConvParams {
 #define FF_EP_NONE 0
 #define FF_EP_GRU_RH 1
 #define FF_EP_GRU_BLEND 2
+#define FF_EP_COORDS 3
 
 int ff_conv2d_fwd(const FFConvParams* p, void* stream);
 
