@@ -650,13 +650,22 @@ def gru_blend(z: Tensor, q: Tensor, h: Tensor, out: Optional[Tensor] = None) -> 
     return out
 
 
-def mask_upsample(hid: Tensor, w_split: Tensor, w_fmt: int, bias: Optional[Tensor], flow: Tensor, out_scale: float = 0.25) -> Tensor:
+def mask_upsample_pack(w_split: Tensor) -> Tensor:
+    """Split rows of the mask head's second convolution (576 x 256) -> ff_mask_upsample_fwd's stage-major weight image."""
+    assert w_split.dtype == torch.uint8 and w_split.numel() == 576 * 1024 and w_split.is_contiguous()
+    out = torch.empty_like(w_split)
+    _hip.call("ff_mask_upsample_pack", _p(w_split), _p(out), _stream())
+    return out
+
+
+def mask_upsample(hid: Tensor, w_stage: Tensor, w_fmt: int, bias: Optional[Tensor], flow: Tensor, out_scale: float = 0.25) -> Tensor:
     """mask[2] (1x1, 256 -> 576) * out_scale + soft-max + convex up-sampling in one launch (ff_mask_upsample_fwd).
-    hid: (B,H,W,256) view of the mask head's hidden tensor; w_split: its split rows; flow: (B,H,W,>=2).  -> (B,2,8H,8W)."""
+    hid: (B,H,W,256) view of the mask head's hidden tensor; w_stage: mask_upsample_pack(split rows); flow: (B,H,W,>=2).
+    -> (B,2,8H,8W)."""
     b, h, w, c = hid.shape
     assert c == 256 and w_fmt in (_hip.W_F16X3, _hip.W_F16) and flow.shape[:3] == (b, h, w)
     out = torch.empty((b, 2, 8 * h, 8 * w), dtype=torch.float32, device=hid.device)
-    _hip.call("ff_mask_upsample_fwd", _p(hid), _ld(hid), _p(w_split), w_fmt, _p(bias), out_scale, _p(flow), _ld(flow), _p(out), b, h, w, _stream())
+    _hip.call("ff_mask_upsample_fwd", _p(hid), _ld(hid), _p(w_stage), w_fmt, _p(bias), out_scale, _p(flow), _ld(flow), _p(out), b, h, w, _stream())
     return out
 
 

@@ -181,7 +181,9 @@ class BasicUpdateBlock(nn.Module):
     def upsample(self, mask_hidden, flow4):
         """run(defer_mask=True)'s hidden tensor + the flow -> flow_up (B,2,8H,8W): ops.mask_upsample."""
         w, b = self._mask2.get()
-        return ops.mask_upsample(mask_hidden, w, self._mask2.fmt, b, flow4, 0.25)
+        if getattr(self, "_mask2_stage_of", None) is not w:       # re-arranged once per packed weight version
+            self._mask2_stage, self._mask2_stage_of = ops.mask_upsample_pack(w), w
+        return ops.mask_upsample(mask_hidden, self._mask2_stage, self._mask2.fmt, b, flow4, 0.25)
 
     def freeze_self(self, mode):
         if mode == "parallel":  # update.py:137-146

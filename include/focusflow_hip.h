@@ -51,7 +51,7 @@ const char* ff_last_error(void);
  *   2 (round 2): FFConvParams + res2, res2_ld, res_split, splitk_ws, splitk; ff_norm_bwd + dx_amax; ff_corr_lookup_bwd and
  *                ff_corr_pyramid_bwd (row-major) removed
  *   3 (round 3): FFConvParams + ep_mode, ep_split, ep_a, ep_a_ld, ep_b, ep_b_ld, stats_part; + ff_conv2d_stats_parts,
- *                ff_norm_stats_finish, ff_launch_timing_begin / _end, ff_mask_upsample_fwd */
+ *                ff_norm_stats_finish, ff_launch_timing_begin / _end, ff_mask_upsample_pack / _fwd */
 #define FF_ABI_VERSION 3
 int ff_abi_version(void);
 
@@ -277,10 +277,13 @@ int ff_gru_blend(const float* z, int z_ld, const float* q, int q_ld, const float
                  float* h_new, int hn_ld, long long npix, int C, void* stream);
 /* update.py:121-124 (mask[2], 1x1 256 -> 576) + the ".25 *" of update.py:133 + raft.py:159-170 (soft-max over the nine
  * neighbours, convex combination of the 8x flow) in ONE launch: the (B, H, W, 576) mask is never written.  hid: the mask
- * head's hidden tensor (B, H, W, 256 channels, leading dimension hid_ld); w_split: the 1x1 weights as split rows
- * (ff_pack_conv_weight + ff_pack_split_f16, w_format FF_W_F16X3 or FF_W_F16), bias [576] or NULL; flow (B, H, W, >= 2);
- * out (B, 2, 8H, 8W).  Same arithmetic as ff_conv2d_fwd + ff_upsample_flow up to the summation order of the products. */
-int ff_mask_upsample_fwd(const float* hid, int hid_ld, const void* w_split, int w_format, const float* bias, float out_scale,
+ * head's hidden tensor (B, H, W, 256 channels, leading dimension hid_ld); w_stage: the 1x1 weights - split rows
+ * (ff_pack_conv_weight + ff_pack_split_f16, w_format FF_W_F16X3 or FF_W_F16) rearranged once per weight version by
+ * ff_mask_upsample_pack into the kernel's stage-major image (576 * 1024 bytes, like the split rows); bias [576] or NULL;
+ * flow (B, H, W, >= 2); out (B, 2, 8H, 8W).  Same arithmetic as ff_conv2d_fwd + ff_upsample_flow up to the summation
+ * order of the products and the soft-max's v_exp_f32 / single reciprocal. */
+int ff_mask_upsample_pack(const void* w_split, void* w_stage, void* stream);
+int ff_mask_upsample_fwd(const float* hid, int hid_ld, const void* w_stage, int w_format, const float* bias, float out_scale,
                          const float* flow, int flow_ld, float* out, int B, int H, int W, void* stream);
 /* convex 8x upsampling (raft.py:159-170): flow NHWC [B*H*W][flow_ld] (2 ch),
  * mask NHWC [B*H*W][mask_ld] (576 ch) -> out NCHW (B,2,8H,8W) */

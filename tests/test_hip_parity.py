@@ -642,7 +642,7 @@ def test_mask_conv_and_convex_upsampling_as_one_kernel(ops, b, h, w):
         mask = pc(hid[..., 256:], out_scale=0.25)
         two = ops.upsample_flow(flow, mask)
         wq, bq = pc.get()
-        one = ops.mask_upsample(hid[..., 256:], wq, pc.fmt, bq, flow, 0.25)
+        one = ops.mask_upsample(hid[..., 256:], ops.mask_upsample_pack(wq), pc.fmt, bq, flow, 0.25)
         # torch: raft.py:159-170 on the fp32 convolution
         m = 0.25 * F.conv2d(nchw(hid[..., 256:].contiguous()).cpu(), conv.weight.cpu(), conv.bias.cpu())
         m = torch.softmax(m.view(b, 1, 9, 8, 8, h, w), dim=2)
