@@ -652,6 +652,50 @@ def test_mask_conv_and_convex_upsampling_as_one_kernel(ops, b, h, w):
     close(one.cpu(), ref, rtol=0, atol=2e-4, what="one launch vs torch")
 
 
+def test_flow_head_takes_the_coordinate_step_bit_for_bit(ops):
+    """FF_EP_COORDS: the 2-channel 3x3 flow head (update.py:13-14) with raft.py:223 / :219 in its epilogue
+    (coords1 += delta, flow = coords1 - coords0) against the convolution followed by ff_coords_step: same delta, same
+    coordinates, same flow4, bit for bit."""
+    from focusflow_official_amd import cce
+    g = torch.Generator().manual_seed(21)
+    conv = torch.nn.Conv2d(256, 2, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(2, 256, 3, 3, generator=g) / 48)
+    pc = cce.PackedConv([conv.to(DEV)])
+    b, h, w = 2, 17, 29
+    x = torch.relu(torch.randn(b, h, w, 256, generator=g)).to(DEV)
+    c0 = ops.coords_init(b, h, w, x)
+    c0 += (torch.randn(c0.shape, generator=g) * 3).to(DEV)       # test plumbing only
+    ca, cb = c0.clone(), c0.clone()
+    with torch.no_grad():
+        d1 = pc(x)
+        f1 = ops.empty_nhwc(b, h, w, 4, x)
+        ops.coords_step(ca, d1, f1, None)
+        f2 = ops.empty_nhwc(b, h, w, 4, x)
+        d2 = pc(x, ep_coords=(cb, f2))
+    assert pc.fmt == 0      # fp32 rows: the vector-ALU kernel
+    assert torch.equal(d1, d2) and torch.equal(ca, cb) and torch.equal(f1, f2)
+
+
+def test_launch_timing_counts_the_lookup_dispatches(ops):
+    """ff_launch_timing_begin / _end: HIP events bound to each lookup dispatch (hipExtLaunchKernelGGL) - the count is the
+    number of launches in between, the durations are those of a real kernel (a few to a few hundred microseconds), and
+    nothing is timed once it is switched off."""
+    g = torch.Generator().manual_seed(2)
+    b, h, w = 2, 32, 40
+    f12 = torch.randn(2 * b, h, w, 256, generator=g).to(DEV)
+    pyr = ops.corr_build(f12[:b].contiguous(), f12[b:].contiguous())
+    coords = ops.coords_init(b, h, w, f12)
+    ops.launch_timing_begin(ops.TIME_LOOKUP)
+    for _ in range(5):
+        out = ops.corr_lookup_tiled(pyr, coords)
+    n, total, lo, hi = ops.launch_timing_end(ops.TIME_LOOKUP)
+    assert n == 5 and 0.5 < lo <= hi < 2000 and abs(total - 5 * (total / 5)) < 1e-6 and lo * 5 <= total * 1.0001 <= hi * 5 * 1.0001
+    ops.corr_lookup_tiled(pyr, coords)
+    assert ops.launch_timing_end(ops.TIME_LOOKUP)[0] == 0
+    assert torch.isfinite(out).all()
+
+
 def test_skip_unused_upsample_is_bit_identical(det_sd):
     """Opt-in inference shortcut: mask head + convex up-sampling for the last iteration only (the reference throws
     the other results away in test_mode, raft.py:226-236) must not change a single bit of either output."""
