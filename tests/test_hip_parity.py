@@ -650,6 +650,20 @@ def test_mask_conv_and_convex_upsampling_as_one_kernel(ops, b, h, w):
         ref = torch.sum(m * uf, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(b, 2, 8 * h, 8 * w)
     close(one.cpu(), two.cpu(), rtol=0, atol=1e-4, what="one launch vs conv + upsample")
     close(one.cpu(), ref, rtol=0, atol=2e-4, what="one launch vs torch")
+    # the one-term reduced-precision format through the same kernel (its TERMS = 1 instance): fp16 operand accuracy
+    prev = ops.conv_precision()
+    ops.set_conv_precision("f16")
+    try:
+        pc1 = cce.PackedConv([conv])
+        with torch.no_grad():
+            w1, b1 = pc1.get()
+            assert pc1.fmt == 2
+            one1 = ops.mask_upsample(hid[..., 256:], ops.mask_upsample_pack(w1), pc1.fmt, b1, flow, 0.25)
+            two1 = ops.upsample_flow(flow, pc1(hid[..., 256:], out_scale=0.25))
+    finally:
+        ops.set_conv_precision(prev)
+    close(one1.cpu(), two1.cpu(), rtol=0, atol=2e-3, what="one launch vs conv + upsample, f16 operands")
+    close(one1.cpu(), ref, rtol=0, atol=0.25, what="one launch, f16 operands, vs torch")
 
 
 def test_flow_head_takes_the_coordinate_step_bit_for_bit(ops):
