@@ -53,6 +53,39 @@ def test_conv_params_struct_layout(lib_path):
     assert FFConvParams.w.offset == off_w and FFConvParams.act_res.offset == off_ar
 
 
+def test_stats_parts_hint_is_host_logic(lib_path):
+    """ff_conv2d_stats_parts (no GPU work): which convolutions can deliver the InstanceNorm statistics of their output
+    from the epilogue, and how many partial entries per (image, channel) the caller must provide - 2 per 8 x 16 (or 4 x 16)
+    output tile of the patch kernel and of the 7x7 stride-2 stem kernel, 0 for everything else."""
+    from focusflow_official_amd import _hip
+    lib = ctypes.CDLL(lib_path)
+    lib.ff_conv2d_stats_parts.restype = ctypes.c_int
+    lib.ff_conv2d_stats_parts.argtypes = [ctypes.POINTER(_hip.FFConvParams)]
+
+    def parts(cin, cout, k, stride, b, h, w, fmt=_hip.W_F16X3, res2=False):
+        p = _hip.FFConvParams()
+        p.x[0], p.x_c[0], p.x_ld[0] = 4096, cin, cin          # fake, aligned pointers: nothing is dereferenced
+        p.w, p.y, p.y_ld = 4096, 4096, cout
+        p.groups, p.B, p.H, p.W, p.Cout = 1, b, h, w, cout
+        p.KH = p.KW = k
+        p.stride, p.pad_h, p.pad_w = stride, k // 2, k // 2
+        p.Ho, p.Wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+        p.w_format = fmt
+        if res2:
+            p.res2 = 4096
+        return lib.ff_conv2d_stats_parts(ctypes.byref(p))
+
+    assert parts(64, 64, 3, 1, 16, 192, 256) == 24 * 16 * 2          # 8-row tiles
+    assert parts(128, 128, 3, 1, 1, 46, 62) == 12 * 4 * 2            # few blocks: 4-row tiles, ragged plane
+    assert parts(4, 64, 7, 2, 16, 384, 512) == 24 * 16 * 2           # the stem: 192 x 256 output
+    assert parts(64, 64, 3, 1, 16, 192, 256, fmt=_hip.W_F16) == 24 * 16 * 2
+    assert parts(64, 64, 3, 1, 16, 192, 256, fmt=_hip.W_F32) == 0    # exact-fp32 rows: the generic kernel
+    assert parts(64, 96, 3, 2, 16, 192, 256) == 0                    # stride 2: im2col kernel
+    assert parts(64, 128, 1, 1, 16, 192, 256) == 0                   # 1x1
+    assert parts(48, 64, 3, 1, 2, 32, 32) == 0                       # Cin % 32 != 0
+    assert parts(64, 64, 3, 1, 16, 192, 256, res2=True) == 0
+
+
 def test_invalid_arguments_are_rejected_without_a_gpu(lib_path):
     """Argument validation happens before any launch, so it is testable here."""
     from focusflow_official_amd import _hip
