@@ -58,6 +58,7 @@ _SIGS = {
     "ff_corr_retile": [_fp, _fp, _ll, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_corr_tile_rows": [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_corr_lookup_tiled_fwd": [C.POINTER(_fp), C.c_int, _fp, _ll, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp],
+    "ff_corr_lookup_tiled_bwd_all": [_fp, C.POINTER(_fp), C.POINTER(_fp), C.c_int, C.c_int, _ll, C.c_int, C.c_int, _fp],
     "ff_corr_lookup_tiled_bwd": [C.POINTER(_fp), _fp, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
     "ff_corr_pyramid_tiled_bwd": [_fp, _fp, _fp, _fp, _ll, C.c_int, C.c_int, _fp],
     "ff_act_copy": [_fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],

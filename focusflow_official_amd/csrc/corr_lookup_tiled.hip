@@ -284,6 +284,11 @@ __global__ __launch_bounds__(64) void lookup_tiled_bwd_kernel(const TLookupBwdAr
         for (int e = lane; e < 4 * BTILES * 32; e += 64) win[e] = 0.f;
         __syncthreads();
         const float* drow = a.dout + q * a.dout_ld;
+        // the six gradient values of this lane in ONE round trip (a load under `if (k < 324)` is waited for before the next
+        // one is issued: six dependent L2 / HBM round trips per query were most of this kernel's time)
+        float gk[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) gk[j] = drow[min(lane + 64 * j, 323)];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int k = lane + 64 * j;
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(64) void lookup_tiled_bwd_kernel(const TLookupBwdAr
                 const int xo0 = tab_o[lv][0][0][ia], xo1 = tab_o[lv][0][1][ia];
                 const int yo0 = tab_o[lv][1][0][ib], yo1 = tab_o[lv][1][1][ib];
                 const float fx = tab_w[lv][0][ia], fy = tab_w[lv][1][ib];
-                const float g = drow[k];
+                const float g = gk[j];
                 const float ex = 1.f - fx, sy = 1.f - fy;
                 float* p = &win[lv * BTILES * 32];
                 atomicAdd(p + yo0 + xo0, g * (sy * ex));
@@ -303,39 +308,47 @@ __global__ __launch_bounds__(64) void lookup_tiled_bwd_kernel(const TLookupBwdAr
             }
         }
         __syncthreads();
-        // whole-tile read-modify-write: all loads first (lanes with nothing to add re-read a valid piece), then the stores
-        f32x4 cur[4][2], add[4][2];
-        long long idx[4][2];
+        // whole-tile read-modify-write, two levels at a time (registers: 3 -> 4-5 waves per SIMD; the kernel is a chain of
+        // dependent memory round trips per query, what it needs is more queries in flight): the loads of both levels
+        // first (lanes with nothing to add re-read a valid piece), then the stores; the addends come from the LDS image again
 #pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-            const int gx0 = geo[lv][0], gy0 = geo[lv][1], ntc = geo[lv][2], ntr = geo[lv][3];
-            const int ntx = a.ntx[lv], nty = a.nty[lv];
-            const float* pl = a.dlvl[lv] + q * a.plane_elems[lv];
+        for (int half = 0; half < 2; ++half) {
+            f32x4 cur[2][2];
+            int idx[2][2], wo[2][2], nvv[2][2];
 #pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-                const int nt = ntc * ntr;
-                const int k = min(k8 + 8 * rd, nt - 1);
-                const int tr = (k * (ntc == 3 ? 43 : (ntc == 2 ? 64 : 128))) >> 7, tc = k - tr * ntc;   // k / ntc, k < 12
-                const int gtx = gx0 + tc, gty = gy0 + tr;
-                const bool in = (unsigned)gtx < (unsigned)ntx && (unsigned)gty < (unsigned)nty && k8 + 8 * rd < nt;
-                const int ctx = min(max(gtx, 0), ntx - 1), cty = min(max(gty, 0), nty - 1);
-                const long long o = (long long)(cty * ntx + ctx) * 32 + piece * 4;
-                cur[lv][rd] = *reinterpret_cast<const f32x4*>(pl + o);
-                f32x4 v = *reinterpret_cast<const f32x4*>(&win[lv * BTILES * 32 + (tr * 3 + tc) * 32 + piece * 4]);
-                const int ey = gty * 4 + (piece >> 1), ex = gtx * 8 + (piece & 1) * 4;
-                const int nv = ((unsigned)ey < (unsigned)(a.h[0] >> lv)) ? min(max((a.w[0] >> lv) - ex, 0), 4) : 0;
+            for (int l2 = 0; l2 < 2; ++l2) {
+                const int lv = 2 * half + l2;
+                const int gx0 = geo[lv][0], gy0 = geo[lv][1], ntc = geo[lv][2], ntr = geo[lv][3];
+                const int ntx = a.ntx[lv], nty = a.nty[lv];
+                const float* pl = a.dlvl[lv] + q * a.plane_elems[lv];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) v[d] = d < nv ? v[d] : 0.f;
-                add[lv][rd] = v;
-                idx[lv][rd] = in ? o : -1;
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int nt = ntc * ntr;
+                    const int k = min(k8 + 8 * rd, nt - 1);
+                    const int tr = (k * (ntc == 3 ? 43 : (ntc == 2 ? 64 : 128))) >> 7, tc = k - tr * ntc;   // k / ntc, k < 12
+                    const int gtx = gx0 + tc, gty = gy0 + tr;
+                    const bool in = (unsigned)gtx < (unsigned)ntx && (unsigned)gty < (unsigned)nty && k8 + 8 * rd < nt;
+                    const int ctx = min(max(gtx, 0), ntx - 1), cty = min(max(gty, 0), nty - 1);
+                    const int o = (cty * ntx + ctx) * 32 + piece * 4;
+                    cur[l2][rd] = *reinterpret_cast<const f32x4*>(pl + o);
+                    const int ey = gty * 4 + (piece >> 1), ex = gtx * 8 + (piece & 1) * 4;
+                    nvv[l2][rd] = ((unsigned)ey < (unsigned)(a.h[0] >> lv)) ? min(max((a.w[0] >> lv) - ex, 0), 4) : 0;
+                    wo[l2][rd] = lv * BTILES * 32 + (tr * 3 + tc) * 32 + piece * 4;
+                    idx[l2][rd] = in ? o : -1;
+                }
             }
-        }
 #pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-            float* pl = a.dlvl[lv] + q * a.plane_elems[lv];
+            for (int l2 = 0; l2 < 2; ++l2) {
+                float* pl = a.dlvl[2 * half + l2] + q * a.plane_elems[2 * half + l2];
 #pragma unroll
-            for (int rd = 0; rd < 2; ++rd)
-                if (idx[lv][rd] >= 0) *reinterpret_cast<f32x4*>(pl + idx[lv][rd]) = cur[lv][rd] + add[lv][rd];
+                for (int rd = 0; rd < 2; ++rd)
+                    if (idx[l2][rd] >= 0) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(&win[wo[l2][rd]]);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) v[d] = d < nvv[l2][rd] ? v[d] : 0.f;
+                        *reinterpret_cast<f32x4*>(pl + idx[l2][rd]) = cur[l2][rd] + v;
+                    }
+            }
         }
         __syncthreads();
     }
@@ -384,6 +397,167 @@ __global__ __launch_bounds__(256) void pyramid_tiled_bwd_kernel(float* __restric
         for (int e = 0; e < 4; ++e)
             if (x + e < w0 && (y >> 1) < h1 && ((x + e) >> 1) < w1) v[e] += 0.25f * s1[(y >> 1) * w1 + ((x + e) >> 1)];
         *reinterpret_cast<f32x4*>(p0 + i * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Lookup backward of ALL iterations at once + the pooling backward chain: d(volume) of a query from the (coords_t, dout_t)
+// of every lookup that read it.  The gradient of the pyramid is a sum over the iterations and nothing needs it before the
+// corr build's own backward, so instead of twelve launches that each read-modify-write ~48 scattered tiles per query in a
+// 400 MB gradient pyramid (170 us each, 1.8 TB/s of scattered RMW traffic) plus a zero fill and a pooling pass, ONE block
+// per query keeps the query's four gradient planes in LDS (15 KB at 46 x 62), scatters the 324 x T gradients into them
+// (ds_add_f32), folds level 3 -> 2 -> 1 -> 0 (avg_pool2d backward: 0.25 to each of the four children) and writes level 0
+// once, in tile order, pad elements zero: dout is read once, d(volume) written once.
+// ---------------------------------------------------------------------------
+constexpr int LBA_MAXT = 32;
+struct LBAArgs {
+    const float* coords[LBA_MAXT];
+    const float* dout[LBA_MAXT];
+    int T, dout_ld;
+    float* d0;
+    long long queries;
+    ff::CorrLayout L;
+};
+
+// 384 threads; thread k < 324 owns output channel k (its gradient) of every iteration.  Per iteration:
+//   A  72 threads replay the coordinate chain of the 36 (level, offset) taps per axis into an LDS table and check, with
+//      a neighbour compare and a ballot, that the nine taps of a level are CONSECUTIVE integers (they are, unless the
+//      coordinate is so large that fp32 rounding skips or repeats a tap); the gradients go to LDS too;
+//   C  regular levels: the bilinear scatter is separable and every window element has exactly one writer -
+//        tmp[b][x] = g[x][b] (1 - fx[x]) + g[x-1][b] fx[x-1]     (9 x 10 per level),
+//      irregular levels: the plain scatter with LDS atomics;
+//   D  regular levels: plane[ylo + y][xlo + x] += tmp[y][x] (1 - fy[y]) + tmp[y-1][x] fy[y-1]   (10 x 10, no atomics).
+// The all-atomics form of this kernel took 1.28 ms per launch (355 M ds_add_f32 for 12 x 22 816 queries), whatever its
+// vector-instruction count or its memory round trips were.
+constexpr int LBA_THREADS = 384;
+__global__ __launch_bounds__(LBA_THREADS) void lookup_bwd_all_kernel(const LBAArgs a) {
+    extern __shared__ float sm[];
+    __shared__ int tab_i[2][36];             // [axis][level * 9 + offset]: first tap
+    __shared__ float tab_w[2][36];           //                           : weight of the second tap
+    __shared__ float gsh[324];
+    __shared__ float tmp[4][9][10];
+    __shared__ int regx[4], regy[4];         // per level: the nine taps of the axis are consecutive integers
+    __shared__ float cs[2 * LBA_MAXT];       // the query's coordinates of every iteration
+    const ff::CorrLayout& L = a.L;
+    const int h0 = L.h[0], w0 = L.w[0], h1 = L.h[1], w1 = L.w[1], h2 = L.h[2], w2 = L.w[2], h3 = L.h[3], w3 = L.w[3];
+    const int n0 = h0 * w0, n1 = h1 * w1, n2 = h2 * w2, n3 = h3 * w3, ntot = n0 + n1 + n2 + n3;
+    float* s0 = sm;
+    float* s1 = s0 + n0;
+    float* s2 = s1 + n1;
+    float* s3 = s2 + n2;
+    const int tid = threadIdx.x;
+    // table role: x axis = lanes 0..35 of wave 0, y axis = lanes 0..35 of wave 1 (a wave-local neighbour compare then tells
+    // whether the taps are consecutive); entry e = level * 9 + offset
+    const int t_axis = tid >> 6, t_e = min(tid & 63, 35), t_lv = t_e / 9, t_o = t_e - t_lv * 9;
+    const bool t_role = tid < 128 && (tid & 63) < 36;
+    const float t_inv = 1.f / (float)(1 << t_lv);
+    const int t_n = ((t_axis & 1) == 0 ? w0 : h0) >> t_lv;
+    // output role (tid < 324): k = level * 81 + a * 9 + b, a = x offset, b = y offset
+    const int k = min(tid, 323), lv = k / 81, rem = k - lv * 81, ia = rem / 9, ib = rem - ia * 9;
+    const int hl = h0 >> lv, wl = w0 >> lv;
+    float* pl = lv == 0 ? s0 : (lv == 1 ? s1 : (lv == 2 ? s2 : s3));
+    // stage-1 role (tid < 360): level c_lv, y offset c_b, window column c_x ; stage-2 roles: items tid and tid + 384 of 400
+    const int c_lv = min(tid / 90, 3), c_rem = tid - c_lv * 90, c_b = c_rem / 10, c_x = c_rem - c_b * 10;
+    for (long long q = blockIdx.x; q < a.queries; q += gridDim.x) {
+        // One round trip for all coordinates, one per FOUR iterations for the gradients (issued a group ahead).
+        for (int i = tid; i < ntot; i += LBA_THREADS) sm[i] = 0.f;
+        if (tid < 2 * a.T) cs[tid] = a.coords[tid >> 1][q * 2 + (tid & 1)];
+        float gc[4], gn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gc[j] = a.dout[min(j, a.T - 1)][q * a.dout_ld + k];
+        __syncthreads();
+        for (int t0 = 0; t0 < a.T; t0 += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gn[j] = a.dout[min(t0 + 4 + j, a.T - 1)][q * a.dout_ld + k];      // (clamped: unconditional loads)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = t0 + j;
+                if (t >= a.T) break;
+                // A (+ B: are the nine taps of a level consecutive?)
+                if (tid < 128) {
+                    int i0 = 0;
+                    float w1v = 0.f;
+                    if (t_role) {
+                        tap_1d(cs[t * 2 + t_axis], t_inv, t_o - 4, t_n, i0, w1v);
+                        tab_i[t_axis][t_e] = i0;
+                        tab_w[t_axis][t_e] = w1v;
+                    }
+                    const int prev = __shfl_up(i0, 1);
+                    const unsigned long long bad = __ballot(t_role && t_o > 0 && i0 != prev + 1);
+                    if ((tid & 63) < 4) (t_axis == 0 ? regx : regy)[tid & 63] = ((bad >> ((tid & 63) * 9)) & 0x1ffull) == 0;
+                }
+                if (tid < 324) gsh[tid] = gc[j];
+                __syncthreads();
+                // C
+                if (tid < 360 && regx[c_lv] && regy[c_lv]) {
+                    float v = 0.f;
+                    if (c_x < 9) v = gsh[c_lv * 81 + c_x * 9 + c_b] * (1.f - tab_w[0][c_lv * 9 + c_x]);
+                    if (c_x > 0) v += gsh[c_lv * 81 + (c_x - 1) * 9 + c_b] * tab_w[0][c_lv * 9 + c_x - 1];
+                    tmp[c_lv][c_b][c_x] = v;
+                }
+                if (tid < 324 && !(regx[lv] && regy[lv])) {
+                    const float g = gc[j];
+                    const int x0 = tab_i[0][lv * 9 + ia], y0 = tab_i[1][lv * 9 + ib];
+                    const float fx = tab_w[0][lv * 9 + ia], fy = tab_w[1][lv * 9 + ib];
+                    const float ex = 1.f - fx, sy = 1.f - fy;
+                    const bool x0ok = (unsigned)x0 < (unsigned)wl, x1ok = (unsigned)(x0 + 1) < (unsigned)wl;
+                    const bool y0ok = (unsigned)y0 < (unsigned)hl, y1ok = (unsigned)(y0 + 1) < (unsigned)hl;
+                    if (y0ok && x0ok) atomicAdd(pl + y0 * wl + x0, g * (sy * ex));
+                    if (y0ok && x1ok) atomicAdd(pl + y0 * wl + x0 + 1, g * (sy * fx));
+                    if (y1ok && x0ok) atomicAdd(pl + (y0 + 1) * wl + x0, g * (fy * ex));
+                    if (y1ok && x1ok) atomicAdd(pl + (y0 + 1) * wl + x0 + 1, g * (fy * fx));
+                }
+                __syncthreads();
+                // D
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int it = tid + rep * LBA_THREADS;
+                    if (it < 400) {
+                        const int dl = it / 100, dr = it - dl * 100, dy = dr / 10, dx = dr - dy * 10;
+                        if (regx[dl] && regy[dl]) {
+                            float v = 0.f;
+                            if (dy < 9) v = tmp[dl][dy][dx] * (1.f - tab_w[1][dl * 9 + dy]);
+                            if (dy > 0) v += tmp[dl][dy - 1][dx] * tab_w[1][dl * 9 + dy - 1];
+                            const int Y = tab_i[1][dl * 9] + dy, X = tab_i[0][dl * 9] + dx;
+                            const int hh = h0 >> dl, ww = w0 >> dl;
+                            float* pp = dl == 0 ? s0 : (dl == 1 ? s1 : (dl == 2 ? s2 : s3));
+                            if ((unsigned)Y < (unsigned)hh && (unsigned)X < (unsigned)ww) pp[Y * ww + X] += v;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gc[j] = gn[j];
+        }
+        for (int i = tid; i < n2; i += LBA_THREADS) {          // pyramid_tiled_bwd_kernel's chain, in LDS
+            const int y = i / w2, x = i - y * w2;
+            if ((y >> 1) < h3 && (x >> 1) < w3) s2[i] += 0.25f * s3[(y >> 1) * w3 + (x >> 1)];
+        }
+        __syncthreads();
+        for (int i = tid; i < n1; i += LBA_THREADS) {
+            const int y = i / w1, x = i - y * w1;
+            if ((y >> 1) < h2 && (x >> 1) < w2) s1[i] += 0.25f * s2[(y >> 1) * w2 + (x >> 1)];
+        }
+        __syncthreads();
+        float* p0 = a.d0 + q * L.plane[0];
+        const int n4 = L.plane[0] >> 2;
+        for (int i = tid; i < n4; i += LBA_THREADS) {          // level 0 in tile order: 4 consecutive x of one tile row per thread
+            const int tile = i >> 3, pc = i & 7;
+            const int y = (tile / L.ntx[0]) * 4 + (pc >> 1), x = (tile % L.ntx[0]) * 8 + (pc & 1) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y < h0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (x + e < w0) {
+                        float u = s0[y * w0 + x + e];
+                        if ((y >> 1) < h1 && ((x + e) >> 1) < w1) u += 0.25f * s1[(y >> 1) * w1 + ((x + e) >> 1)];
+                        v[e] = u;
+                    }
+            }
+            *reinterpret_cast<f32x4*>(p0 + i * 4) = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -457,9 +631,38 @@ extern "C" int ff_corr_lookup_tiled_bwd(float* const* dlevels, const float* coor
     a.dout = dout;
     a.dout_ld = dout_ld;
     a.queries = queries;
-    const long long blocks = queries < 256ll * 16 ? queries : 256ll * 16;
+    static const int bwd_wpc = getenv("FF_LOOKUP_BWD_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_BWD_WAVES_PER_CU")) : 20;
+    const long long blocks = queries < 256ll * bwd_wpc ? queries : 256ll * bwd_wpc;
     lookup_tiled_bwd_kernel<<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
     return ff::check_launch("ff_corr_lookup_tiled_bwd");
+}
+
+extern "C" int ff_corr_lookup_tiled_bwd_all(float* d0, const float* const* coords_list, const float* const* dout_list, int T, int dout_ld,
+                                            long long queries, int h0, int w0, void* stream) {
+    FF_REQUIRE(d0 && coords_list && dout_list && T > 0 && queries > 0 && dout_ld >= 324 && ff::aligned16(d0), "ff_corr_lookup_tiled_bwd_all: bad argument");
+    FF_REQUIRE((h0 >> 3) >= 2 && (w0 >> 3) >= 2, "ff_corr_lookup_tiled_bwd_all: level 3 must be at least 2x2");
+    if (T > LBA_MAXT) return 1;                       // more lookups than the argument block holds: the caller goes launch by launch
+    LBAArgs a;
+    a.L = ff::corr_layout(h0, w0, false);
+    const size_t lds = (size_t)(a.L.h[0] * a.L.w[0] + a.L.h[1] * a.L.w[1] + a.L.h[2] * a.L.w[2] + a.L.h[3] * a.L.w[3]) * sizeof(float);
+    if (lds > 64 * 1024) return 1;                    // the four planes of a query do not fit: launch by launch
+    for (int t = 0; t < T; ++t) {
+        FF_REQUIRE(coords_list[t] && dout_list[t], "ff_corr_lookup_tiled_bwd_all: null entry %d", t);
+        a.coords[t] = coords_list[t];
+        a.dout[t] = dout_list[t];
+    }
+    a.T = T;
+    a.dout_ld = dout_ld;
+    a.d0 = d0;
+    a.queries = queries;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lookup_bwd_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr = true;
+    }
+    const long long blocks = queries < 256ll * 64 ? queries : 256ll * 64;
+    lookup_bwd_all_kernel<<<(unsigned)blocks, LBA_THREADS, lds, static_cast<hipStream_t>(stream)>>>(a);
+    return ff::check_launch("ff_corr_lookup_tiled_bwd_all");
 }
 
 extern "C" int ff_corr_pyramid_tiled_bwd(float* d0, float* d1, float* d2, const float* d3, long long planes, int h0, int w0,

@@ -143,6 +143,7 @@ class ParamGate(torch.autograd.Function):
 
 
 _scope: Optional[GraphScope] = None
+_LOOKUP_BWD_ALL = os.environ.get("FF_LOOKUP_BWD_ALL", "1") != "0"   # A/B switch: one lookup-backward launch per pass instead of one per iteration
 _ZERO_ARENA = os.environ.get("FF_ZERO_ARENA", "1") != "0"    # A/B switch: one zero fill per pass for the backward's accumulation buffers
 _AMAX_HINT = os.environ.get("FF_AMAX_HINT", "1") != "0"      # A/B switch: the norm backward measures max|dx| for the conv it feeds
 
@@ -365,12 +366,24 @@ class CorrBuildFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dtoken):
         f1, f2 = ctx.saved_tensors
-        gp = ctx.block.grad_pyr
+        blk = ctx.block
+        b, h, w, _ = f1.shape
+        pending, blk.pending = getattr(blk, "pending", None), None
+        if pending:
+            # every lookup of the pass in one launch (+ the pooling chain), if the planes of a query fit LDS
+            d0 = ops.corr_lookup_tiled_bwd_all([c for c, _ in pending], [d for _, d in pending], blk.pyr.h0, blk.pyr.w0) if _LOOKUP_BWD_ALL else None
+            if d0 is None:
+                blk.grad_pyr = ops.TiledPyramid.empty(blk.pyr.levels[0].shape[0], blk.pyr.h0, blk.pyr.w0, False, f1.device, zero=True)
+                for c, d in pending:
+                    ops.corr_lookup_tiled_bwd(blk.grad_pyr, c, d)
+            else:
+                df1, df2 = ops.corr_volume_bwd(d0.view(b, h * w, -1), f1, f2, tiled=True)
+                return df1, df2, None, None
+        gp = blk.grad_pyr
         if gp is None:
             return torch.zeros_like(f1), torch.zeros_like(f2), None, None
         ops.corr_pyramid_tiled_bwd(gp)
-        ctx.block.grad_pyr = None
-        b, h, w, _ = f1.shape
+        blk.grad_pyr = None
         df1, df2 = ops.corr_volume_bwd(gp.levels[0].view(b, h * w, -1), f1, f2, tiled=True)
         return df1, df2, None, None
 
@@ -386,10 +399,11 @@ class LookupFn(torch.autograd.Function):
     def backward(ctx, dout):
         (coords,) = ctx.saved_tensors
         blk = ctx.block
-        if blk.grad_pyr is None:
-            pyr = blk.pyr
-            blk.grad_pyr = ops.TiledPyramid.empty(pyr.levels[0].shape[0], pyr.h0, pyr.w0, False, dout.device, zero=True)
-        ops.corr_lookup_tiled_bwd(blk.grad_pyr, coords, _dense(dout))
+        # deferred: the gradient of the pyramid is a sum over the lookups and nothing reads it before CorrBuildFn.backward,
+        # which scatters all of them in one launch (ops.corr_lookup_tiled_bwd_all)
+        if getattr(blk, "pending", None) is None:
+            blk.pending = []
+        blk.pending.append((coords, _dense(dout)))
         return torch.zeros(1, device=dout.device), None, None
 
 

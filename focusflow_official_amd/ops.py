@@ -814,6 +814,26 @@ def corr_lookup_tiled_bwd(dpyr: TiledPyramid, coords: Tensor, dout: Tensor):
     _hip.call("ff_corr_lookup_tiled_bwd", dpyr.ptrs(), _p(coords), _p(dout), _ld(dout), b * h * w, dpyr.h0, dpyr.w0, _stream())
 
 
+def corr_lookup_tiled_bwd_all(coords_list, dout_list, h0: int, w0: int):
+    """d(volume) [B*Q][plane_0] (tiled fp32) from every lookup of a pass at once (ff_corr_lookup_tiled_bwd_all), or None
+    when the kernel declines (planes too large for LDS, more than 32 lookups): the caller then goes launch by launch."""
+    n = len(coords_list)
+    b, h, w, _ = coords_list[0].shape
+    q = b * h * w
+    ld = _ld(dout_list[0])
+    assert all(c.is_contiguous() and c.shape == (b, h, w, 2) for c in coords_list) and all(_ld(d) == ld for d in dout_list)
+    d0 = torch.empty((q, TiledPyramid.plane_elems(h0, w0, 0, False)), dtype=torch.float32, device=coords_list[0].device)
+    cl = (C.c_void_p * n)(*[c.data_ptr() for c in coords_list])
+    dl = (C.c_void_p * n)(*[d.data_ptr() for d in dout_list])
+    lib = _hip.load()
+    rc = lib.ff_corr_lookup_tiled_bwd_all(_p(d0), cl, dl, n, ld, q, h0, w0, _stream())
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise _hip.FocusFlowHipError(f"ff_corr_lookup_tiled_bwd_all failed ({rc}): {lib.ff_last_error().decode()}")
+    return d0
+
+
 def corr_pyramid_tiled_bwd(dpyr: TiledPyramid):
     """avg_pool2d backward chain, in place: afterwards dpyr.levels[0] is d(volume) in tile order."""
     lv = dpyr.levels

@@ -51,7 +51,8 @@ const char* ff_last_error(void);
  *   2 (round 2): FFConvParams + res2, res2_ld, res_split, splitk_ws, splitk; ff_norm_bwd + dx_amax; ff_corr_lookup_bwd and
  *                ff_corr_pyramid_bwd (row-major) removed
  *   3 (round 3): FFConvParams + ep_mode, ep_split, ep_a, ep_a_ld, ep_b, ep_b_ld, stats_part; + ff_conv2d_stats_parts,
- *                ff_norm_stats_finish, ff_launch_timing_begin / _end, ff_mask_upsample_pack / _fwd */
+ *                ff_norm_stats_finish, ff_launch_timing_begin / _end, ff_mask_upsample_pack / _fwd,
+ *                ff_corr_lookup_tiled_bwd_all */
 #define FF_ABI_VERSION 3
 int ff_abi_version(void);
 
@@ -254,6 +255,14 @@ int ff_corr_lookup_tiled_fwd(const void* const* levels /* HOST array of 4 device
                              float* out, int out_ld, int* taps_dbg, void* stream);
 int ff_corr_lookup_tiled_bwd(float* const* dlevels /* HOST array */, const float* coords, const float* dout,
                              int dout_ld, long long queries, int h0, int w0, void* stream);
+/* The lookup backward of ALL T iterations of a CorrBlock at once + the avg_pool2d backward chain: d0 [queries][plane_0]
+ * (tiled fp32, every element written - no zero fill needed) = d(volume) from coords_list[t] ([queries][2]) and
+ * dout_list[t] ([queries][dout_ld >= 324]), t < T <= 32 (both HOST arrays of device pointers).  One block per query
+ * keeps its four gradient planes in LDS: returns 1 (nothing launched) when they do not fit 64 KB or T > 32 - then call
+ * ff_corr_lookup_tiled_bwd per iteration and ff_corr_pyramid_tiled_bwd.  Replaces T launches of the former + one of the
+ * latter + the zero fill (corr.py:29-50 backward, :24-27 backward). */
+int ff_corr_lookup_tiled_bwd_all(float* d0, const float* const* coords_list, const float* const* dout_list, int T, int dout_ld,
+                                 long long queries, int h0, int w0, void* stream);
 int ff_corr_pyramid_tiled_bwd(float* d0, float* d1, float* d2, const float* d3, long long planes, int h0, int w0,
                               void* stream);
 
