@@ -223,6 +223,38 @@ def test_update_block_step_backward_against_fp64(det_sd):
         close(params[n].grad.cpu(), s2[pre + "." + n].grad, rtol=0, atol_rel=5e-5, what=n)
 
 
+def test_lookup_backward_of_all_iterations_in_one_launch():
+    """ff_corr_lookup_tiled_bwd_all (scatter of every iteration + pooling chain, planes of a query in LDS, separable
+    atomic-free path for consecutive taps) against the route it replaces - zero fill, one ff_corr_lookup_tiled_bwd per
+    iteration, ff_corr_pyramid_tiled_bwd - on ragged planes, with coordinates far outside the plane and coordinates so
+    large that fp32 skips taps (the irregular path), and T that is not a multiple of four; planes too large for LDS
+    are declined (None)."""
+    from focusflow_official_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (b, h, w, T) in [(2, 16, 24, 5), (1, 23, 31, 12), (1, 46, 62, 3)]:
+        f = torch.randn(b, h, w, 8, generator=g).to(DEV)
+        base = ops.coords_init(b, h, w, f)
+        cl, dl = [], []
+        for t in range(T):
+            c = base + (torch.rand(base.shape, generator=g) * 10 - 5).to(DEV)
+            c[0, 0, 0] = torch.tensor([-37.25, 1e6]).to(DEV)            # far outside / huge
+            c[0, 1, 2] = torch.tensor([3e7, 2.5]).to(DEV)               # fp32 spacing > 1: taps repeat
+            c[0, 2, 1] = torch.tensor([float(w) + 3.5, -2.75]).to(DEV)
+            cl.append(c.contiguous())
+            dl.append(torch.randn(b, h, w, 324, generator=g).to(DEV))
+        d0 = ops.corr_lookup_tiled_bwd_all(cl, dl, h, w)
+        assert d0 is not None
+        dp = ops.TiledPyramid.empty(b * h * w, h, w, False, f.device, zero=True)
+        for c, d in zip(cl, dl):
+            ops.corr_lookup_tiled_bwd(dp, c, d)
+        ops.corr_pyramid_tiled_bwd(dp)
+        ref = dp.levels[0]
+        assert d0.shape == ref.shape
+        close(d0.cpu(), ref.cpu(), rtol=0, atol_rel=2e-5, what=f"d(volume) {b}x{h}x{w} T={T}")
+    big = ops.coords_init(1, 128, 160, f)
+    assert ops.corr_lookup_tiled_bwd_all([big], [torch.zeros(1, 128, 160, 324, device=DEV)], 128, 160) is None
+
+
 @pytest.mark.parametrize("h,w,half", [(16, 24, False), (17, 19, False), (20, 16, True)], ids=["16x24", "17x19-odd", "20x16-fp16"])
 def test_corr_block_backward(mods, h, w, half):
     """d(loss)/d(fmap1, fmap2) through volume -> pyramid -> 3 lookups at different coords (tiled gradient planes:
