@@ -399,17 +399,18 @@ def secondary_measurements(args, device):
         targs = copy.copy(args)
         targs.batch, targs.height, targs.width, targs.iters = 8, 384, 512, 12      # -> 368 x 496 crops (train_setup)
         step, h, w = train_setup(targs, 1, 0, 0, device)
-        for _ in range(2):
+        nw = 4          # (the caching allocator and the backward's zero arena settle over the first three steps)
+        for _ in range(nw):
             step()
         torch.cuda.synchronize()
-        n = 3
+        n = 5
         t0 = time.perf_counter()
         for _ in range(n):
             loss = step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         out["train_step"] = {"metric": f"training frame-pairs/sec FF-RAFT {h}x{w} iters=12 (fwd+MixLoss+bwd+clip+AdamW)",
-                             "value": round(8 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 2), "steps": n, "warmup": 2,
+                             "value": round(8 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 2), "steps": n, "warmup": nw,
                              "workload": "BASELINE configs[2] shape on ONE GPU: 8 pairs, MixLoss, no DDP", "finite_loss": bool(torch.isfinite(loss))}
         del step
     except Exception as e:          # noqa: BLE001 - reported, never fatal for the headline line
