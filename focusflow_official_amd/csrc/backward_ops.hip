@@ -2,6 +2,8 @@
 // (SURVEY §3.3): activation masks, Instance/BatchNorm backward, GRU gates,
 // convex-upsampling backward.  All HBM-bound.  (Lookup / pooling backward: corr_lookup_tiled.hip.)
 #include "ff_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -60,18 +62,38 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const float* dy, int d
     const unsigned cg = (unsigned)Cpad >> 2, cgin = (unsigned)C >> 2;
     const unsigned total = npix * cg;
     float mx = 0.f;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const unsigned p = i / cg, c4 = i - p * cg;
-        const unsigned cc = min(c4, cgin - 1);          // padding groups re-read the last real one and store zeros
-        f32x4 v = *reinterpret_cast<const f32x4*>(dy + (size_t)p * dy_ld + cc * 4) * scale;
-        if (HAS_ACT) {
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + (size_t)p * y_ld + cc * 4);
+    // four items per trip, all eight loads first: one item per trip left a thread with two loads in flight and the kernel
+    // at 2 TB/s (35 us for the 70 MB of a 22 816 x 256 gradient)
+    const unsigned stride = gridDim.x * 256u;
+    for (unsigned i0 = blockIdx.x * 256u + threadIdx.x; i0 < total; i0 += 4u * stride) {
+        f32x4 v[4], yv[4];
+        unsigned off_g[4];
+        bool live[4], pad[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_output(yv[j], act);
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * stride;
+            live[u] = i < total;
+            const unsigned ic = live[u] ? i : total - 1;             // (clamped: unconditional loads)
+            const unsigned p = ic / cg, c4 = ic - p * cg;
+            const unsigned cc = min(c4, cgin - 1);                    // padding groups re-read the last real one and store zeros
+            pad[u] = c4 >= cgin;
+            v[u] = *reinterpret_cast<const f32x4*>(dy + (size_t)p * dy_ld + cc * 4);
+            if (HAS_ACT) yv[u] = *reinterpret_cast<const f32x4*>(y + (size_t)p * y_ld + cc * 4);
+            off_g[u] = p * (unsigned)g_ld + c4 * 4;
         }
-        if (c4 >= cgin) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (g != dy) *reinterpret_cast<f32x4*>(g + (size_t)p * g_ld + c4 * 4) = v;     // g == dy: only max|dy| is wanted
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 w = v[u] * scale;
+            if (HAS_ACT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] *= act_grad_from_output(yv[u][j], act);
+            }
+            if (pad[u]) w = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (live[u]) {
+                if (g != dy) *reinterpret_cast<f32x4*>(g + off_g[u]) = w;     // g == dy: only max|dy| is wanted
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
+            }
+        }
     }
     if (amax) {
         __shared__ float wmax[4];
@@ -357,10 +379,13 @@ extern "C" int ff_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, 
     FF_REQUIRE(act == FF_ACT_NONE || (y && y_ld >= C), "ff_act_bwd: activation needs the forward output");
     const bool vec = C % 4 == 0 && Cpad % 4 == 0 && dy_ld % 4 == 0 && g_ld % 4 == 0 && ff::aligned16(dy) && ff::aligned16(g) &&
                      (act == FF_ACT_NONE || (y_ld % 4 == 0 && ff::aligned16(y))) && npix * (Cpad / 4) < (1ll << 31);
+    // (four items per thread and trip; at most FF_ACT_BWD_BLOCKS blocks: every block ends in an atomicMax on ONE word)
+    static const int cap = getenv("FF_ACT_BWD_BLOCKS") ? atoi(getenv("FF_ACT_BWD_BLOCKS")) : 512;
+    const int gv = (int)std::min<long long>(std::max<long long>((npix * (Cpad / 4) + 1023) / 1024, 1), cap);
     if (vec && act == FF_ACT_NONE)
-        act_bwd_vec_kernel<false><<<grid_for(npix * (Cpad / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(dy, dy_ld, y, y_ld, g, g_ld, (unsigned)npix, C, Cpad, act, scale, amax);
+        act_bwd_vec_kernel<false><<<gv, 256, 0, static_cast<hipStream_t>(stream)>>>(dy, dy_ld, y, y_ld, g, g_ld, (unsigned)npix, C, Cpad, act, scale, amax);
     else if (vec)
-        act_bwd_vec_kernel<true><<<grid_for(npix * (Cpad / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(dy, dy_ld, y, y_ld, g, g_ld, (unsigned)npix, C, Cpad, act, scale, amax);
+        act_bwd_vec_kernel<true><<<gv, 256, 0, static_cast<hipStream_t>(stream)>>>(dy, dy_ld, y, y_ld, g, g_ld, (unsigned)npix, C, Cpad, act, scale, amax);
     else
         act_bwd_kernel<<<grid_for(npix * Cpad), 256, 0, static_cast<hipStream_t>(stream)>>>(dy, dy_ld, y, y_ld, g, g_ld, npix, C, Cpad, act, scale, amax);
     return ff::check_launch("ff_act_bwd");
