@@ -419,7 +419,10 @@ extern "C" int ff_norm_bwd(const float* x, int x_ld, const float* dy, int dy_ld,
     dim3 g1((HW + NSLAB - 1) / NSLAB, B);
     norm_bwd_stats_kernel<<<g1, 256, 0, s>>>(a);
     int gx = (int)(((long long)HW * (C / 4) + 255) / 256);
-    if (gx > 1024) gx = 1024;
+    // at most ~FF_NORM_BWD_BLOCKS blocks in all when max|dx| is wanted: every block then ends in an atomicMax on ONE word
+    static const int cap = getenv("FF_NORM_BWD_BLOCKS") ? atoi(getenv("FF_NORM_BWD_BLOCKS")) : 1024;
+    const int gmax = dx_amax ? std::max(1, cap / B) : 1024;
+    if (gx > gmax) gx = gmax;
     norm_bwd_apply_kernel<<<dim3(gx, B), 256, 0, s>>>(a);
     return ff::check_launch("ff_norm_bwd");
 }
