@@ -129,18 +129,22 @@ __device__ __forceinline__ int row_bcast8(int v) {
 
 // ABL: timing-only ablation bits (FF_LOOKUP_ABLATE3, WRONG results): 1 no output stores, 4 no blend, 8 no tap chains inside
 // the loop, 16 no DMA inside the loop.
-template <bool HALF, bool DBG, int ABL = 0>
-__global__ __launch_bounds__(64) void lookup_dma_kernel(const DArgs a) {
+// NW: query-waves per block (1 or 4).  Every wave keeps its private WAVE_LDS bytes and never meets the others (no barrier):
+// four-wave blocks only quarter the number of workgroups the dispatcher has to place (4 096 -> 1 024 per launch).
+template <bool HALF, bool DBG, int ABL = 0, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void lookup_dma_kernel(const DArgs a) {
     constexpr int TSH = HALF ? 3 : 2, TH = 1 << TSH, ESZ = HALF ? 2 : 4;
     constexpr int CSH = HALF ? 3 : 2;            // log2(columns per 16-byte chunk)
     constexpr int DATA_CH = HALF ? 3 : 4;        // chunks of a window row that carry data
     constexpr int XMAX = DATA_CH * (1 << CSH) - 2;
     constexpr int ROWB = 8 * ESZ;                // bytes of one tile row
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // WAVE_LDS bytes, addressed absolutely below (base 0)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NW * WAVE_LDS bytes, addressed absolutely below (base 0)
     asm volatile("" ::"v"((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem));
 
-    const int lane = threadIdx.x;
-    const unsigned wave = blockIdx.x, nwaves = gridDim.x;
+    const int lane = NW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    const unsigned wib = NW == 1 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned wbase = wib * WAVE_LDS;                                 // this wave's LDS region
+    const unsigned wave = blockIdx.x * NW + wib, nwaves = gridDim.x * NW;
     const unsigned count = a.qdiv + (wave < a.qrem ? 1u : 0u);             // the grid never exceeds the queries: count >= 1
     const unsigned qlast = wave + (count - 1) * nwaves;
     typedef const __attribute__((address_space(4))) f32x2* ccoords_t;     // scalar loads: off the vector memory counter
@@ -150,8 +154,10 @@ __global__ __launch_bounds__(64) void lookup_dma_kernel(const DArgs a) {
     // ---- launch-independent lane roles (five 16-byte loads from the code object's table) ----
     const u32x4* tp = reinterpret_cast<const u32x4*>(&g_lane_tab.v[lane][0]);
     const u32x4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3], t4 = tp[4];
-    const unsigned d_row[4] = {t0.x, t0.y, t0.z, t0.w}, d_col[4] = {t1.x, t1.y, t1.z, t1.w};
-    const unsigned bx[6] = {t2.x, t2.y, t2.z, t2.w, t3.x, t3.y}, by[6] = {t3.z, t3.w, t4.x, t4.y, t4.z, t4.w};
+    const unsigned d_row[4] = {t0.x + wbase, t0.y + wbase, t0.z + wbase, t0.w + wbase};
+    const unsigned d_col[4] = {t1.x + wbase, t1.y + wbase, t1.z + wbase, t1.w + wbase};
+    const unsigned bx[6] = {t2.x + wbase, t2.y + wbase, t2.z + wbase, t2.w + wbase, t3.x + wbase, t3.y + wbase};
+    const unsigned by[6] = {t3.z + wbase, t3.w + wbase, t4.x + wbase, t4.y + wbase, t4.z + wbase, t4.w + wbase};
 
     // ---- per-lane constants of the level row (lanes 16 l .. 16 l + 15 = level l): selected from the host's tables ----
     const int lv = lane >> 4, li = lane & 15;
@@ -177,15 +183,15 @@ __global__ __launch_bounds__(64) void lookup_dma_kernel(const DArgs a) {
     // against an empty grid (always out of range) and write a word that is out of range anyway.
     const unsigned nty_r = li < ROWS ? (unsigned)nty : 0u, ntx_c = li < DATA_CH ? (unsigned)ntx : 0u;
     const unsigned rstride = (unsigned)ntx * 128u;
-    const unsigned row_w = li < ROWS ? OFF_ROW + (lv * ROWS + li) * 4 : OFF_ROW_OOB;
-    const unsigned col_w = OFF_COL + (lv * 8 + min(li, 7)) * 4;           // li >= 8 rewrites chunk 7 (never read) with OOB
+    const unsigned row_w = wbase + (li < ROWS ? OFF_ROW + (lv * ROWS + li) * 4 : OFF_ROW_OOB);
+    const unsigned col_w = wbase + OFF_COL + (lv * 8 + min(li, 7)) * 4;           // li >= 8 rewrites chunk 7 (never read) with OOB
     // tap entries: lanes that are no tap lanes write theirs to a scratch place - the padding chunk of a window row of the
     // same buffer (idle while the taps run, never read) - so that the loop body has no exec-masked branch
-    const unsigned tab_x = OFF_TAB + (lv * 9 + min(li, 8)) * 8;
-    const unsigned scratch = (lv * 7 + max(li - 9, 0)) * PITCH + 64;
+    const unsigned tab_x = wbase + OFF_TAB + (lv * 9 + min(li, 8)) * 8;
+    const unsigned scratch = wbase + (lv * 7 + max(li - 9, 0)) * PITCH + 64;
     const unsigned tab_wx0 = is_tap ? tab_x : scratch, tab_wy0 = is_tap ? tab_x + 288 : scratch + 8;
     const unsigned tab_wx1 = tab_wx0 + (is_tap ? TAB : WIN), tab_wy1 = tab_wy0 + (is_tap ? TAB : WIN);
-    const unsigned win_lv = lv * LVL_BYTES;
+    const unsigned win_lv = wbase + lv * LVL_BYTES;
     // stores: pairs (2 L + 128 p, + 1) for p = 0, 1, 2; the third pair exists for lanes 0..33 only (channels 256..323)
     const unsigned st2 = lane < 34 ? (unsigned)(lane * 8 + 1024) : OOB;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.base), 0, (int)a.total_bytes, 0x00020000);
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(64) void lookup_dma_kernel(const DArgs a) {
         unsigned s[NDMA];
 #pragma unroll
         for (int d = 0; d < NDMA; ++d) s[d] = __builtin_elementwise_add_sat(lds_ld<unsigned>(d_row[d]), lds_ld<unsigned>(d_col[d]));
-        const unsigned dst = buf * WIN;
+        const unsigned dst = wbase + buf * WIN;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
                      "buffer_load_dwordx4 %1, %5, 0 offen lds\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
@@ -344,7 +350,10 @@ __global__ __launch_bounds__(64) void lookup_dma_kernel(const DArgs a) {
             const unsigned q2 = min(q + 2 * nwaves, qlast);
             const f32x2 c2 = cptr[q2];
             if (!(ABL & 16)) dma(P ^ 1, has1 ? rs_in : rs_null);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            // the window of query k: everything older than {the three output stores of query k - 1, the NDMA instructions
+            // just issued} (vector-memory operations complete in issue order on gfx9: stores need not be waited for)
+            if ((ABL & 1) || (P == 0 && k == 0)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 3) : "memory");
             blend_and_taps(q, q2, c2.x, c2.y, P);
             q += nwaves;
         }
@@ -397,25 +406,33 @@ int lookup_dma_fwd(const void* const* levels, int half, const float* coords, lon
     const int wpc = env_wpc > 0 && env_wpc <= 16 ? env_wpc : 16;
     long long waves = 256ll * wpc;
     if (waves > queries) waves = queries;
-    const unsigned blocks = (unsigned)waves;
+    // FF_LOOKUP_BLOCK_WAVES=4 (opt-in A/B switch): four query-waves per block.  Measured on 8 x 48 x 64 queries inside
+    // bench.py: 19.9 us per launch either way - placing 4 096 one-wave workgroups is not what the ramp costs.
+    static const int env_bw = getenv("FF_LOOKUP_BLOCK_WAVES") ? atoi(getenv("FF_LOOKUP_BLOCK_WAVES")) : 1;
+    const bool quad = env_bw == 4 && waves % 4 == 0 && waves >= 1024 && !taps_dbg;
+    const unsigned blocks = (unsigned)(quad ? waves / 4 : waves);
     a.qdiv = (unsigned)(queries / waves);
     a.qrem = (unsigned)(queries % waves);
-#define FF_LAUNCH(H_, D_) FF_LAUNCH3(H_, D_, 0)
     hipEvent_t ev0, ev1;          // null unless ff_launch_timing_begin(FF_TIME_LOOKUP) is in effect
     launch_timing_events(FF_TIME_LOOKUP, &ev0, &ev1);
-#define FF_LAUNCH3(H_, D_, A_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, D_, A_>), dim3(blocks), dim3(64), WAVE_LDS, s, ev0, ev1, 0, a)
+#define FF_LAUNCH3(H_, D_, A_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, D_, A_, 1>), dim3(blocks), dim3(64), WAVE_LDS, s, ev0, ev1, 0, a)
+#define FF_LAUNCH4(H_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, false, 0, 4>), dim3(blocks), dim3(256), 4 * WAVE_LDS, s, ev0, ev1, 0, a)
+#define FF_LAUNCH(H_, D_) FF_LAUNCH3(H_, D_, 0)
     const char* abl_s = getenv("FF_LOOKUP_ABLATE3");
     const int abl = abl_s ? atoi(abl_s) : 0;
-#define FF_ABL(V_) if (abl == V_ && !half) { FF_LAUNCH3(false, false, V_); return check_launch("ff_corr_lookup_tiled_fwd (dma, ablated)"); }
+#define FF_ABL(V_) if (abl == V_ && !half && !quad) { FF_LAUNCH3(false, false, V_); return check_launch("ff_corr_lookup_tiled_fwd (dma, ablated)"); }
     FF_ABL(1) FF_ABL(4) FF_ABL(8) FF_ABL(16) FF_ABL(20) FF_ABL(28) FF_ABL(12)
 #undef FF_ABL
-    if (half) {
+    if (quad) {
+        if (half) FF_LAUNCH4(true); else FF_LAUNCH4(false);
+    } else if (half) {
         if (taps_dbg) FF_LAUNCH(true, true); else FF_LAUNCH(true, false);
     } else {
         if (taps_dbg) FF_LAUNCH(false, true); else FF_LAUNCH(false, false);
     }
 #undef FF_LAUNCH
 #undef FF_LAUNCH3
+#undef FF_LAUNCH4
     return check_launch("ff_corr_lookup_tiled_fwd (dma)");
 }
 
