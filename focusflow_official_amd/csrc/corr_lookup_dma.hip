@@ -71,12 +71,15 @@ constexpr int NPOS = 4 * ROWS * CH;          // 240 pieces per query
 constexpr int NDMA = 4;                      // 256 lanes: the last 16 write 256 bytes of spill behind the window
 constexpr int WIN = 4096;                    // window stride: 3840 bytes + spill
 constexpr int TAB = 2 * 36 * 8;              // x entries, then y entries (8 bytes each: LDS offset, weight of tap 1)
-constexpr int OFF_TAB = 2 * WIN;             // two table buffers
-constexpr int OFF_ROW = OFF_TAB + 2 * TAB;   // row offsets  [4][12] + one word that is always out of range
+constexpr int OFF_ROW = 0;                   // row offsets  [4][12] + one word that is always out of range
 constexpr int OFF_ROW_OOB = OFF_ROW + 48 * 4;
 constexpr int OFF_COL = OFF_ROW + 52 * 4;    // chunk offsets [4][8]
-constexpr int WAVE_LDS = OFF_COL + 32 * 4;   // 9680 bytes
-static_assert(WAVE_LDS * 16 <= 160 * 1024, "16 waves per CU");
+constexpr int OFF_TAB = OFF_COL + 32 * 4;    // NBUF table buffers, then NBUF windows (NBUF - 1 = queries in flight ahead of the blend)
+constexpr int off_win(int nbuf) { return OFF_TAB + nbuf * TAB; }
+constexpr int wave_lds(int nbuf) { return off_win(nbuf) + nbuf * WIN; }
+static_assert(wave_lds(2) == 9680 && wave_lds(2) * 16 <= 160 * 1024, "two buffers: 16 waves per CU");
+static_assert(wave_lds(3) == 14352 && wave_lds(3) * 11 <= 160 * 1024, "three buffers: 11 waves per CU");
+static_assert(off_win(2) % 16 == 0 && off_win(3) % 16 == 0 && OFF_TAB % 16 == 0, "DMA destinations are 16-byte aligned");
 
 
 // ---- per-lane constants that do not depend on the launch: a table in the code object ----
@@ -131,8 +134,11 @@ __device__ __forceinline__ int row_bcast8(int v) {
 // the loop, 16 no DMA inside the loop.
 // NW: query-waves per block (1 or 4).  Every wave keeps its private WAVE_LDS bytes and never meets the others (no barrier):
 // four-wave blocks only quarter the number of workgroups the dispatcher has to place (4 096 -> 1 024 per launch).
-template <bool HALF, bool DBG, int ABL = 0, int NW = 1>
+// NBUF: window + table buffers of a wave; the DMA of query k + NBUF - 1 is issued before the blend of query k.
+template <bool HALF, bool DBG, int ABL = 0, int NW = 1, int NBUF = 2>
 __global__ __launch_bounds__(64 * NW) void lookup_dma_kernel(const DArgs a) {
+    constexpr int WAVE_LDS = wave_lds(NBUF), OFF_WIN = off_win(NBUF), D = NBUF - 1;
+    static_assert(ABL == 0 || NBUF == 2, "the ablations exist for the two-buffer kernel");
     constexpr int TSH = HALF ? 3 : 2, TH = 1 << TSH, ESZ = HALF ? 2 : 4;
     constexpr int CSH = HALF ? 3 : 2;            // log2(columns per 16-byte chunk)
     constexpr int DATA_CH = HALF ? 3 : 4;        // chunks of a window row that carry data
@@ -149,7 +155,9 @@ __global__ __launch_bounds__(64 * NW) void lookup_dma_kernel(const DArgs a) {
     const unsigned qlast = wave + (count - 1) * nwaves;
     typedef const __attribute__((address_space(4))) f32x2* ccoords_t;     // scalar loads: off the vector memory counter
     const ccoords_t cptr = (ccoords_t)(a.coords);
-    const f32x2 c0 = cptr[wave], c1 = cptr[min(wave + nwaves, qlast)];
+    f32x2 cpro[NBUF];                                                     // the first NBUF queries of the wave
+#pragma unroll
+    for (int i = 0; i < NBUF; ++i) cpro[i] = cptr[min(wave + i * nwaves, qlast)];
 
     // ---- launch-independent lane roles (five 16-byte loads from the code object's table) ----
     const u32x4* tp = reinterpret_cast<const u32x4*>(&g_lane_tab.v[lane][0]);
@@ -188,10 +196,14 @@ __global__ __launch_bounds__(64 * NW) void lookup_dma_kernel(const DArgs a) {
     // tap entries: lanes that are no tap lanes write theirs to a scratch place - the padding chunk of a window row of the
     // same buffer (idle while the taps run, never read) - so that the loop body has no exec-masked branch
     const unsigned tab_x = wbase + OFF_TAB + (lv * 9 + min(li, 8)) * 8;
-    const unsigned scratch = wbase + (lv * 7 + max(li - 9, 0)) * PITCH + 64;
-    const unsigned tab_wx0 = is_tap ? tab_x : scratch, tab_wy0 = is_tap ? tab_x + 288 : scratch + 8;
-    const unsigned tab_wx1 = tab_wx0 + (is_tap ? TAB : WIN), tab_wy1 = tab_wy0 + (is_tap ? TAB : WIN);
-    const unsigned win_lv = wbase + lv * LVL_BYTES;
+    const unsigned scratch = wbase + OFF_WIN + (lv * 7 + max(li - 9, 0)) * PITCH + 64;
+    unsigned tab_wx[NBUF], tab_wy[NBUF];
+#pragma unroll
+    for (int i = 0; i < NBUF; ++i) {
+        tab_wx[i] = (is_tap ? tab_x : scratch) + i * (is_tap ? TAB : WIN);
+        tab_wy[i] = (is_tap ? tab_x + 288 : scratch + 8) + i * (is_tap ? TAB : WIN);
+    }
+    const unsigned win_lv = wbase + OFF_WIN + lv * LVL_BYTES;
     // stores: pairs (2 L + 128 p, + 1) for p = 0, 1, 2; the third pair exists for lanes 0..33 only (channels 256..323)
     const unsigned st2 = lane < 34 ? (unsigned)(lane * 8 + 1024) : OOB;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.base), 0, (int)a.total_bytes, 0x00020000);
@@ -235,8 +247,8 @@ __global__ __launch_bounds__(64 * NW) void lookup_dma_kernel(const DArgs a) {
         ex.y = __float_as_int(t.wx);
         ey.x = __umul24(wyc, PITCH) + (win_lv + buf * WIN);
         ey.y = __float_as_int(t.wy);
-        lds_st<i32x2>(buf ? tab_wx1 : tab_wx0, ex);
-        lds_st<i32x2>(buf ? tab_wy1 : tab_wy0, ey);
+        lds_st<i32x2>(tab_wx[buf], ex);
+        lds_st<i32x2>(tab_wy[buf], ey);
         if (DBG) {
             if (is_tap && a.taps) {
                 int* tp2 = a.taps + ((size_t)q * 4 + lv) * 18;
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(64 * NW) void lookup_dma_kernel(const DArgs a) {
         unsigned s[NDMA];
 #pragma unroll
         for (int d = 0; d < NDMA; ++d) s[d] = __builtin_elementwise_add_sat(lds_ld<unsigned>(d_row[d]), lds_ld<unsigned>(d_col[d]));
-        const unsigned dst = wbase + buf * WIN;
+        const unsigned dst = wbase + OFF_WIN + buf * WIN;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
                      "buffer_load_dwordx4 %1, %5, 0 offen lds\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
@@ -334,27 +346,31 @@ __global__ __launch_bounds__(64 * NW) void lookup_dma_kernel(const DArgs a) {
         }
     };
 
-    taps_b(wave, taps_a(c0.x, c0.y), 0);
-    dma(0, rs_in);
-    taps_b(min(wave + nwaves, qlast), taps_a(c1.x, c1.y), 1);
-    // Iteration k: DMA of query k + 1 (its offsets were published by the previous iteration) -> wait for the window of
-    // query k (everything older than the NDMA newest vector-memory operations) -> blend k, interleaved with the taps of
-    // query k + 2.  Past the end the same instructions run on the last query with an empty resource (no traffic, no branches).
-    unsigned q = wave;
-    for (unsigned k = 0; k < count; k += 2) {
+    // prologue: tables of the first NBUF queries, DMAs of the first NBUF - 1
 #pragma unroll
-        for (int P = 0; P < 2; ++P) {
+    for (int i = 0; i < NBUF; ++i) {
+        taps_b(min(wave + i * nwaves, qlast), taps_a(cpro[i].x, cpro[i].y), i);
+        if (i < D) dma(i, (unsigned)i < count ? rs_in : rs_null);
+    }
+    // Iteration k: DMA of query k + D (its offsets were published by the previous iteration) -> wait for the window of
+    // query k -> blend k, interleaved with the taps of query k + NBUF.  Past the end the same instructions run on the last
+    // query with an empty resource (no traffic, no branches).
+    // The wait: vector-memory operations complete in issue order (gfx9: one counter for loads and stores), and behind the
+    // DMA of query k the wave has issued, per later iteration, three output stores and NDMA DMA instructions - none of
+    // which it has to wait for: D * NDMA + min(k, D) * 3 operations may stay in flight.
+    unsigned q = wave;
+    for (unsigned k = 0; k < count; k += NBUF) {
+#pragma unroll
+        for (int P = 0; P < NBUF; ++P) {
             const unsigned kk = k + P;
             if (kk >= count) break;
-            const bool has1 = kk + 1 < count;
-            const unsigned q2 = min(q + 2 * nwaves, qlast);
-            const f32x2 c2 = cptr[q2];
-            if (!(ABL & 16)) dma(P ^ 1, has1 ? rs_in : rs_null);
-            // the window of query k: everything older than {the three output stores of query k - 1, the NDMA instructions
-            // just issued} (vector-memory operations complete in issue order on gfx9: stores need not be waited for)
-            if ((ABL & 1) || (P == 0 && k == 0)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 3) : "memory");
-            blend_and_taps(q, q2, c2.x, c2.y, P);
+            const unsigned qn = min(q + NBUF * nwaves, qlast);
+            const f32x2 cn = cptr[qn];
+            if (!(ABL & 16)) dma((P + D) % NBUF, kk + D < count ? rs_in : rs_null);
+            if ((ABL & 1) || (P == 0 && k == 0)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NDMA) : "memory");
+            else if (D == 2 && P == 1 && k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NDMA + 3) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NDMA + D * 3) : "memory");
+            blend_and_taps(q, qn, cn.x, cn.y, P);
             q += nwaves;
         }
     }
@@ -401,29 +417,35 @@ int lookup_dma_fwd(const void* const* levels, int half, const float* coords, lon
     a.queries = (unsigned)queries;
     a.out_bytes = (unsigned)out_bytes;
     a.out_ld = out_ld;
-    // one wave per block, 16 blocks per CU (9.5 KB of LDS each)
+    // one wave per block; 16 blocks per CU with two buffers (9.5 KB of LDS each), 11 with three (14 KB)
     static const int env_wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 0;
-    const int wpc = env_wpc > 0 && env_wpc <= 16 ? env_wpc : 16;
+    static const int env_depth = getenv("FF_LOOKUP_DEPTH") ? atoi(getenv("FF_LOOKUP_DEPTH")) : 1;      // A/B switch
+    static const int env_bw = getenv("FF_LOOKUP_BLOCK_WAVES") ? atoi(getenv("FF_LOOKUP_BLOCK_WAVES")) : 1;
+    const char* abl_s = getenv("FF_LOOKUP_ABLATE3");
+    const int abl = abl_s ? atoi(abl_s) : 0;
+    const bool deep = env_depth == 2 && !taps_dbg && !abl;
+    const int max_wpc = deep ? 11 : 16;
+    const int wpc = env_wpc > 0 && env_wpc <= max_wpc ? env_wpc : max_wpc;
     long long waves = 256ll * wpc;
     if (waves > queries) waves = queries;
     // FF_LOOKUP_BLOCK_WAVES=4 (opt-in A/B switch): four query-waves per block.  Measured on 8 x 48 x 64 queries inside
     // bench.py: 19.9 us per launch either way - placing 4 096 one-wave workgroups is not what the ramp costs.
-    static const int env_bw = getenv("FF_LOOKUP_BLOCK_WAVES") ? atoi(getenv("FF_LOOKUP_BLOCK_WAVES")) : 1;
-    const bool quad = env_bw == 4 && waves % 4 == 0 && waves >= 1024 && !taps_dbg;
+    const bool quad = env_bw == 4 && waves % 4 == 0 && waves >= 1024 && !taps_dbg && !deep;
     const unsigned blocks = (unsigned)(quad ? waves / 4 : waves);
     a.qdiv = (unsigned)(queries / waves);
     a.qrem = (unsigned)(queries % waves);
     hipEvent_t ev0, ev1;          // null unless ff_launch_timing_begin(FF_TIME_LOOKUP) is in effect
     launch_timing_events(FF_TIME_LOOKUP, &ev0, &ev1);
-#define FF_LAUNCH3(H_, D_, A_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, D_, A_, 1>), dim3(blocks), dim3(64), WAVE_LDS, s, ev0, ev1, 0, a)
-#define FF_LAUNCH4(H_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, false, 0, 4>), dim3(blocks), dim3(256), 4 * WAVE_LDS, s, ev0, ev1, 0, a)
+#define FF_LAUNCH3(H_, D_, A_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, D_, A_, 1, 2>), dim3(blocks), dim3(64), wave_lds(2), s, ev0, ev1, 0, a)
+#define FF_LAUNCH4(H_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, false, 0, 4, 2>), dim3(blocks), dim3(256), 4 * wave_lds(2), s, ev0, ev1, 0, a)
+#define FF_LAUNCH_DEEP(H_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, false, 0, 1, 3>), dim3(blocks), dim3(64), wave_lds(3), s, ev0, ev1, 0, a)
 #define FF_LAUNCH(H_, D_) FF_LAUNCH3(H_, D_, 0)
-    const char* abl_s = getenv("FF_LOOKUP_ABLATE3");
-    const int abl = abl_s ? atoi(abl_s) : 0;
 #define FF_ABL(V_) if (abl == V_ && !half && !quad) { FF_LAUNCH3(false, false, V_); return check_launch("ff_corr_lookup_tiled_fwd (dma, ablated)"); }
     FF_ABL(1) FF_ABL(4) FF_ABL(8) FF_ABL(16) FF_ABL(20) FF_ABL(28) FF_ABL(12)
 #undef FF_ABL
-    if (quad) {
+    if (deep) {
+        if (half) FF_LAUNCH_DEEP(true); else FF_LAUNCH_DEEP(false);
+    } else if (quad) {
         if (half) FF_LAUNCH4(true); else FF_LAUNCH4(false);
     } else if (half) {
         if (taps_dbg) FF_LAUNCH(true, true); else FF_LAUNCH(true, false);
@@ -433,6 +455,7 @@ int lookup_dma_fwd(const void* const* levels, int half, const float* coords, lon
 #undef FF_LAUNCH
 #undef FF_LAUNCH3
 #undef FF_LAUNCH4
+#undef FF_LAUNCH_DEEP
     return check_launch("ff_corr_lookup_tiled_fwd (dma)");
 }
 
