@@ -35,8 +35,28 @@ class FFConvParams(C.Structure):
     ]
 
 
+PACK_MAX_MEMBERS = 4    # include/focusflow_hip.h: FF_PACK_MAX_MEMBERS / FF_PACK_MAX_SLICES
+PACK_MAX_SLICES = 4
+
+
+class FFPackJob(C.Structure):
+    _fields_ = [
+        ("w", _fp * PACK_MAX_MEMBERS), ("bias", _fp * PACK_MAX_MEMBERS),
+        ("cout_m", C.c_int * PACK_MAX_MEMBERS), ("off", C.c_int * PACK_MAX_MEMBERS), ("nmem", C.c_int), ("cout", C.c_int),
+        ("cin_src", C.c_int), ("nslice", C.c_int), ("slice_lo", C.c_int * PACK_MAX_SLICES), ("slice_hi", C.c_int * PACK_MAX_SLICES),
+        ("cin", C.c_int), ("cin_pad", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
+        ("fwd", _fp), ("bias_dst", _fp), ("dgrad", _fp),
+        ("fwd_format", C.c_int), ("dgrad_format", C.c_int), ("cout_pad", C.c_int), ("reserved", C.c_int),
+        ("items_fwd", _ll), ("items_dgrad", _ll), ("block0", _ll),
+    ]
+
+
 # name -> argtypes; every function returns int (0 = ok) except the two below
 _SIGS = {
+    "ff_pack_job_check": [C.POINTER(FFPackJob)],
+    "ff_pack_weights_table": [_fp, C.c_int, _ll, _fp],
+    "ff_unpack_wgrad_group": [_fp, _fp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int,
+                              C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, _fp, _fp],
     "ff_conv2d_fwd": [C.POINTER(FFConvParams), _fp],
     "ff_pack_conv_weight": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp],
     "ff_pack_split_f16": [_fp, _fp, _ll, C.c_int, _fp],
@@ -116,7 +136,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint", "ff_conv2d_stats_parts"])
 
-ABI_VERSION = 3      # include/focusflow_hip.h: FF_ABI_VERSION
+ABI_VERSION = 4      # include/focusflow_hip.h: FF_ABI_VERSION
 _lib = None
 
 

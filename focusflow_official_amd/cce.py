@@ -8,7 +8,9 @@ launches on NHWC fp32 tensors.
 """
 from typing import Tuple, Optional, Sequence
 
+import ctypes
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -22,6 +24,11 @@ EPS = 1e-5
 _NORM_ON_LOAD = os.environ.get("FF_NORM_ON_LOAD", "1") != "0"      # measurement switch (ResidualBlock conv2 normalises while loading)
 
 
+_ALL_PACKED = weakref.WeakSet()      # every PackedConv alive: prepack() finds the ones of a model here
+_PREPACK = os.environ.get("FF_PREPACK", "1") != "0"     # A/B switch: all stale weight layouts of a training step in one launch
+_serial = [0]
+
+
 class PackedConv:
     """Cache of one (or several Cout-concatenated) nn.Conv2d in kernel layout.
 
@@ -31,7 +38,8 @@ class PackedConv:
     # defaults for subclasses that build their own state (pwcnet._TrainPacked)
     cin_slices = None
     use_bias = True
-    _w_raw = _wd_raw = None
+    _w_raw = _wd_raw = _w_split = _wd_split = None
+    _used_f = _used_d = False      # get() / get_dgrad() have been asked for: prepack() keeps these layouts fresh
 
     def __init__(self, convs: Sequence[nn.Conv2d], cin_pad: Optional[int] = None,
                  cin_slices: Optional[Sequence[Tuple[int, int]]] = None, use_bias: bool = True):
@@ -57,12 +65,27 @@ class PackedConv:
         self.b = None
         self._dkey = None
         self.wd = None
-        self._w_raw = self._wd_raw = None
+        self._w_raw = self._wd_raw = self._w_split = self._wd_split = None
+        _serial[0] += 1
+        self._serial = _serial[0]
+        _ALL_PACKED.add(self)
 
-    def get(self):
-        key = (ops.conv_precision(),) + tuple(
+    def _fwd_key(self):
+        return (ops.conv_precision(),) + tuple(
             (c.weight._version, c.weight.data_ptr()) + ((c.bias._version, c.bias.data_ptr()) if c.bias is not None else ())
             for c in self.convs)
+
+    def _dgrad_key(self):
+        return (ops.conv_precision(),) + tuple((c.weight._version, c.weight.data_ptr()) for c in self.convs)
+
+    def _small(self):
+        # 1- and 2-channel 3x3 heads stay in fp32 rows: ff_conv2d_fwd runs them as dot products on the vector ALU
+        # (conv_small.hip) instead of wasting a 64-wide matrix tile on them
+        return self.cout <= 2 and (self.kh, self.kw, self.stride) == (3, 3, 1) and self.pad == (1, 1)
+
+    def get(self):
+        self._used_f = True
+        key = self._fwd_key()
         if key != self._key:
             dev = self.convs[0].weight.device
             if self._w_raw is None or self._w_raw.device != dev:     # re-packed every training step: the buffers stay
@@ -78,10 +101,7 @@ class PackedConv:
                 if c.bias is not None and self.use_bias:
                     self.b[off:off + c.out_channels].copy_(c.bias.detach())  # device memcpy
                 off += c.out_channels
-            # 1- and 2-channel 3x3 heads stay in fp32 rows: ff_conv2d_fwd runs them as dot products on the vector ALU
-            # (conv_small.hip) instead of wasting a 64-wide matrix tile on them
-            small = self.cout <= 2 and (self.kh, self.kw, self.stride) == (3, 3, 1) and self.pad == (1, 1)
-            self.fmt = 0 if small else ops.w_format()
+            self.fmt = 0 if self._small() else ops.w_format()
             if self.fmt != 0:
                 self.w = ops.pack_split(self.w)
             self._key = key
@@ -91,7 +111,8 @@ class PackedConv:
         """Weights of the input-gradient convolution: [cin_pad][KH][KW][cout_pad], flipped + transposed, in the
         active conv format (fp32 rows, or fp16-split rows: the dgrad then runs on the f16 matrix pipe with the
         gradient scaled by a power of two, see FFConvParams.x_amax).  Returns (rows, format)."""
-        key = (ops.conv_precision(),) + tuple((c.weight._version, c.weight.data_ptr()) for c in self.convs)
+        self._used_d = True
+        key = self._dgrad_key()
         if key != self._dkey:
             cout_pad = (self.cout + 3) // 4 * 4
             dev = self.convs[0].weight.device
@@ -134,6 +155,102 @@ class PackedConv:
             full[:, lo:hi] = part[:, o:o + hi - lo]
             o += hi - lo
         return full
+
+
+def _pack_job(pc, need_f, need_d, dev):
+    """FFPackJob of one PackedConv (its destination buffers are created here and stay): -> (job, fmt, dfmt)."""
+    J = _hip.FFPackJob()
+    convs = pc.convs
+    off = 0
+    for m, cv in enumerate(convs):
+        J.w[m] = cv.weight.data_ptr()
+        J.bias[m] = cv.bias.data_ptr() if (cv.bias is not None and pc.use_bias) else None
+        J.cout_m[m], J.off[m] = cv.out_channels, off
+        off += cv.out_channels
+    J.nmem, J.cout, J.cin_src = len(convs), pc.cout, convs[0].in_channels
+    sl = pc.cin_slices or []
+    J.nslice = len(sl)
+    for i, (lo, hi) in enumerate(sl):
+        J.slice_lo[i], J.slice_hi[i] = lo, hi
+    J.cin, J.cin_pad, J.KH, J.KW = pc.cin, pc.cin_pad, pc.kh, pc.kw
+    fmt = 0 if pc._small() else ops.w_format()
+    dfmt = ops.w_format()
+    kf = pc.kh * pc.kw * pc.cin_pad
+    if need_f:
+        if pc.b is None or pc.b.device != dev or pc.b.shape[0] != pc.cout:
+            pc.b = torch.zeros(pc.cout, dtype=torch.float32, device=dev)
+        if fmt == 0:
+            if pc._w_raw is None or pc._w_raw.device != dev:
+                pc._w_raw = torch.empty((pc.cout, kf), dtype=torch.float32, device=dev)
+            dst = pc._w_raw
+        else:
+            if pc._w_split is None or pc._w_split.device != dev:
+                pc._w_split = torch.empty((pc.cout, (kf + 31) // 32 * 128), dtype=torch.uint8, device=dev)
+            dst = pc._w_split
+        J.fwd, J.fwd_format = dst.data_ptr(), fmt
+        J.bias_dst = pc.b.data_ptr() if pc.use_bias else None
+        J.items_fwd = pc.cout * ((kf + 31) // 32) * 4
+    cout_pad = (pc.cout + 3) // 4 * 4
+    kd = pc.kh * pc.kw * cout_pad
+    if need_d:
+        if dfmt == 0:
+            if pc._wd_raw is None or pc._wd_raw.device != dev:
+                pc._wd_raw = torch.zeros((pc.cin_pad, kd), dtype=torch.float32, device=dev)
+            dst = pc._wd_raw
+        else:
+            if pc._wd_split is None or pc._wd_split.device != dev:
+                pc._wd_split = torch.empty((pc.cin_pad, (kd + 31) // 32 * 128), dtype=torch.uint8, device=dev)
+            dst = pc._wd_split
+        J.dgrad, J.dgrad_format, J.cout_pad = dst.data_ptr(), dfmt, cout_pad
+        J.items_dgrad = pc.cin_pad * ((kd + 31) // 32) * 4
+    return J, fmt, dfmt
+
+
+def prepack(owner: nn.Module, device) -> int:
+    """Bring every stale weight layout of `owner`'s convolutions up to date in ONE launch (ff_pack_weights_table) - the
+    layouts this process has asked for before (PackedConv.get / get_dgrad mark them), i.e. from the second training step
+    on: the optimiser has just changed every parameter, and packing lazily costs ~7 small launches per convolution per
+    step.  The job table lives on the device and is rebuilt only when a pointer, a format or the set of stale layouts
+    changes.  Returns the number of PackedConvs packed (0: nothing stale, or FF_PREPACK=0)."""
+    if not _PREPACK:
+        return 0
+    ids = owner.__dict__.get("_ff_param_ids")
+    if ids is None or ids[0] != sum(1 for _ in owner.parameters()):
+        ids = owner.__dict__["_ff_param_ids"] = (sum(1 for _ in owner.parameters()), {id(p) for p in owner.parameters()})
+    device = torch.device(device)
+    todo = []
+    for pc in sorted((pc for pc in _ALL_PACKED if type(pc) is PackedConv and (pc._used_f or pc._used_d)), key=lambda pc: pc._serial):
+        w0 = pc.convs[0].weight
+        if id(w0) not in ids[1] or w0.device != device or len(pc.convs) > _hip.PACK_MAX_MEMBERS \
+                or len(pc.cin_slices or ()) > _hip.PACK_MAX_SLICES:
+            continue
+        kf = pc._fwd_key() if pc._used_f else None
+        kd = pc._dgrad_key() if pc._used_d else None
+        nf, nd = pc._used_f and kf != pc._key, pc._used_d and kd != pc._dkey
+        if nf or nd:
+            todo.append((pc, nf, nd, kf, kd))
+    if len(todo) < 4:           # a few stragglers: get() / get_dgrad() pack them on demand
+        return 0
+    jobs = [_pack_job(pc, nf, nd, device) for pc, nf, nd, _, _ in todo]
+    sig = tuple((pc._serial, nf, nd, bytes(J)) for (pc, nf, nd, _, _), (J, _, _) in zip(todo, jobs))
+    cache = owner.__dict__.get("_ff_pack_table")
+    if cache is None or cache[0] != sig:
+        arr = (_hip.FFPackJob * len(jobs))()
+        blk = 0
+        for i, (J, _, _) in enumerate(jobs):
+            J.block0 = blk
+            _hip.call("ff_pack_job_check", ctypes.byref(J))
+            blk += (J.items_fwd + J.items_dgrad + 255) // 256
+            arr[i] = J
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        cache = owner.__dict__["_ff_pack_table"] = (sig, host.to(device), len(jobs), blk)
+    ops.pack_weights_table(cache[1], cache[2], cache[3])
+    for (pc, nf, nd, kf, kd), (J, fmt, dfmt) in zip(todo, jobs):
+        if nf:
+            pc.w, pc.fmt, pc._key = (pc._w_raw if fmt == 0 else pc._w_split), fmt, kf
+        if nd:
+            pc.wd, pc.dfmt, pc._dkey = (pc._wd_raw if dfmt == 0 else pc._wd_split), dfmt, kd
+    return len(todo)
 
 
 def train_streams() -> bool:

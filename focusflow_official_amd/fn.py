@@ -130,6 +130,23 @@ class ParamGate(torch.autograd.Function):
         pc = ctx.pc
         acc = ctx.scope.acc.pop(pc, None)
         grads: List[Optional[Tensor]] = [None, None]
+        if acc is not None and _UNPACK_GROUP and type(pc).__name__ == "PackedConv" and len(pc.convs) <= 4 \
+                and len(pc.cin_slices or ()) <= 4 and all(ctx.needs_input_grad[2:]):
+            # every member's OIHW gradient and bias gradient in one launch, as views of one buffer
+            has_b = [cv.bias is not None and pc.use_bias for cv in pc.convs]
+            couts = [cv.out_channels for cv in pc.convs]
+            offs = [sum(couts[:j]) for j in range(len(couts))]
+            cin_src = pc.convs[0].in_channels
+            flat = ops.unpack_wgrad_group(acc[0], acc[1], couts, offs, has_b, cin_src, pc.cin_slices, pc.kh, pc.kw, pc.cin_pad)
+            at = 0
+            for cv, co, hb in zip(pc.convs, couts, has_b):
+                n = co * cin_src * pc.kh * pc.kw
+                grads.append(flat[at:at + n].view(co, cin_src, pc.kh, pc.kw))
+                at += n
+                if hb:
+                    grads.append(flat[at:at + co])
+                    at += co
+            return tuple(grads)
         off, k = 0, 2                     # k: position among this node's inputs (None parameters were not passed)
         for j, cv in enumerate(pc.convs):
             co = cv.out_channels
@@ -143,6 +160,7 @@ class ParamGate(torch.autograd.Function):
 
 
 _scope: Optional[GraphScope] = None
+_UNPACK_GROUP = os.environ.get("FF_UNPACK_GROUP", "1") != "0"   # A/B switch: one gradient-unpacking launch per packed convolution
 _LOOKUP_BWD_ALL = os.environ.get("FF_LOOKUP_BWD_ALL", "1") != "0"   # A/B switch: one lookup-backward launch per pass instead of one per iteration
 _ZERO_ARENA = os.environ.get("FF_ZERO_ARENA", "1") != "0"    # A/B switch: one zero fill per pass for the backward's accumulation buffers
 _AMAX_HINT = os.environ.get("FF_AMAX_HINT", "1") != "0"      # A/B switch: the norm backward measures max|dx| for the conv it feeds

@@ -733,6 +733,30 @@ def unpack_conv_wgrad(packed: Tensor, cout, cin, kh, kw, cin_pad, cout_offset) -
     return dw
 
 
+def pack_weights_table(table_dev: Tensor, njobs: int, total_blocks: int):
+    """Run a device-resident FFPackJob table (cce.prepack builds it): every stale weight layout in one launch."""
+    if not table_dev.is_cuda:
+        raise _hip.FocusFlowHipError("ff_pack_weights_table: the job table must live on the HIP device")
+    _hip.call("ff_pack_weights_table", _p(table_dev), njobs, total_blocks, _stream())
+
+
+def unpack_wgrad_group(dw: Tensor, db: Optional[Tensor], couts, offs, has_bias, cin_src: int, slices, kh: int, kw: int,
+                       cin_pad: int) -> Tensor:
+    """Packed dW rows (+ db) of one PackedConv -> one flat tensor: per member its OIHW gradient (zero outside `slices`),
+    then its bias gradient if has_bias[m]."""
+    _require_gpu(dw)
+    n = len(couts)
+    total = sum(c * cin_src * kh * kw + (c if hb else 0) for c, hb in zip(couts, has_bias))
+    out = torch.empty(total, dtype=torch.float32, device=dw.device)
+    arr = C.c_int * n
+    ns = len(slices) if slices else 0
+    sarr = C.c_int * max(ns, 1)
+    _hip.call("ff_unpack_wgrad_group", _p(dw), _p(db), n, arr(*couts), arr(*offs), arr(*[int(bool(h)) for h in has_bias]), cin_src, ns,
+              sarr(*([lo for lo, _ in slices] if ns else [0])), sarr(*([hi for _, hi in slices] if ns else [0])), kh, kw, cin_pad,
+              _p(out), _stream())
+    return out
+
+
 def pack_conv_weight_dgrad(w_oihw: Tensor, dst: Tensor, cout_pad: int, cout_offset: int):
     co, ci, kh, kw = w_oihw.shape
     # rows beyond Cin (channel padding of the forward input) stay zero: their input gradient is zero

@@ -4,7 +4,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _hip, fn, ops
+from . import _hip, cce, fn, ops
 from .cce import BasicParallelFusionLayer, train_streams
 from .corr_block import CorrBlock
 from .ops import ACT_RELU, ACT_TANH
@@ -80,6 +80,7 @@ class RAFT(nn.Module):
         ops.begin_forward(image1.device)     # one zeroed arena for this pass's norm statistics
         if torch.is_grad_enabled():
             fn.begin_graph(image1.device)   # one weight-gradient buffer per conv for this recorded pass (fn.GraphScope)
+            cce.prepack(self, image1.device)   # the optimiser changed every parameter: all kernel layouts in one launch
         try:
             return self._forward(image1, image2, mask1, mask2, iters, flow_init, test_mode, b, hh, ww, h8, w8)
         finally:

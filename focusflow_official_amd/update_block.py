@@ -181,8 +181,8 @@ class BasicUpdateBlock(nn.Module):
     def upsample(self, mask_hidden, flow4):
         """run(defer_mask=True)'s hidden tensor + the flow -> flow_up (B,2,8H,8W): ops.mask_upsample."""
         w, b = self._mask2.get()
-        if getattr(self, "_mask2_stage_of", None) is not w:       # re-arranged once per packed weight version
-            self._mask2_stage, self._mask2_stage_of = ops.mask_upsample_pack(w), w
+        if getattr(self, "_mask2_stage_of", None) != self._mask2._key:       # re-arranged once per packed weight version
+            self._mask2_stage, self._mask2_stage_of = ops.mask_upsample_pack(w), self._mask2._key
         return ops.mask_upsample(mask_hidden, self._mask2_stage, self._mask2.fmt, b, flow4, 0.25)
 
     def freeze_self(self, mode):

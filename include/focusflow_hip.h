@@ -53,7 +53,7 @@ const char* ff_last_error(void);
  *   3 (round 3): FFConvParams + ep_mode, ep_split, ep_a, ep_a_ld, ep_b, ep_b_ld, stats_part; + ff_conv2d_stats_parts,
  *                ff_norm_stats_finish, ff_launch_timing_begin / _end, ff_mask_upsample_pack / _fwd,
  *                ff_corr_lookup_tiled_bwd_all */
-#define FF_ABI_VERSION 3
+#define FF_ABI_VERSION 4
 int ff_abi_version(void);
 
 /* Kernel-timestamp timing of one class of the library's launches (measurement only; bench.py's roofline uses it).
@@ -320,6 +320,42 @@ int ff_unpack_conv_wgrad(const float* packed, int Cout, int Cin, int KH, int KW,
  * dst[ci][KH-1-kh][KW-1-kw][cout_offset+co] = w[co][ci][kh][kw]  (CALLER ZEROES dst) */
 int ff_pack_conv_weight_dgrad(const float* w_oihw, int Cout, int Cin, int KH, int KW, float* dst,
                               int cout_pad, int cout_offset, void* stream);
+/* ---- every weight layout of a training step in ONE launch (pack_table.hip) ----
+ * A training step changes every parameter, so every convolution re-packs its forward rows (ff_pack_conv_weight +
+ * ff_pack_split_f16), its bias vector and its input-gradient rows (ff_pack_conv_weight_dgrad + ff_pack_split_f16) once
+ * per step: ~680 launches of 3-5 us each for FF-RAFT.  One FFPackJob describes all of that for one packed convolution
+ * (up to FF_PACK_MAX_MEMBERS nn.Conv2d concatenated along Cout - the GRU's z and r gates, the flow and mask heads -
+ * optionally over slices of their input channels); the table lives in DEVICE memory and is reused as long as no pointer
+ * in it changes.  Results are bit-identical to the per-convolution entry points. */
+#define FF_PACK_MAX_MEMBERS 4
+#define FF_PACK_MAX_SLICES 4
+typedef struct FFPackJob {
+    const float* w[FF_PACK_MAX_MEMBERS];      /* OIHW parameters [cout_m][cin_src][KH][KW]                              */
+    const float* bias[FF_PACK_MAX_MEMBERS];   /* nullable per member                                                   */
+    int cout_m[FF_PACK_MAX_MEMBERS], off[FF_PACK_MAX_MEMBERS];   /* member channels and their first packed output row  */
+    int nmem, cout;                           /* cout = sum of cout_m                                                  */
+    int cin_src;                              /* input channels of the parameters                                      */
+    int nslice, slice_lo[FF_PACK_MAX_SLICES], slice_hi[FF_PACK_MAX_SLICES];   /* packed channels = these ranges of the
+                                                 source channels, concatenated (nslice 0: all of them)                  */
+    int cin, cin_pad, KH, KW;                 /* cin = packed input channels (sum of the slices), padded to cin_pad      */
+    void* fwd;                                /* forward rows [cout][KH*KW*cin_pad] in fwd_format (FF_W_*), or unused    */
+    float* bias_dst;                          /* [cout] bias vector (0 where a member has none), nullable               */
+    void* dgrad;                              /* input-gradient rows [cin_pad][KH*KW*cout_pad] in dgrad_format, or unused */
+    int fwd_format, dgrad_format, cout_pad, reserved;
+    long long items_fwd;                      /* cout * ceil(KH*KW*cin_pad / 32) * 4, or 0: no forward rows              */
+    long long items_dgrad;                    /* cin_pad * ceil(KH*KW*cout_pad / 32) * 4, or 0: no input-gradient rows   */
+    long long block0;                         /* first block of this job: sum over the earlier jobs of
+                                                 ceil((items_fwd + items_dgrad) / 256)                                  */
+} FFPackJob;
+/* host-side validation of one job (the table itself is device memory: the launch cannot check it) */
+int ff_pack_job_check(const FFPackJob* job);
+/* jobs_dev: njobs jobs in device memory, ordered by block0; total_blocks = block0 + blocks of the last job */
+int ff_pack_weights_table(const FFPackJob* jobs_dev, int njobs, long long total_blocks, void* stream);
+/* The way back for one packed convolution: packed dW rows (+ db) -> dst = for every member, its OIHW gradient
+ * [cout_m][cin_src][KH][KW] (zero outside the slices) followed, if has_bias[m], by its bias gradient [cout_m]. */
+int ff_unpack_wgrad_group(const float* dw_packed, const float* db_packed, int nmem, const int* cout, const int* off,
+                          const int* has_bias, int cin_src, int nslice, const int* slice_lo, const int* slice_hi,
+                          int KH, int KW, int cin_pad, float* dst, void* stream);
 /* g = dy * act'(y) * scale (activation derivative from the forward OUTPUT), zero-padded to Cpad; amax (nullable,
  * CALLER ZEROES): bits of max|g|.  g == dy is allowed (then nothing is stored: the call only measures max|dy|, for
  * activation-free convolutions whose gradient needs no copy) */

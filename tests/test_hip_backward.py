@@ -647,3 +647,113 @@ def test_encoder_branch_streams_at_test_sizes():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_weight_layouts_of_a_step_in_one_launch(mods):
+    """cce.prepack (ff_pack_weights_table) against the per-convolution packing it replaces from the second training step
+    on: forward rows, bias vectors and input-gradient rows BYTE for byte - a 7x7 stem over a padded input channel, a
+    two-member group over input-channel slices without bias, a 2-channel head (fp32 rows forward, split rows backward),
+    a 1x1 with an odd channel count; and ff_unpack_wgrad_group against ff_unpack_conv_wgrad + bias slices."""
+    cce, ops = mods.cce, mods.ops
+    torch.manual_seed(5)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = nn.Conv2d(3, 64, 7, 2, 3)
+            self.z, self.r = nn.Conv2d(160, 48, (1, 5), padding=(0, 2)), nn.Conv2d(160, 80, (1, 5), padding=(0, 2))
+            self.head = nn.Conv2d(256, 2, 3, padding=1)
+            self.odd = nn.Conv2d(324, 126, 1, bias=False)
+            self.body = nn.Conv2d(64, 96, 3, padding=1)
+
+    net = Net().to(DEV)
+
+    def build():
+        return [cce.PackedConv([net.stem], 4), cce.PackedConv([net.z, net.r], cin_slices=[(96, 160), (0, 32)], use_bias=False),
+                cce.PackedConv([net.z, net.r]), cce.PackedConv([net.head]), cce.PackedConv([net.odd], 352), cce.PackedConv([net.body])]
+
+    for precision in ("f16x3", "fp32"):
+        prev = ops.conv_precision()
+        ops.set_conv_precision(precision)
+        try:
+            pcs = build()
+            for pc in pcs:                      # first use: packed on demand, and marked as wanted
+                pc.get()
+                pc.get_dgrad()
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.mul_(1.5).add_(0.01)
+            want = []
+            for pc in build():                  # what packing on demand gives for the new values
+                w, b = pc.get()
+                wd, dfmt = pc.get_dgrad()
+                want.append((w.clone(), b.clone(), pc.fmt, wd.clone(), dfmt))
+            assert cce.prepack(net, DEV) == len(pcs)
+            for pc, (w, b, fmt, wd, dfmt) in zip(pcs, want):
+                assert pc._key == pc._fwd_key() and pc._dkey == pc._dgrad_key()
+                gw, gb = pc.get()
+                gwd, gdf = pc.get_dgrad()
+                assert (pc.fmt, gdf) == (fmt, dfmt)
+                assert gw.dtype == w.dtype and gw.shape == w.shape and torch.equal(gw.view(torch.uint8), w.view(torch.uint8)), (precision, pc.cout, "forward rows")
+                assert torch.equal(gb, b), (precision, pc.cout, "bias")
+                assert gwd.shape == wd.shape and torch.equal(gwd.view(torch.uint8), wd.view(torch.uint8)), (precision, pc.cout, "dgrad rows")
+            assert cce.prepack(net, DEV) == 0   # nothing stale now
+        finally:
+            ops.set_conv_precision(prev)
+
+    # the way back
+    for pc in build()[:5]:
+        kdim = pc.kh * pc.kw * pc.cin_pad
+        dw = torch.randn(pc.cout, kdim, device=DEV)
+        db = torch.randn(pc.cout, device=DEV)
+        has_b = [cv.bias is not None and pc.use_bias for cv in pc.convs]
+        couts = [cv.out_channels for cv in pc.convs]
+        offs = [sum(couts[:j]) for j in range(len(couts))]
+        flat = ops.unpack_wgrad_group(dw, db, couts, offs, has_b, pc.convs[0].in_channels, pc.cin_slices, pc.kh, pc.kw, pc.cin_pad)
+        at = 0
+        for j, cv in enumerate(pc.convs):
+            ref = pc.unpack_wgrad(dw, j, offs[j])
+            n = ref.numel()
+            assert torch.equal(flat[at:at + n].view_as(ref), ref)
+            at += n
+            if has_b[j]:
+                assert torch.equal(flat[at:at + couts[j]], db[offs[j]:offs[j] + couts[j]])
+                at += couts[j]
+        assert at == flat.numel()
+
+
+def test_two_training_steps_with_and_without_the_one_launch_packing(det_sd, mods):
+    """The second step of a training run packs every weight layout through cce.prepack and unpacks gradients per group:
+    same parameters after two AdamW steps as with FF_PREPACK=0 / FF_UNPACK_GROUP=0 (up to the atomics' summation order)."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    from focusflow_official_amd.losses import build_losses
+    inp = [t.to(DEV) for t in orc.shifted_pair(1, 128, 160, seed=4)]
+    flow_gt = torch.zeros(1, 2, 128, 160, device=DEV)
+    valid = torch.ones(1, 128, 160, device=DEV)
+    crit = build_losses("MixLoss", gamma=0.8, max_flow=400, kernel_size=1, sigma=0.01, lamda=1)
+    res = {}
+    for on in (True, False):
+        mods.cce._PREPACK, mods.fn._UNPACK_GROUP = on, on
+        try:
+            m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg())
+            m.load_state_dict(det_sd, strict=True)
+            m = m.to(DEV).train()
+            m.flow_net.freeze_bn()
+            opt = torch.optim.SGD(m.parameters(), lr=1e-4)
+            packed = []
+            for _ in range(3):
+                preds = m(*inp, raft_iters=2)
+                packed.append("_ff_pack_table" in m.flow_net.__dict__ or "_ff_pack_table" in m.__dict__)
+                loss, _ = crit(preds, flow_gt, valid, inp[2])
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+                assert torch.isfinite(loss) and torch.isfinite(gn)
+                opt.step()
+            assert packed[-1] == on
+            res[on] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        finally:
+            mods.cce._PREPACK, mods.fn._UNPACK_GROUP = True, True
+    for k, v in res[True].items():
+        if v.dtype.is_floating_point:
+            close(v.cpu(), res[False][k].cpu(), rtol=1e-4, atol_rel=1e-4, what=k)
