@@ -261,6 +261,35 @@ def train_mode(args, world, rank, local_rank, device, ranks_seen=1):
         dist.destroy_process_group()
 
 
+def memory_only_companion(launch_bytes, achieved_gbs, device):
+    """What this part delivers to ANY kernel that moves as many bytes as one lookup launch: ff_probe_memory_kernel
+    (probe.hip) - 4096 one-wave blocks like the lookup, per wave and trip five 1 KB loads from random 128-byte segments
+    of a 2 GB buffer (nothing left in the 256 MB last-level cache between launches) and four 1 KB stores, no arithmetic -
+    timed with the same dispatch-bound events.  The lookup's distance to THIS number is what is left for the kernel."""
+    from focusflow_official_amd import ops
+    blocks = 4096
+    trips = max(1, int(round(launch_bytes / (blocks * 9 * 1024))))
+    src = torch.empty(2 << 30, dtype=torch.uint8, device=device)
+    src.fill_(1)
+    dst = torch.empty(blocks * trips * 4096 + 16, dtype=torch.uint8, device=device)
+    for salt in range(3):
+        rd, wr = ops.probe_memory_kernel(src, dst, 128, blocks, trips, salt)
+    torch.cuda.synchronize()
+    ops.launch_timing_begin(ops.TIME_PROBE)
+    for salt in range(3, 23):
+        ops.probe_memory_kernel(src, dst, 128, blocks, trips, salt)
+    n, tot, lo, hi = ops.launch_timing_end(ops.TIME_PROBE)
+    del src, dst
+    torch.cuda.empty_cache()
+    avg = tot / max(1, n)
+    gbs = (rd + wr) / (avg * 1e-6) / 1e9 if avg > 0 else 0.0
+    return {"kernel": "probe_kernel (ff_probe_memory_kernel): loads from random 128-byte segments + streaming stores 5 : 4, no arithmetic, 4096 one-wave blocks",
+            "bytes_per_launch": rd + wr, "launches": n, "avg_launch_us": round(avg, 2), "min_launch_us": round(lo, 2), "max_launch_us": round(hi, 2),
+            "achieved": round(gbs, 1), "unit": "GB/s", "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+            "lookup_over_this": round(achieved_gbs / gbs, 4) if gbs > 0 else None,
+            "note": "back-to-back launches on an otherwise idle chip; the lookup is timed inside the pipeline"}
+
+
 def _epe(a, b):
     return torch.sqrt(((a - b) ** 2).sum(1))
 
@@ -587,6 +616,8 @@ def main():
                          "avg_launch_us_bracketed": round(sum(bracketed) / max(1, len(bracketed)) * 1e3, 2),
                          "algorithmic_bytes_per_query": per_q, "algorithmic_bytes_per_launch": per_q * q},
         }
+        if not args.graph:
+            line["roofline"]["memory_only_kernel"] = memory_only_companion(per_q * q, achieved, device)
         # corr-volume build (BASELINE.md "also reported"): dense HWxC x CxHW contraction on the matrix pipe
         q1 = (args.height // 8) * (args.width // 8)
         vol_flop = 2.0 * (hi - lo) * q1 * q1 * 256

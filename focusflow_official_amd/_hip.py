@@ -64,6 +64,7 @@ _SIGS = {
     "ff_norm_stats_finish": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "ff_mask_upsample_pack": [_fp, _fp, _fp],
     "ff_mask_upsample_fwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_float, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_probe_memory_kernel": [_fp, _ll, _fp, _ll, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _fp],
     "ff_launch_timing_begin": [C.c_int],
     "ff_launch_timing_end": [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "ff_norm_apply": [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_float,

@@ -26,6 +26,12 @@
 //     loop); the tap chains of query k + 2 run while the blend's LDS reads are in flight; coordinates arrive by scalar loads;
 //   * outputs leave through a buffer resource over the output tensor: row base in a scalar register, no address
 //     arithmetic on the vector ALU; the loop body is one basic block (no exec-masked branch).
+// Measured variants kept behind switches (8 x 48 x 64 queries inside bench.py, same box): the window wait that also
+// covered the previous query's three output stores (vmcnt NDMA instead of NDMA + 3) 19.9 -> 19.1 us; four query-waves
+// per block (FF_LOOKUP_BLOCK_WAVES=4: a quarter of the workgroups to place) 19.9 vs 19.9 us; a third window / table
+// buffer with two queries in flight at 11 waves per CU (FF_LOOKUP_DEPTH=2) 23.0 vs 19.4 us - the kernel is not short of
+// bytes in flight, it needs its 16 waves.  A memory-only kernel of the same launch shape, byte count and segment size
+// (probe.hip / tools/proto/hbm_gather.hip) takes 13.9-14.6 us.
 #pragma clang fp contract(off)
 #include <cstdlib>
 #include "ff_common.h"

@@ -100,7 +100,17 @@ def profile_notes(label):
     return list(_prof_notes.get(label, []))
 
 
-TIME_LOOKUP, TIME_CORR_BUILD = 1, 2          # include/focusflow_hip.h: FF_TIME_*
+TIME_LOOKUP, TIME_CORR_BUILD, TIME_PROBE = 1, 2, 3          # include/focusflow_hip.h: FF_TIME_*
+
+
+def probe_memory_kernel(src: Tensor, dst: Tensor, seg_bytes: int, blocks: int, trips: int, salt: int):
+    """ff_probe_memory_kernel: the memory-only companion of the lookup (measurement aid) -> (bytes read, bytes written)."""
+    if not (src.is_cuda and dst.is_cuda):
+        raise _hip.FocusFlowHipError("ff_probe_memory_kernel: device buffers only")
+    rd, wr = C.c_longlong(0), C.c_longlong(0)
+    _hip.call("ff_probe_memory_kernel", _p(src), src.numel() * src.element_size(), _p(dst), dst.numel() * dst.element_size(), seg_bytes,
+              blocks, trips, salt, C.byref(rd), C.byref(wr), _stream())
+    return rd.value, wr.value
 
 
 def launch_timing_begin(*which: int):

@@ -64,9 +64,16 @@ int ff_abi_version(void);
  * while a stream is being captured into a hipGraph. */
 #define FF_TIME_LOOKUP 1        /* ff_corr_lookup_tiled_fwd's kernel */
 #define FF_TIME_CORR_BUILD 2    /* ff_corr_build's kernel            */
-#define FF_TIME_KINDS 2
+#define FF_TIME_PROBE 3         /* ff_probe_memory_kernel's kernel   */
+#define FF_TIME_KINDS 3
 int ff_launch_timing_begin(int which);
 int ff_launch_timing_end(int which, long long* launches, double* total_us, double* min_us, double* max_us);
+/* Measurement aid (probe.hip): a memory-only kernel with the lookup's launch shape (`blocks` one-wave blocks) and access
+ * pattern - per trip and wave five 1 KB loads from random aligned seg_bytes-segments of src (salt picks the addresses)
+ * and four 1 KB stores to the wave's own stream in dst (dst_bytes >= blocks * trips * 4096 + 4).  Reports the bytes it
+ * moves; time it with FF_TIME_PROBE.  What it reaches is the part's ceiling for a launch of that size. */
+int ff_probe_memory_kernel(const void* src, long long src_bytes, void* dst, long long dst_bytes, int seg_bytes, int blocks,
+                           int trips, unsigned int salt, long long* bytes_read, long long* bytes_written, void* stream);
 
 /* ------------------------------------------------------------------------
  * Convolution (implicit GEMM on fp32 MFMA), replaces every nn.Conv2d call of

@@ -1006,3 +1006,20 @@ def test_update_loop_on_batch_slices_opt_in():
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "2 passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_memory_probe_moves_the_bytes_it_reports():
+    """ff_probe_memory_kernel (bench.py's memory-only companion of the lookup): every stored byte comes from the source
+    buffer, the byte counts are those of the launch shape, and its launches are timed under FF_TIME_PROBE."""
+    from focusflow_official_amd import ops
+    blocks, trips = 64, 3
+    src = torch.full((1 << 20,), 7, dtype=torch.uint8, device=DEV)
+    dst = torch.zeros(blocks * trips * 4096 + 16, dtype=torch.uint8, device=DEV)
+    ops.launch_timing_begin(ops.TIME_PROBE)
+    rd, wr = ops.probe_memory_kernel(src, dst, 128, blocks, trips, 5)
+    n, tot, lo, hi = ops.launch_timing_end(ops.TIME_PROBE)
+    assert (rd, wr) == (blocks * trips * 5120, blocks * trips * 4096) and n == 1 and 0 < lo <= hi
+    assert bool((dst[:wr] == 7).all()) and bool((dst[wr:] == 0).all())
+    with pytest.raises(Exception, match="dst holds"):
+        ops.probe_memory_kernel(src, dst[:1000], 128, blocks, trips, 5)
