@@ -14,7 +14,12 @@ echo "== training step"
 python bench.py --mode train --steps 6 --warmup 3 > "$out/train_line.json" 2> "$out/train_line.err"
 bash tools/prof_trace.sh r03/train_b8 bench.py --mode train --steps 4 --warmup 2
 echo "== A/B switches (training)"
-for v in 0 1 0 1; do FF_ZERO_ARENA=$v python bench.py --mode train --steps 6 --warmup 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FF_ZERO_ARENA=$v', d['value'], d['ms_per_step'])"; done | tee "$out/ab_train.txt"
+for v in 0 1 0 1; do FF_PREPACK=$v FF_UNPACK_GROUP=$v python bench.py --mode train --steps 6 --warmup 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FF_PREPACK=FF_UNPACK_GROUP=$v', d['value'], d['ms_per_step'])"; done | tee "$out/ab_train.txt"
+for v in 1536 512 1536 512; do FF_WGRAD_BLOCKS=$v python bench.py --mode train --steps 6 --warmup 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FF_WGRAD_BLOCKS=$v', d['value'], d['ms_per_step'])"; done | tee -a "$out/ab_train.txt"
+echo "== weight-gradient table"
+python tools/wgrad_table.py > "$out/wgrad_table.txt" 2>&1; head -4 "$out/wgrad_table.txt"
+echo "== memory-only kernels of the lookup's size"
+hipcc -O2 --offload-arch=gfx950 -o gpurun_out/hbm_gather tools/proto/hbm_gather.hip && timeout -k 10 120 ./gpurun_out/hbm_gather 16 > "$out/hbm_gather.log" 2>&1; grep "72.0 MB" "$out/hbm_gather.log"
 echo "== lookup lab"
 bash tools/lookup_lab.sh 8 48 64 0 8 50 > "$out/lookup_lab_b8_fp32.log" 2>&1; tail -8 "$out/lookup_lab_b8_fp32.log"
 ./gpurun_out/lookup_lab 8 48 64 1 8 50 > "$out/lookup_lab_b8_fp16.log" 2>&1
