@@ -31,14 +31,6 @@ def _side_stream(device):
     return _side_streams[key]
 
 
-_GRU_XSHARE = os.environ.get("FF_GRU_XSHARE", "1") != "0"     # A/B switch (inference): see SepConvGRU.__init__
-
-
-class _Pre(tuple):
-    """(zr_pre, q_pre) as views of one tensor `full` = [z | r | q]."""
-    full = None
-
-
 class FlowHead(nn.Module):
     def __init__(self, input_dim=128, hidden_dim=256):
         super().__init__()
@@ -68,28 +60,11 @@ class SepConvGRU(nn.Module):
         self._zr_ctx = [PackedConv(g.convs, cin_slices=ctx, use_bias=False) for g in self._zr]
         self._q_ctx = [PackedConv(g.convs, cin_slices=ctx, use_bias=False) for g in self._q]
 
-        # Inference variant (FF_GRU_XSHARE): the MOTION features' share of z|r|q is one 384-channel convolution per pass
-        # (the context share rides in as its residual), the pass-2 one on the side stream from the start of the GRU; the
-        # convolutions that sit on the dependent chain h -> z|r -> r*h -> q -> h then only reduce over h's 128 channels.
-        mo, hh = [(hidden_dim + 128, c)], [(0, hidden_dim)]
-        self._zrq_m = [PackedConv(g.convs + q.convs, cin_slices=mo, use_bias=False) for g, q in zip(self._zr, self._q)]
-        self._zrq_ctx = [PackedConv(g.convs + q.convs, cin_slices=ctx, use_bias=False) for g, q in zip(self._zr, self._q)]
-        self._zr_h = [PackedConv(g.convs, cin_slices=hh) for g in self._zr]
-        self._q_h = [PackedConv(g.convs, cin_slices=hh) for g in self._q]
-
     def prepare(self, inp):
         """The context features' contribution to z|r and q of both passes, [(zr_pre, q_pre)] x 2.  Recorded passes too:
         autograd then sums the twelve pre-activation gradients that reach each share and runs the share's weight and
         input gradient ONCE (sum_t inp (x) g_t = inp (x) sum_t g_t)."""
         assert inp.shape[3] == 128
-        if _GRU_XSHARE and not torch.is_grad_enabled() and ops.w_format() in (_hip.W_F16X3, _hip.W_F16):
-            out = []
-            for cc in self._zrq_ctx:      # [z | r | q] shares in one tensor: the residual of the motion-share convolution
-                t = cc(inp)
-                p = _Pre((t[..., :2 * self.hidden_dim], t[..., 2 * self.hidden_dim:]))
-                p.full = t
-                out.append(p)
-            return out
         return [(fn.conv(zc, inp), fn.conv(qc, inp)) for zc, qc in zip(self._zr_ctx, self._q_ctx)]
 
     def run(self, h, xs, pre=None):
@@ -107,27 +82,6 @@ class SepConvGRU(nn.Module):
             # (not while a hipGraph is being captured: there the K splits of these short reductions pay more, and the
             # split partial sums cannot carry an epilogue)
             fused = _GRU_EPILOGUE and ops.w_format() in (_hip.W_F16X3, _hip.W_F16) and not torch.cuda.is_current_stream_capturing()
-            if fused and len(xs) == 2 and all(getattr(p, "full", None) is not None for p in pre) and not ops.policy.single_stream:
-                motion = xs[1]
-                main = torch.cuda.current_stream()
-                side = _side_stream(h.device)
-                fork = torch.cuda.Event()
-                fork.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(fork)
-                    ms2 = self._zrq_m[1]([motion], res=pre[1].full)
-                    join = torch.cuda.Event()
-                    join.record(side)
-                motion.record_stream(side)
-                ms = self._zrq_m[0]([motion], res=pre[0].full)
-                for i in range(2):
-                    if i == 1:
-                        main.wait_event(join)
-                        ms2.record_stream(main)
-                        ms = ms2
-                    zr = self._zr_h[i]([h], res=ms[..., :2 * c], act_res=ACT_SIGMOID, ep_rh=h, ep_split=c)
-                    h = self._q_h[i]([zr[..., c:]], res=ms[..., 2 * c:], act_res=ACT_TANH, ep_blend=(zr[..., :c], h))
-                return h
             for zr_conv, q_conv, (zr_pre, q_pre) in zip(self._zr_hm, self._q_hm, pre):
                 if fused:
                     # the two element-wise steps ride in the epilogues of the convolutions that precede them (FFConvParams
