@@ -86,6 +86,35 @@ def test_stats_parts_hint_is_host_logic(lib_path):
     assert parts(64, 64, 3, 1, 16, 192, 256, res2=True) == 0
 
 
+def test_pack_job_table_is_host_checked(lib_path):
+    """cce._pack_job builds the FFPackJob a packed convolution contributes to ff_pack_weights_table; the launch cannot
+    check a table that lives in device memory, so every job passes ff_pack_job_check (host logic, no GPU) first: a
+    consistent job passes, and wrong item counts / member layouts / slices are refused with the field named."""
+    import torch.nn as nn
+    from focusflow_official_amd import _hip, cce
+    z, r = nn.Conv2d(160, 48, (1, 5), padding=(0, 2)), nn.Conv2d(160, 80, (1, 5), padding=(0, 2))
+    cpu = torch.device("cpu")
+    for pc in (cce.PackedConv([z, r], cin_slices=[(96, 160), (0, 32)], use_bias=False), cce.PackedConv([z, r]),
+               cce.PackedConv([nn.Conv2d(3, 64, 7, 2, 3)], 4), cce.PackedConv([nn.Conv2d(256, 2, 3, padding=1)])):
+        J, fmt, dfmt = cce._pack_job(pc, True, True, cpu)
+        _hip.call("ff_pack_job_check", ctypes.byref(J))
+        kf, kd = pc.kh * pc.kw * pc.cin_pad, pc.kh * pc.kw * ((pc.cout + 3) // 4 * 4)
+        assert J.items_fwd == pc.cout * ((kf + 31) // 32) * 4 and J.items_dgrad == pc.cin_pad * ((kd + 31) // 32) * 4
+        assert (J.nmem, J.cout, J.cin, J.nslice) == (len(pc.convs), pc.cout, pc.cin, len(pc.cin_slices or ()))
+        assert fmt == (0 if pc.cout <= 2 else dfmt)
+    J, _, _ = cce._pack_job(cce.PackedConv([z, r], cin_slices=[(96, 160), (0, 32)]), True, True, cpu)
+    for field, value, msg in (("items_fwd", J.items_fwd + 4, "items_fwd"), ("items_dgrad", 8, "items_dgrad"), ("cin", 95, "cin does not match the slices"),
+                              ("nmem", 5, "members"), ("cout", J.cout + 1, "do not add up"), ("cout_pad", J.cout - 4, "dgrad rows")):
+        keep = getattr(J, field)
+        setattr(J, field, value)
+        with pytest.raises(_hip.FocusFlowHipError, match=msg):
+            _hip.call("ff_pack_job_check", ctypes.byref(J))
+        setattr(J, field, keep)
+    _hip.call("ff_pack_job_check", ctypes.byref(J))
+    # nothing to pack without a recorded use: prepack is a no-op on a fresh module (and never touches a CPU model)
+    assert cce.prepack(nn.Sequential(z, r), cpu) == 0
+
+
 def test_invalid_arguments_are_rejected_without_a_gpu(lib_path):
     """Argument validation happens before any launch, so it is testable here."""
     from focusflow_official_amd import _hip
