@@ -339,7 +339,13 @@ __global__ __launch_bounds__(64 * NW) void lookup_dma_kernel(const DArgs a) {
                 const float s0 = __fsub_rn(1.f, wy);
                 const f32x2 wa = ew * s0, wb = ew * wy;
                 const f32x2 ta = f32x2{v00[j], v01[j]} * wa, tb = f32x2{v10[j], v11[j]} * wb;
-                o[j] = __fadd_rn(__fadd_rn(__fadd_rn(ta.x, ta.y), tb.x), tb.y);
+                // (the empty statements keep the three additions scalar: the vectoriser paired them across two outputs and
+                // paid six register moves per pair of outputs for three packed additions)
+                float s1 = __fadd_rn(ta.x, ta.y);
+                asm volatile("" : "+v"(s1));
+                float s2 = __fadd_rn(s1, tb.x);
+                asm volatile("" : "+v"(s2));
+                o[j] = __fadd_rn(s2, tb.y);
             }
 #pragma unroll
             for (int p2 = 0; p2 < 3; ++p2) {
