@@ -10,9 +10,11 @@ try:
     t_end = max(k[1] for k in ks)
     ks = [k for k in ks if k[0] >= t_end - win]
 except ValueError:
-    marks = [k[0] for k in ks if sys.argv[2] in k[2]]
+    name, _, which = sys.argv[2].partition(":")          # marker or marker:index (which burst opens the window; default: the last but one)
+    marks = [k[0] for k in ks if name in k[2]]
     bursts = [m for i, m in enumerate(marks) if i == 0 or m - marks[i - 1] > 5e6]       # first of each burst (5 ms apart)
-    a, b = bursts[-2], bursts[-1]
+    i0 = int(which) if which else len(bursts) - 2
+    a, b = bursts[i0], bursts[i0 + 1]
     ks = [k for k in ks if a <= k[0] < b]
 t_end = max(k[1] for k in ks)
 t0 = ks[0][0]
