@@ -75,7 +75,7 @@ extern "C" int ff_launch_timing_end(int which, long long* launches, double* tota
     t.ev.clear();
     return rc;
 }
-// 3: FFConvParams + ep_mode ... ep_b_ld (GRU steps in the conv epilogue).  2: FFConvParams grew res2 / res2_ld / res_split / splitk_ws / splitk, ff_norm_bwd gained dx_amax, the row-major corr
+// 4: entry points only (ff_pack_weights_table, ff_pack_job_check, ff_unpack_wgrad_group, ff_probe_memory_kernel, FF_TIME_PROBE).  3: FFConvParams + ep_mode ... ep_b_ld (GRU steps in the conv epilogue).  2: FFConvParams grew res2 / res2_ld / res_split / splitk_ws / splitk, ff_norm_bwd gained dx_amax, the row-major corr
 // backward entry points went away (round 2).  Callers zero-initialise the WHOLE FFConvParams and check this number.
 extern "C" int ff_abi_version(void) { return FF_ABI_VERSION; }
 
