@@ -617,7 +617,10 @@ def main():
                          "algorithmic_bytes_per_query": per_q, "algorithmic_bytes_per_launch": per_q * q},
         }
         if not args.graph:
-            line["roofline"]["memory_only_kernel"] = memory_only_companion(per_q * q, achieved, device)
+            try:
+                line["roofline"]["memory_only_kernel"] = memory_only_companion(per_q * q, achieved, device)
+            except Exception as e:          # noqa: BLE001 - a measurement aid must not cost the bench line
+                line["roofline"]["memory_only_kernel"] = {"error": f"{type(e).__name__}: {e}"}
         # corr-volume build (BASELINE.md "also reported"): dense HWxC x CxHW contraction on the matrix pipe
         q1 = (args.height // 8) * (args.width // 8)
         vol_flop = 2.0 * (hi - lo) * q1 * q1 * 256
