@@ -618,7 +618,14 @@ def main():
         }
         if not args.graph:
             try:
-                line["roofline"]["memory_only_kernel"] = memory_only_companion(per_q * q, achieved, device)
+                mo = memory_only_companion(per_q * q, achieved, device)
+                traffic = line["roofline"]["traffic"]
+                if traffic and mo["bytes_per_launch"]:
+                    # the same kernel's time scaled to the HBM bytes the counters see for one lookup launch (128-byte lines
+                    # around 64-80-byte window rows: 1.245 x the algorithmic bytes) - a derived figure, not a measurement
+                    mo["scaled_to_counted_traffic_us"] = round(mo["avg_launch_us"] * traffic / mo["bytes_per_launch"], 2)
+                    mo["lookup_over_scaled"] = round(mo["scaled_to_counted_traffic_us"] / (per_launch_ms * 1e3), 4) if per_launch_ms > 0 else None
+                line["roofline"]["memory_only_kernel"] = mo
             except Exception as e:          # noqa: BLE001 - a measurement aid must not cost the bench line
                 line["roofline"]["memory_only_kernel"] = {"error": f"{type(e).__name__}: {e}"}
         # corr-volume build (BASELINE.md "also reported"): dense HWxC x CxHW contraction on the matrix pipe
