@@ -19,7 +19,16 @@ from ._hip import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, FFConvPa
 Tensor = torch.Tensor
 
 
+# The current stream of the current device as a raw hipStream_t.  torch.cuda.current_stream() builds a Stream object through
+# several Python layers (~8 us; a one-pair forward asks ~350 times and is host-bound): the two C entry points behind it
+# are used directly where this torch has them.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
