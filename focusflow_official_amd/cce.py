@@ -71,12 +71,22 @@ class PackedConv:
         _ALL_PACKED.add(self)
 
     def _fwd_key(self):
-        return (ops.conv_precision(),) + tuple(
-            (c.weight._version, c.weight.data_ptr()) + ((c.bias._version, c.bias.data_ptr()) if c.bias is not None else ())
-            for c in self.convs)
+        # (parameters through the module's own table: nn.Module.__getattr__ is several times slower, and a one-pair
+        # forward asks for ~200 of these keys while it is host-bound)
+        k = [ops.conv_precision()]
+        for c in self.convs:
+            w, b = c._parameters["weight"], c._parameters.get("bias")
+            k += (w._version, w.data_ptr())
+            if b is not None:
+                k += (b._version, b.data_ptr())
+        return tuple(k)
 
     def _dgrad_key(self):
-        return (ops.conv_precision(),) + tuple((c.weight._version, c.weight.data_ptr()) for c in self.convs)
+        k = [ops.conv_precision()]
+        for c in self.convs:
+            w = c._parameters["weight"]
+            k += (w._version, w.data_ptr())
+        return tuple(k)
 
     def _small(self):
         # 1- and 2-channel 3x3 heads stay in fp32 rows: ff_conv2d_fwd runs them as dot products on the vector ALU
