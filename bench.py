@@ -70,6 +70,34 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def refuse_lab_switches():
+    """Timing-only ablations return WRONG results by design and tuning overrides change what is measured: a stray variable in
+    the caller's shell must not reach a bench line.  (The library refuses the ablation variables as well: _hip.load.)"""
+    from focusflow_official_amd import _hip
+    bad = _hip.lab_variables_set()
+    if bad:
+        raise SystemExit(f"bench.py: refusing to run with lab switches set in the environment: {', '.join(bad)} "
+                         "(timing-only ablations and tuning overrides; unset them)")
+
+
+def host_issue_time(step, n=5):
+    """Host time to ISSUE one step (no synchronisation inside, the queue drained before every sample) next to the wall
+    time of the same step: with N ranks sharing one host, a rank whose issue time approaches its step time is host-starved,
+    not slow on the GPU - the two cannot be told apart from a throughput number alone."""
+    issue, total = [], []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        issue.append(t1 - t0)
+        total.append(time.perf_counter() - t0)
+    issue.sort()
+    total.sort()
+    return round(issue[len(issue) // 2] * 1e3, 3), round(total[len(total) // 2] * 1e3, 3)
+
+
 def pmc_traffic(queries, pyramid):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r03_lookup_traffic[_fp16].json:
     TCC_EA0_RDREQ x 128 B + WRITE_SIZE), scaled per query, and where the number comes from; (None, reason) if the
@@ -545,9 +573,14 @@ def main():
     if args.harness_selftest:
         return harness_selftest(args)
 
+    refuse_lab_switches()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N ranks share the host: each keeps its CPU-side torch work (fills, index arithmetic, the optimiser in train mode) to
+    # its share of the cores instead of N pools of `cores` threads fighting the N issuing threads
+    host_threads = max(1, host_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    torch.set_num_threads(host_threads)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world)
@@ -595,6 +628,12 @@ def main():
     log(f"{args.steps} timed steps in {elapsed:.3f} s")
     lk, vb = ops.launch_timing_end(ops.TIME_LOOKUP), ops.launch_timing_end(ops.TIME_CORR_BUILD)
     assert torch.isfinite(out[1]).all()
+    # host time to issue one step, MAX over ranks like the step time itself (outside the timed region)
+    issue_ms, issue_total_ms = host_issue_time(step)
+    if world > 1:
+        t = torch.tensor([issue_ms, issue_total_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        issue_ms, issue_total_ms = round(t[0].item(), 3), round(t[1].item(), 3)
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -699,6 +738,9 @@ def main():
                     f"(tools/proto/mfma_peak.hip)",
             "launches": len(conv_ms), "sum_launch_ms": round(tot_ms, 3), "useful_gflop_per_step": round(useful / 1e9, 1)}
         line["rccl_ranks_seen"] = ranks_seen
+        line["host"] = {"host_issue_ms": issue_ms, "step_ms_same_sample": issue_total_ms, "threads_per_rank": host_threads, "cores": host_cores(),
+                        "note": "median host time to issue one step with an empty queue (no sync inside) and the wall time of the same step, "
+                                "MAX over ranks; a rank is host-bound where the two meet"}
         checker = {}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.height, args.width, args.iters, keep=checker)

@@ -145,11 +145,29 @@ class FocusFlowHipError(RuntimeError):
     pass
 
 
+# Timing-only ablations (WRONG results by design) live in the separate lab build (tools/): the product refuses to load
+# while one of their switches is set, so that a stray variable in a shell cannot silently corrupt flow.
+_ABLATION_VARS = ("FF_LOOKUP_ABLATE", "FF_LOOKUP_ABLATE3", "FF_CORR_BUILD_ABLATE", "FF_PATCH_ABLATE")
+# tuning overrides: results stay right, measurements change - bench.py refuses these too
+_TUNING_VARS = ("FF_PATCH_TH", "FF_PATCH_TN", "FF_PATCH_WB1", "FF_PATCH_LDS_PAD", "FF_PATCH_PIN", "FF_SPLIT_TILE", "FF_SPLIT_NST", "FF_SPLIT_OCC",
+                "FF_SPLIT_NO_UNI", "FF_SPLIT_F16_128", "FF_NO_PATCH_CONV", "FF_CORR_BUILD_LDS_PAD", "FF_LOOKUP_IMPL",
+                "FF_LOOKUP_DEPTH", "FF_LOOKUP_BLOCK_WAVES", "FF_LOOKUP_WAVES_PER_CU", "FF_MFMA16", "FF_WGRAD_BLOCKS", "FF_DMA_CONV")
+
+
+def lab_variables_set():
+    """Names of lab switches present in the environment (ablations first)."""
+    return [v for v in _ABLATION_VARS + _TUNING_VARS if os.environ.get(v) is not None]
+
+
 def load():
     """Load the library once.  Raises if it has not been built (no fallback)."""
     global _lib
     if _lib is not None:
         return _lib
+    abl = [v for v in _ABLATION_VARS if os.environ.get(v) is not None]
+    if abl:
+        raise FocusFlowHipError(f"{', '.join(abl)} set in the environment: timing-only ablations return wrong results and are not part of "
+                                "libfocusflow_hip.so; unset them (the lab build under tools/ is where they live)")
     if not os.path.exists(LIB_PATH):
         raise FocusFlowHipError(
             f"{LIB_PATH} is missing: build it with `python -m focusflow_official_amd.build` "

@@ -36,26 +36,32 @@ def build_hip(force=False, verbose=True):
     def compile_one(name):
         src = os.path.join(CSRC, name)
         obj = os.path.join(objdir, name[:-4] + ".o")
-        if force or _newer([src] + hdrs, obj) or os.environ.get("FF_HIPCC_EXTRA_" + name[:-4]) is not None:
-            extra = []
-            with open(src) as f:
-                # files that replay the reference's separately rounded fp32 chains (sampler coordinates, bilinear blend)
-                # say so with a pragma; hipcc does not honour it inside templates / lambdas, so they also get the flag
-                text = f.read()
-                if "#pragma clang fp contract(off)" in text:
-                    extra = ["-ffp-contract=off"]
-                # a file may name further flags of its own: a line "// hipcc-flags: <flags>"
-                for line in text.splitlines():
-                    if line.startswith("// hipcc-flags:"):
-                        extra += line.split(":", 1)[1].split()
-            # experiments: FF_HIPCC_EXTRA_<file stem>="<flags>" (the object is rebuilt when the variable is set)
-            env_extra = os.environ.get("FF_HIPCC_EXTRA_" + name[:-4])
-            if env_extra is not None:
-                extra += env_extra.split()
-            cmd = [HIPCC, *FLAGS, *extra, "-c", src, "-o", obj]
+        extra = []
+        with open(src) as f:
+            # files that replay the reference's separately rounded fp32 chains (sampler coordinates, bilinear blend)
+            # say so with a pragma; hipcc does not honour it inside templates / lambdas, so they also get the flag
+            text = f.read()
+        if "#pragma clang fp contract(off)" in text:
+            extra = ["-ffp-contract=off"]
+        # a file may name further flags of its own: a line "// hipcc-flags: <flags>"
+        for line in text.splitlines():
+            if line.startswith("// hipcc-flags:"):
+                extra += line.split(":", 1)[1].split()
+        # experiments: FF_HIPCC_EXTRA_<file stem>="<flags>"
+        env_extra = os.environ.get("FF_HIPCC_EXTRA_" + name[:-4])
+        if env_extra is not None:
+            extra += env_extra.split()
+        # the flags an object was built with are recorded beside it: an experimental object (FF_HIPCC_EXTRA_*, an edited
+        # hipcc-flags line) is rebuilt as soon as the effective flags differ - also when the variable goes away again
+        cmd = [HIPCC, *FLAGS, *extra, "-c", src, "-o", obj]
+        stamp, want = obj + ".flags", " ".join(cmd[:-4])
+        have = open(stamp).read() if os.path.exists(stamp) else None
+        if force or _newer([src] + hdrs, obj) or have != want:
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
+            with open(stamp, "w") as f:
+                f.write(want)
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:

@@ -40,6 +40,7 @@ class PackedConv:
     use_bias = True
     _w_raw = _wd_raw = _w_split = _wd_split = None
     _used_f = _used_d = False      # get() / get_dgrad() have been asked for: prepack() keeps these layouts fresh
+    _gen = 0
 
     def __init__(self, convs: Sequence[nn.Conv2d], cin_pad: Optional[int] = None,
                  cin_slices: Optional[Sequence[Tuple[int, int]]] = None, use_bias: bool = True):
@@ -61,6 +62,7 @@ class PackedConv:
         for c in self.convs:
             assert c.kernel_size == c0.kernel_size and c.in_channels == c0.in_channels and c.stride == c0.stride
         self._key = None
+        self._gen = 0        # bumped by every repack of the forward rows: derived images (update_block's stage-major mask weights) key on it
         self.w = None
         self.b = None
         self._dkey = None
@@ -115,6 +117,7 @@ class PackedConv:
             if self.fmt != 0:
                 self.w = ops.pack_split(self.w)
             self._key = key
+            self._gen += 1
         return self.w, self.b
 
     def get_dgrad(self):
@@ -258,6 +261,7 @@ def prepack(owner: nn.Module, device) -> int:
     for (pc, nf, nd, kf, kd), (J, fmt, dfmt) in zip(todo, jobs):
         if nf:
             pc.w, pc.fmt, pc._key = (pc._w_raw if fmt == 0 else pc._w_split), fmt, kf
+            pc._gen += 1
         if nd:
             pc.wd, pc.dfmt, pc._dkey = (pc._wd_raw if dfmt == 0 else pc._wd_split), dfmt, kd
     return len(todo)
@@ -305,6 +309,9 @@ def invalidate_packed(module: nn.Module) -> int:
             n += 1
         if getattr(m, "_pair_key", None) is not None:
             m._pair_key = None
+            n += 1
+        if getattr(m, "_mask2_stage_of", None) is not None:     # BasicUpdateBlock.upsample's stage-major image of mask[2]
+            m._mask2_stage = m._mask2_stage_of = None
             n += 1
     return n
 

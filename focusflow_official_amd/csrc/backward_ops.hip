@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const float* dy, int d
     const unsigned stride = gridDim.x * 256u;
     for (unsigned i0 = blockIdx.x * 256u + threadIdx.x; i0 < total; i0 += 4u * stride) {
         f32x4 v[4], yv[4];
-        unsigned off_g[4];
+        size_t off_g[4];
         bool live[4], pad[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const float* dy, int d
             pad[u] = c4 >= cgin;
             v[u] = *reinterpret_cast<const f32x4*>(dy + (size_t)p * dy_ld + cc * 4);
             if (HAS_ACT) yv[u] = *reinterpret_cast<const f32x4*>(y + (size_t)p * y_ld + cc * 4);
-            off_g[u] = p * (unsigned)g_ld + c4 * 4;
+            off_g[u] = (size_t)p * g_ld + c4 * 4;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

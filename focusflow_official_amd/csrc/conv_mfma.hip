@@ -302,14 +302,14 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
                                ff::aligned16(p.in_scale) && ff::aligned16(p.in_shift)),
                "ff_conv2d_fwd: in_scale needs the patch kernel (a split weight format, one segment, 3x3, stride 1, Cin %% 32 == 0)");
     FF_REQUIRE(!p.res2 || (p.res && p.w_format != FF_W_F32 && p.KH == 1 && p.KW == 1 && p.groups == 1 && p.res_split > 0 &&
-                           p.res_split < p.Cout && p.res2_ld >= p.Cout - p.res_split && !getenv("FF_WS_CONV")),
+                           p.res_split < p.Cout && p.res2_ld >= p.Cout - p.res_split),
                "ff_conv2d_fwd: res2 needs res, a split weight format and a 1x1 kernel (0 < res_split < Cout)");
     FF_REQUIRE(!p.stats_part || (ff::aligned16(p.stats_part) && ff_conv2d_stats_parts(pp) > 0),
                "ff_conv2d_fwd: stats_part: this convolution cannot produce statistics (ff_conv2d_stats_parts returned 0) or the buffer is misaligned");
     FF_REQUIRE(p.ep_mode >= FF_EP_NONE && p.ep_mode <= FF_EP_COORDS, "ff_conv2d_fwd: bad ep_mode %d", p.ep_mode);
     if (p.ep_mode == FF_EP_COORDS) {
         FF_REQUIRE(p.w_format == FF_W_F32 && p.Cout == 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 && p.groups == 1 &&
-                   p.act == FF_ACT_NONE && !p.res && p.ep_a && p.ep_b && ff::aligned16(p.ep_b) && (reinterpret_cast<uintptr_t>(p.ep_a) & 7) == 0,
+                   dlh == 1 && dlw == 1 && p.act == FF_ACT_NONE && !p.res && p.ep_a && p.ep_b && ff::aligned16(p.ep_b) && (reinterpret_cast<uintptr_t>(p.ep_a) & 7) == 0,
                    "ff_conv2d_fwd: FF_EP_COORDS belongs to the 2-channel 3x3 flow head in fp32 rows (ep_a = coords1, ep_b = flow4)");
     } else if (p.ep_mode) {
         FF_REQUIRE((p.w_format == FF_W_F16X3 || p.w_format == FF_W_F16) && p.groups == 1 && p.stride == 1 && cin % 32 == 0 && p.KH * p.KW >= 3 && !p.res2 && !p.in_scale &&
@@ -324,6 +324,8 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (p.w_format != FF_W_F32) return ff::conv2d_fwd_split(p, (int)M, cin, s);
     if (const int rc = ff::conv2d_fwd_small(p, cin, s); rc != 1) return rc;    // 1- and 2-channel 3x3 heads: vector ALU
+    // the exact-fp32 MFMA kernels below have no epilogue modes: never drop one silently
+    FF_REQUIRE(p.ep_mode == FF_EP_NONE && !p.stats_part && !p.in_scale && !p.res2, "ff_conv2d_fwd: ep_mode / stats_part / in_scale / res2 are not available in the exact-fp32 format for this shape");
     KernArgs a;
     a.p = p;
     a.M = (int)M;

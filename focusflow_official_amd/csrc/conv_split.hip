@@ -445,9 +445,7 @@ namespace ff {
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s) {
     int rc = conv2d_fwd_stem(p, cin, s);              // the encoders' 7x7 stride-2 stems over NHWC4 (conv_stem.hip)
     if (rc != 1) return rc;
-    rc = (p.ep_mode || p.stats_part) ? 1 : conv2d_fwd_ws(p, cin, s);   // stride-1 "same" convs: wave-specialised patch kernel (no epilogue extras)
-    if (rc != 1) return rc;
-    rc = conv2d_fwd_patch(p, cin, s);                // same shapes, single-role waves (small grids / FF_WS_CONV=0)
+    rc = conv2d_fwd_patch(p, cin, s);                // stride-1 "same" convolutions: patch-stationary kernel
     if (rc != 1) return rc;
     if (p.in_scale) return fail(FF_EINVAL, "ff_conv2d_fwd: in_scale/in_shift: the patch kernel declined this shape");
     if (p.ep_mode) return fail(FF_EINVAL, "ff_conv2d_fwd: ep_mode: the patch kernel declined this shape");

@@ -65,7 +65,6 @@ int conv2d_fwd_stem(const FFConvParams& p, int cin, hipStream_t s);          // 
 int conv2d_stem_stats_parts(const FFConvParams& p, int cin);                  // conv_stem.hip; entries per (image, channel), 0 = not this route
 int conv2d_stats_parts(const FFConvParams& p, int cin);                       // conv_patch.hip; entries per (image, channel), 0 = cannot
 int conv2d_splitk_hint(const FFConvParams& p, int cin);                       // conv_patch.hip; K splits worth using, 0 = none
-int conv2d_fwd_ws(const FFConvParams& p, int cin, hipStream_t s);            // conv_ws.hip (wave-specialised); 1 = not eligible
 // corr_lookup_dma.hip: the LDS-DMA lookup; 1 = not eligible (levels more than 4 GB apart)
 int lookup_dma_fwd(const void* const* levels, int half, const float* coords, long long queries, int h0, int w0, float* out,
                    int out_ld, int* taps_dbg, hipStream_t s);

@@ -388,10 +388,12 @@ class CorrBuildFn(torch.autograd.Function):
         b, h, w, _ = f1.shape
         pending, blk.pending = getattr(blk, "pending", None), None
         if pending:
-            # every lookup of the pass in one launch (+ the pooling chain), if the planes of a query fit LDS
-            d0 = ops.corr_lookup_tiled_bwd_all([c for c, _ in pending], [d for _, d in pending], blk.pyr.h0, blk.pyr.w0) if _LOOKUP_BWD_ALL else None
+            # every lookup of the pass in one launch (+ the pooling chain): LookupFn.backward only queues where that launch
+            # is going to accept the pass (plane sizes and count checked up front), so a refusal here is a library change
+            d0 = ops.corr_lookup_tiled_bwd_all([c for c, _ in pending], [d for _, d in pending], blk.pyr.h0, blk.pyr.w0)
             if d0 is None:
-                blk.grad_pyr = ops.TiledPyramid.empty(blk.pyr.levels[0].shape[0], blk.pyr.h0, blk.pyr.w0, False, f1.device, zero=True)
+                if blk.grad_pyr is None:
+                    blk.grad_pyr = ops.TiledPyramid.empty(blk.pyr.levels[0].shape[0], blk.pyr.h0, blk.pyr.w0, False, f1.device, zero=True)
                 for c, d in pending:
                     ops.corr_lookup_tiled_bwd(blk.grad_pyr, c, d)
             else:
@@ -418,10 +420,20 @@ class LookupFn(torch.autograd.Function):
         (coords,) = ctx.saved_tensors
         blk = ctx.block
         # deferred: the gradient of the pyramid is a sum over the lookups and nothing reads it before CorrBuildFn.backward,
-        # which scatters all of them in one launch (ops.corr_lookup_tiled_bwd_all)
-        if getattr(blk, "pending", None) is None:
-            blk.pending = []
-        blk.pending.append((coords, _dense(dout)))
+        # which scatters all of them in one launch (ops.corr_lookup_tiled_bwd_all) - where that launch exists for the
+        # pass: a query's four planes must fit its LDS and it takes at most LOOKUP_BWD_ALL_MAX lookups.  Otherwise the
+        # gradient is scattered right away and nothing is retained (large crops would keep every dout alive on top of
+        # the zeroed gradient pyramid).
+        pend = getattr(blk, "pending", None) or []
+        if _LOOKUP_BWD_ALL and blk.grad_pyr is None and len(pend) < ops.LOOKUP_BWD_ALL_MAX and ops.lookup_bwd_all_fits(blk.pyr.h0, blk.pyr.w0):
+            pend.append((coords, _dense(dout)))
+            blk.pending = pend
+        else:
+            if blk.grad_pyr is None:
+                blk.grad_pyr = ops.TiledPyramid.empty(blk.pyr.levels[0].shape[0], blk.pyr.h0, blk.pyr.w0, False, dout.device, zero=True)
+            blk.pending = None
+            for c, d in pend + [(coords, _dense(dout))]:       # (the queue is only non-empty when the pass has more lookups than one launch takes)
+                ops.corr_lookup_tiled_bwd(blk.grad_pyr, c, d)
         return torch.zeros(1, device=dout.device), None, None
 
 

@@ -857,6 +857,14 @@ def corr_lookup_tiled_bwd(dpyr: TiledPyramid, coords: Tensor, dout: Tensor):
     _hip.call("ff_corr_lookup_tiled_bwd", dpyr.ptrs(), _p(coords), _p(dout), _ld(dout), b * h * w, dpyr.h0, dpyr.w0, _stream())
 
 
+LOOKUP_BWD_ALL_MAX = 32      # csrc/corr_lookup_tiled.hip: LBA_MAXT
+
+
+def lookup_bwd_all_fits(h0: int, w0: int) -> bool:
+    """Whether ff_corr_lookup_tiled_bwd_all takes planes of this size (the four gradient planes of a query in 64 KB of LDS)."""
+    return sum((h0 >> l) * (w0 >> l) for l in range(4)) * 4 <= 64 * 1024
+
+
 def corr_lookup_tiled_bwd_all(coords_list, dout_list, h0: int, w0: int):
     """d(volume) [B*Q][plane_0] (tiled fp32) from every lookup of a pass at once (ff_corr_lookup_tiled_bwd_all), or None
     when the kernel declines (planes too large for LDS, more than 32 lookups): the caller then goes launch by launch."""

@@ -144,20 +144,6 @@ def test_stem_conv_kernel(ops, b, h, w, cout):
     close(nchw(out2), torch.relu(conv * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), what="stem conv, scale/shift + relu")
 
 
-def test_conv2d_wave_specialised_kernel_opt_in():
-    """conv_ws.hip (persistent, wave-specialised) is opt-in via FF_WS_CONV=1, read once per process: run the
-    half-precision conv cases through it in ONE child process and require the same tolerances."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, FF_WS_CONV="1", FF_DEBUG_DISPATCH="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        os.path.abspath(__file__), "-k", "test_conv2d and not fp32 and not wave_specialised"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
-
 def test_conv_epilogue_scale_shift_and_outscale(ops):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, 64, 16, 24, generator=g)
@@ -472,6 +458,50 @@ def test_config1_384x512_and_batch_consistency(det_sd):
     for i in range(8):
         close(fu8[i].cpu(), flow_up[0].cpu(), rtol=0, atol=5e-4, what=f"batch sample {i}")
         assert torch.equal(fu8[i], fu8[0])
+
+
+def test_mask_stage_image_follows_an_in_place_weight_write(det_sd, monkeypatch):
+    """`weight.data.mul_()` changes neither the parameter's version nor its storage; after
+    cce.invalidate_packed the fused mask / up-sampling kernel must run on the NEW mask-head weights (its stage-major
+    image is keyed on the PackedConv's pack generation) - compare it with the two-launch route, which repacks."""
+    from focusflow_official_amd import cce, raft_net
+    inp = [t.to(DEV) for t in orc.shifted_pair(1, 128, 160, seed=12)]
+    m = _model(det_sd)
+    with torch.no_grad():
+        before = m(*inp, raft_iters=3, test_mode=True)[1].clone()
+        m.flow_net.update_block.mask[2].weight.data.mul_(1.5)
+        m.flow_net.update_block.mask[2].bias.data.add_(0.1)
+        assert cce.invalidate_packed(m) > 0
+        fused = m(*inp, raft_iters=3, test_mode=True)[1].clone()
+        monkeypatch.setattr(raft_net, "_MASK_UPSAMPLE", False)
+        plain = m(*inp, raft_iters=3, test_mode=True)[1].clone()
+    assert (fused - before).abs().max() > 1e-3, "the new mask-head weights must change the up-sampled flow"
+    close(fused.cpu(), plain.cpu(), rtol=0, atol=2e-5, what="fused mask/up-sampling after invalidate_packed vs the two launches")
+
+
+def test_config2_8_distinct_pairs_384x512_vs_oracle(det_sd):
+    """The headline launch shapes on eight DIFFERENT pairs (8 x 48 x 64 = 24 576 queries per lookup, the launch the bench
+    times): every sample of the batch against the CPU oracle run on that sample alone.  Eight copies of one pair
+    (test_config1_384x512_and_batch_consistency) cannot see a cross-sample indexing slip - a sample reading its
+    neighbour's pyramid plane, context features or coordinates gives the right answer there."""
+    shifts = [(3, -5), (-4, 2), (1, 6), (-2, -3), (5, 1), (0, -7), (-6, 4), (2, 2)]
+    pairs = [orc.shifted_pair(1, 384, 512, seed=40 + i, shift=sh) for i, sh in enumerate(shifts)]
+    batch = [torch.cat([p[k] for p in pairs], 0).to(DEV) for k in range(4)]
+    m = _model(det_sd)
+    with torch.no_grad():
+        fl8, fu8 = m(*batch, raft_iters=12, test_mode=True)
+    fl8, fu8 = fl8.cpu(), fu8.cpu()
+    means = []
+    for i, p in enumerate(pairs):
+        with torch.no_grad():
+            ref_low, ref_up = orc.ffraft_forward(det_sd, *p, raft_iters=12, test_mode=True)
+        close(fl8[i:i + 1], ref_low, rtol=0, atol=1e-3, what=f"distinct pair {i} flow_low")
+        close(fu8[i:i + 1], ref_up, rtol=0, atol=1e-3, what=f"distinct pair {i} flow_up")
+        means.append(ref_low)
+    # the samples really are different problems: pairwise, their flows are further apart than the tolerance by far
+    for i in range(8):
+        for j in range(i):
+            assert (means[i] - means[j]).abs().max() > 0.05, (i, j)
 
 
 def test_reduced_precision_mode_end_to_end_epe_against_the_references_tf32_level(det_sd):

@@ -1,3 +1,5 @@
+// PROTOTYPE (round 1-3 experiment, not built into libfocusflow_hip.so since round 4): measured on par with conv_patch.hip,
+// 3 % slower end to end.  Kept for the record of what it measured.
 // Wave-specialised, persistent, patch-stationary fp16x3 convolution (stride-1 "same" convs, Cin % 32 == 0).
 //
 // Findings that shaped it ("conv kernels"): in conv_patch.hip the memory phase and the MFMA phase of
