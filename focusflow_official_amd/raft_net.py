@@ -15,7 +15,6 @@ _MASK_UPSAMPLE = os.environ.get("FF_MASK_UPSAMPLE", "1") != "0"   # A/B switch: 
 _GRU_CTX_ONCE = os.environ.get("FF_GRU_CTX_ONCE", "1") != "0"      # measurement switch (see SepConvGRU.prepare)
 _STREAMS_MIN_PIXELS = int(os.environ.get("FF_STREAMS_MIN_PIXELS", "700000"))   # below: host-bound, the fork / join events cost more than they gain
 _ENC_STREAMS = os.environ.get("FF_ENC_STREAMS", "1") != "0"           # cnet on a second stream beside fnet (inference)
-_UPSAMPLE_LATE = os.environ.get("FF_UPSAMPLE_LATE", "1") != "0"      # A/B switch: the up-sampling of iteration k is issued behind the lookup of iteration k + 1 (inference)
 _UPDATE_SPLIT = int(os.environ.get("FF_UPDATE_SPLIT", "1"))         # experiment: update loop of n batch slices on n streams
 
 
@@ -164,19 +163,6 @@ class RAFT(nn.Module):
         # inference: the mask head's 1x1 convolution and the convex up-sampling run as one kernel (no 576-channel mask tensor)
         fused_coords = _COORDS_EPILOGUE and not taped and not torch.is_grad_enabled() and coords1.is_contiguous()
         fused_up = _MASK_UPSAMPLE and not taped and not torch.is_grad_enabled() and ops.w_format() in (_hip.W_F16X3, _hip.W_F16)
-        # The lookup of iteration k + 1 needs coords1 (0.2 MB, written by the flow head's epilogue), not the 25 MB of
-        # up-sampled flow the mask kernel of iteration k leaves dirty in L2: issued behind the lookup (same stream, and
-        # behind the fork of the motion encoder's side stream) the up-sampling no longer sits in front of the one
-        # bandwidth-bound kernel of the loop (MI355X_MICROARCH.md: a kernel pays for the dirty bytes of its predecessor).
-        late = fused_up and _UPSAMPLE_LATE and not lazy
-        waiting = []                            # (mask head's hidden tensor, flow4) of the previous iteration
-
-        def flush():
-            nonlocal flow_up
-            while waiting:
-                flow_up = self.update_block.upsample(*waiting.pop(0))
-                flow_predictions.append(flow_up)
-
         for it in range(iters):
             # coords1 is advanced in place by ff_coords_step (raw pointer: autograd cannot see it), so a
             # recorded lookup keeps its own snapshot for the backward scatter
@@ -188,27 +174,22 @@ class RAFT(nn.Module):
             need_mask = not lazy or it == iters - 1
             if fused_coords and need_mask:      # the flow head's last convolution takes the coordinate step with it
                 nflow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
-                net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre, defer_mask=fused_up, coords_out=(coords1, nflow4),
-                                                            after_lookup=flush if late else None)
+                net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre, defer_mask=fused_up, coords_out=(coords1, nflow4))
                 flow4 = nflow4
             else:
-                net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre, defer_mask=fused_up,
-                                                            after_lookup=flush if late else None)
+                net, up_mask, delta = self.update_block.run(net, inp, corr, flow4, fill, need_mask, gru_pre, defer_mask=fused_up)
                 flow4 = ops.empty_nhwc(b, h8, w8, 4, cnet)
                 ops.coords_step(coords1, delta.detach(), flow4, None)         # coords1 += delta
             if need_mask:
-                if fused_up and late:
-                    waiting.append((up_mask, flow4))
-                    if it == iters - 1:
-                        flush()
-                elif fused_up:
+                if fused_up:
+                    # (issuing this behind the NEXT iteration's lookup - so that the lookup's predecessor is the flow head's
+                    # 0.2 MB instead of these 25 MB of dirty output - was measured: 540 -> 532 pairs/s, lookup 19.4 -> 19.8 us)
                     flow_up = self.update_block.upsample(up_mask, flow4)
                 elif fn.recording(delta, up_mask):
                     flow_up = fn.UpsampleFn.apply(flow4, delta, up_mask)
                 else:
                     flow_up = ops.upsample_flow(flow4, up_mask)
-                if not (fused_up and late):
-                    flow_predictions.append(flow_up)
+                flow_predictions.append(flow_up)
             out.update(flow4=flow4, flow_up=flow_up, preds=flow_predictions)
             yield
 

@@ -118,11 +118,9 @@ class BasicMotionEncoder(nn.Module):
         self._f1, self._f2 = PackedConv([self.convf1], 4), PackedConv([self.convf2])
         self._cv = PackedConv([self.conv])
 
-    def run(self, flow4, corr, fill_flow, after_lookup=None):
+    def run(self, flow4, corr, fill_flow):
         """flow4: (B,H,W,4) zero-padded flow.  Returns motion (B,H,W,128): 126 conv channels, and
-        `fill_flow(motion)` writes the flow into channels 126:128 (torch.cat([out, flow]), update.py:97).
-        after_lookup: called once the side stream has been forked behind the lookup - work of the PREVIOUS iteration that
-        the caller wants on the main stream behind the lookup but not in front of the flow branch (RAFT._loop_steps)."""
+        `fill_flow(motion)` writes the flow into channels 126:128 (torch.cat([out, flow]), update.py:97)."""
         c1 = self._c1p if corr.shape[3] == self._c1p.cin_pad else self._c1
         if _SIDE_STREAM and not ops.policy.single_stream and not torch.is_grad_enabled():
             # Inference: the flow branch (convf1 -> convf2) does not depend on the lookup and neither branch fills the
@@ -138,14 +136,10 @@ class BasicMotionEncoder(nn.Module):
                 join = torch.cuda.Event()
                 join.record(side)
             flow4.record_stream(side)          # allocated on the main stream, read on the side stream
-            if after_lookup is not None:
-                after_lookup()
             cor = self._c2(c1(corr, act=ACT_RELU), act=ACT_RELU)
             main.wait_event(join)
             flo.record_stream(main)            # allocated on the side stream, read on the main stream
             return fn.conv(self._cv, [cor, flo], act=ACT_RELU, pad_out=True, fill_tail=fill_flow)
-        if after_lookup is not None:
-            after_lookup()
         cor = fn.conv(self._c2, fn.conv(c1, corr, act=ACT_RELU), act=ACT_RELU)
         flo = fn.conv(self._f2, fn.conv(self._f1, flow4, act=ACT_RELU), act=ACT_RELU)
         return fn.conv(self._cv, [cor, flo], act=ACT_RELU, pad_out=True, fill_tail=fill_flow)
@@ -164,13 +158,13 @@ class BasicUpdateBlock(nn.Module):
         self._flow2 = PackedConv([self.flow_head.conv2])
         self._mask2 = PackedConv([self.mask[2]])
 
-    def run(self, net, inp, corr, flow4, fill_flow, need_mask=True, gru_pre=None, defer_mask=False, coords_out=None, after_lookup=None):
+    def run(self, net, inp, corr, flow4, fill_flow, need_mask=True, gru_pre=None, defer_mask=False, coords_out=None):
         """-> (net, up_mask, delta_flow), all NHWC.  update.py:126-135.  need_mask=False (inference only, opt-in)
         leaves out the up-sampling mask head when the caller is going to discard it.  defer_mask (inference): up_mask
         comes back as the mask head's HIDDEN tensor (B,H,W,256) - the caller finishes it with upsample() below (the
         second mask convolution and the convex up-sampling as one launch).  coords_out = (coords1, flow4_next) (inference):
         the flow head's last convolution also takes the coordinate step coords1 += delta, flow4_next = coords1 - grid."""
-        motion = self.encoder.run(flow4, corr, fill_flow, after_lookup)
+        motion = self.encoder.run(flow4, corr, fill_flow)
         net = self.gru.run(net, [inp, motion], gru_pre)
         if not need_mask:
             return net, None, fn.conv(self._flow2, fn.conv(self._head1, net, act=ACT_RELU))
