@@ -32,6 +32,7 @@ class FFConvParams(C.Structure):
         ("splitk_ws", _fp), ("splitk", C.c_int),
         ("ep_mode", C.c_int), ("ep_split", C.c_int), ("ep_a", _fp), ("ep_a_ld", C.c_int), ("ep_b", _fp), ("ep_b_ld", C.c_int),
         ("stats_part", _fp),
+        ("x_fmt", C.c_int * MAX_SEG), ("y_fmt", C.c_int), ("y_fmt_from", C.c_int), ("y2", _fp), ("y2_ld", C.c_int),
     ]
 
 
@@ -83,6 +84,7 @@ _SIGS = {
     "ff_corr_lookup_tiled_bwd": [C.POINTER(_fp), _fp, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
     "ff_corr_pyramid_tiled_bwd": [_fp, _fp, _fp, _fp, _ll, C.c_int, C.c_int, _fp],
     "ff_act_copy": [_fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
+    "ff_split_copy": [_fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, C.c_int, _fp],
     "ff_coords_init": [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_coords_step": [_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_gru_rh": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
@@ -137,7 +139,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint", "ff_conv2d_stats_parts"])
 
-ABI_VERSION = 4      # include/focusflow_hip.h: FF_ABI_VERSION
+ABI_VERSION = 5      # include/focusflow_hip.h: FF_ABI_VERSION
 _lib = None
 
 

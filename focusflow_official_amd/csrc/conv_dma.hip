@@ -1,0 +1,421 @@
+// Convolutions over SPLIT-PAIR activations (FF_FMT_SPLIT, focusflow_hip.h): stride-1 "same" 3x3 / 1x5 / 5x1 layers whose
+// inputs were written by their producers as [x0: 32 fp16 | x1: 32 fp16] per 32-channel chunk - the update block's
+// motion encoder, SepConvGRU and heads (update.py:45-60, 89-97, 121-135), twelve times per forward.
+//
+// What conv_patch.hip pays for per 32-channel chunk and block - load fp32 -> convert -> split -> ds_write of the input
+// patch through registers (16 % of its time), an 8 KB weight chunk per tap through registers and LDS with two barriers
+// (10 %), and one LDS fragment read per MFMA (12 %; DESIGN.md section 4, the ablation table) - is removed here:
+//
+//   * the patch with its halo travels L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR staging, no VALU, zero
+//     padding by the buffer's range check; two patch buffers, the next chunk's patch in flight during this chunk's taps;
+//   * the weights never touch LDS: the four waves of a block own DIFFERENT output channels (1 x 4 wave grid over N) and
+//     every wave loads its own 16 x 32 A fragments straight from the packed rows (a lane's 16 bytes = one k-group of one
+//     channel: the rows are already in MFMA operand order), one tap ahead, into two register sets;
+//   * so the only barrier left is ONE per 32-channel chunk (patch buffers flip), and a wave reads
+//     2 x TH fragments per 3 x NV x TH MFMAs: 0.33 LDS reads per MFMA at NV = 2 (conv_patch: 1.0 / 0.5).
+//
+// Matrix form: v_mfma_f32_16x16x32_f16, A = weights (rows = 16 output channels), B = 16 pixels of one patch row; a lane
+// then owns FOUR CONSECUTIVE CHANNELS of a pixel (the epilogue's 16-byte loads / stores, and the two 8-byte stores of a
+// split-pair output).  Arithmetic and summation order are those of conv_patch.hip's 16x16x32 variant: chunk -> tap ->
+// three terms (w0 x0, w1 x0, w0 x1), so a layer computes the same bits whichever of the two kernels runs it.
+//
+// LDS image of a patch: row r = py * PW + px (PW = 16 + KW - 1, even), 128 bytes per row, the eight 16-byte slots of a
+// row XOR-swizzled by (px >> 1) & 7 ON THE SOURCE SIDE (a DMA lane picks which slot of its pixel it fetches).  A B-fragment
+// read (lane = (i, g): pixel column PI16(i) + dx, k-group g) is then free of bank conflicts for every tap: the hardware
+// serves {i = 0-3, 12-15 of k-group g} together with {i = 4-11 of g + 1}; PI16 puts the first set on odd and the second
+// on even columns, i.e. on different halves of the 64 banks (PW even), and eight same-parity consecutive columns differ in
+// (px >> 1) & 7.  Because the key depends on px only, a tap's dy and the pixel row u are plain immediate offsets: the
+// main loop has no address arithmetic at all.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include "ff_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char* lds_ptr_t;
+
+__device__ __forceinline__ int PI16(int i) { return (i >= 4 && i < 12) ? 2 * (i - 4) : (i < 4 ? 2 * i + 1 : 2 * (i - 12) + 9); }
+
+struct DArgs {
+    FFConvParams p;
+    int Cin, nci;
+    int tiles_x, tiles_y, n_tiles;
+    long long w_row_bytes;
+};
+
+__device__ __forceinline__ f16x8 lds_ld16(unsigned addr) { return *(__attribute__((address_space(3))) const f16x8*)(unsigned long)addr; }
+
+constexpr unsigned OOB = 0x7fffffffu;     // + any soffset < 2^31 stays below 2^32: the range check sees it out of range -> zeros
+
+// one LDS-DMA piece: 64 lanes x 16 bytes -> 1 KB at LDS address `dst` (M0), source = rsrc base + voff + soff
+__device__ __forceinline__ void dma_piece(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned dst, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rs), "s"(dst), "s"(soff)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// KH x KW taps; TH pixel rows x 16 columns per block; NV 16-channel tiles per wave (block = 4 waves = 64 NV channels)
+// EPI: FFConvParams.ep_mode (GRU steps, motion tail); TERMS 3 (f16x3) or 1 (f16)
+template <int KH, int KW, int TH, int NV, int TERMS, int EPI>
+__device__ __forceinline__ void conv_dma_body(const DArgs& a) {
+    constexpr int PW = 16 + KW - 1, PH = TH + KH - 1, NPIX = PH * PW, NPIECE = (NPIX + 7) / 8, NPP = (NPIECE + 3) / 4;
+    constexpr int PBYTES = NPIECE * 1024, NT = KH * KW, NWL = NV * (TERMS == 3 ? 2 : 1);
+    static_assert(PW % 2 == 0, "the bank argument needs an even patch width");
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // two patch buffers
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem;
+    const FFConvParams& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W;
+    // blocks of one XCD (blockIdx % 8) take a contiguous run of (pixel tile, channel tile): the channel tiles of a pixel
+    // tile - which read the same patch - then meet in one L2
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, x = bid & 7;
+        bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (bid >> 3);
+    }
+    const int nt = bid % a.n_tiles; bid /= a.n_tiles;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int bimg = bid / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * 16, n0 = nt * (64 * NV) + wave * (16 * NV);    // n0: this WAVE's first output channel
+
+    const long long pix_total = (long long)p.B * H * W;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((long long)p.Cout * a.w_row_bytes), 0x00020000);
+    const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
+
+    // ---- DMA roles: piece pc = wave + 4 j covers LDS rows 8 pc .. 8 pc + 7; lane -> row (lane >> 3), slot (lane & 7)
+    // per piece one word: (image pixel << 7) | byte offset of the source slot inside the pixel's 128-byte chunk, or -1
+    // (outside the image / past the patch: zeros)
+    int ppix[NPP];
+#pragma unroll
+    for (int j = 0; j < NPP; ++j) {
+        const int r = (wave + 4 * j) * 8 + (lane >> 3);
+        const int py = r / PW, px = r - py * PW;
+        const int yy = y0 - p.pad_h + py, xx = x0 - p.pad_w + px;
+        const bool in = r < NPIX && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        ppix[j] = in ? ((((bimg * H + yy) * W + xx) << 7) | (((lane & 7) ^ ((px >> 1) & 7)) * 16)) : -1;
+    }
+    // (segment bookkeeping by mask arithmetic on scalars: `?:` chains over kernel-argument arrays or over buffer resources
+    // become a scratch-resident table whose loads - and their vmcnt(0) - would sit inside the pipelined loop)
+    const int ld0 = p.x_ld[0] * 4, ld1 = p.x_ld[1] * 4, ld2 = p.x_ld[2] * 4;
+    const unsigned long long xp0 = (unsigned long long)p.x[0], xp1 = (unsigned long long)p.x[1], xp2 = (unsigned long long)p.x[2];
+    auto issue_patch = [&](int c, int buf) {          // 32-channel chunk c of the concatenated input -> patch buffer buf
+        const int ci = c * 32;
+        const int in0 = -(int)(ci < c0), in1 = -(int)(ci >= c0 && ci < c01), in2 = -(int)(ci >= c01);     // all ones / zero
+        const int ldb = (ld0 & in0) | (ld1 & in1) | (ld2 & in2);
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((ci - (c0 & (in1 | in2)) - ((c01 - c0) & in2)) * 4);
+        const unsigned long long xp = (xp0 & (unsigned long long)(long long)in0) | (xp1 & (unsigned long long)(long long)in1) | (xp2 & (unsigned long long)(long long)in2);
+        // (readfirstlane: the asm below needs the descriptor in scalar registers whatever unit computed the select)
+        const unsigned long long xpu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)xp);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(xpu), 0, __builtin_amdgcn_readfirstlane((int)(pix_total * ldb)), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NPP; ++j) {
+            if ((wave + 4 * j) < NPIECE) {       // wave-uniform
+                const unsigned voff = ppix[j] >= 0 ? __umul24((unsigned)(ppix[j] >> 7), (unsigned)ldb) + (unsigned)(ppix[j] & 127) : OOB;
+                dma_piece(voff, rs, lds0 + buf * PBYTES + (wave + 4 * j) * 1024, soff);
+            }
+        }
+    };
+    // ---- weights: lane (i, g) holds k-group g of channel n0 + 16 v + i; term 1 = + 64 bytes
+    const int i16 = lane & 15, g16 = lane >> 4;
+    int woff[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int n = n0 + 16 * v + i16;
+        woff[v] = n < p.Cout ? (int)(n * a.w_row_bytes) + g16 * 16 : (int)(OOB - 64);
+    }
+    // (ordinary buffer loads: the compiler keeps the registers and counts vmcnt for them - an asm load into a register the
+    // compiler believes ready was copied around by the register allocator BEFORE its data had landed.  The LDS-DMA pieces are
+    // asm and unknown to that count, which makes the compiler's waits conservative, never early: vmcnt(N) leaves the N
+    // youngest operations in flight whatever they are.)
+    f32x4 wr[2][NV][2];     // [register set][channel tile][term]
+    auto issue_w = [&](auto set_tag, int kc) {
+        constexpr int SET = decltype(set_tag)::value;
+        const int soff = kc * 128;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            wr[SET][v][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[v], soff, 0));
+            if (TERMS == 3) wr[SET][v][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[v] + 64, soff, 0));
+        }
+    };
+
+    // ---- B fragments: pixel column PI16(i) + dx of patch row u + dy
+    const int pcol = PI16(i16);
+
+    f32x4 acc[NV][TH];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int u = 0; u < TH; ++u) acc[v][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nci = a.nci;
+
+    issue_patch(0, 0);
+    issue_w(std::integral_constant<int, 0>{}, 0);
+    // One step = one (chunk c, tap t).  A RUN-TIME loop over the steps, two per trip so that the weight register sets
+    // alternate without copies (set of step s = s & 1): the accumulators are loop-carried values and stay in place - fully
+    // unrolled, every MFMA chain ended in a fresh register and the kernel needed twice the accumulator registers.
+    // Memory operations of a wave, in issue order (vmcnt counts them in order):
+    //   step (c, 0):  W(c, 1)  P(c + 1)        step (c, 1):  W(c, 2)        ...        step (c, NT - 1):  W(c + 1, 0)
+    // Step (c, t) uses W(c, t), loaded one step earlier.  At a chunk's top everything older than the NWL weight loads of
+    // W(c, 0) must have landed - that includes the patch of chunk c, issued a whole chunk ago.
+    const int nsteps = nci * NT;
+    auto step = [&](int s, auto set_tag) {
+        constexpr int CUR = decltype(set_tag)::value, NXT = CUR ^ 1;
+        const int c = s / NT, t = s - c * NT, dy = t / KW, dx = t - dy * KW;       // (scalar unit; NT, KW are constants)
+        const bool more = c + 1 < nci, last_tap = t + 1 == NT;
+        if (t == 0) {
+            wait_vm<NWL>();
+            __builtin_amdgcn_s_barrier();      // every wave's pieces of patch c have landed; everybody is done with the other buffer
+        }
+        // (unconditionally - the last step re-reads chunk 0 for nothing: a load under a condition would leave the compiler's
+        // vmcnt bookkeeping with two histories to merge, and it then waits for vmcnt(0), i.e. for the loads just issued)
+        issue_w(std::integral_constant<int, NXT>{}, s + 1 < nsteps ? (last_tap ? c + 1 : (t + 1) * nci + c) : 0);
+        __builtin_amdgcn_sched_barrier(0);     // the loads stay HERE: left alone the scheduler sinks them below this tap's MFMAs (fewer live registers) and the next tap starts with their round trip
+        // this lane's fragment rows of the tap: column px = pcol + dx (swizzle key (px >> 1) & 7), patch row dy (+ u: immediates)
+        const int px = pcol + dx;
+        const unsigned sw = (unsigned)((px >> 1) & 7);
+        const unsigned rowb = lds0 + (unsigned)(c & 1) * PBYTES + (unsigned)((dy * PW + px) * 128);
+        const unsigned xa0 = rowb + ((g16 ^ sw) << 4), xa1 = rowb + (((4 + g16) ^ sw) << 4);
+#pragma unroll
+        for (int u = 0; u < TH; ++u) {
+            const f16x8 xa = lds_ld16(xa0 + u * PW * 128);
+            f16x8 xb;
+            if (TERMS == 3) xb = lds_ld16(xa1 + u * PW * 128);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const f16x8 w0 = __builtin_bit_cast(f16x8, wr[CUR][v][0]);
+                acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa, acc[v][u], 0, 0, 0);
+                if (TERMS == 3) {
+                    const f16x8 w1 = __builtin_bit_cast(f16x8, wr[CUR][v][1]);
+                    acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa, acc[v][u], 0, 0, 0);
+                    acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xb, acc[v][u], 0, 0, 0);
+                }
+            }
+        }
+        // schedule of the tap: the fragment reads run two pixel rows ahead of the MFMAs (three rows of fragments live, not TH)
+        constexpr int RD = TERMS == 3 ? 2 : 1, LEAD = TH < 2 ? TH : 2;
+        __builtin_amdgcn_sched_group_barrier(0x100, RD * LEAD, 0);
+#pragma unroll
+        for (int u = 0; u < TH; ++u) {
+            if (u + LEAD < TH) __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NV * TERMS, 0);
+        }
+        // the next chunk's patch, once per chunk, BEHIND this tap's waits: the compiler's vmcnt(N) for the weights does not
+        // know the DMA pieces and would otherwise wait for pieces (or weight loads) issued a moment ago; from here they have
+        // the whole of tap 1 to land before a weight wait reaches back to them
+        if (t == 0 && more) issue_patch(c + 1, (c + 1) & 1);
+    };
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        step(s, std::integral_constant<int, 0>{});
+        step(s + 1, std::integral_constant<int, 1>{});
+    }
+    if (s < nsteps) step(s, std::integral_constant<int, 0>{});
+
+    // ---- epilogue (conv_patch.hip's 16x16x32 form): acc[v][u][r] = channel n4 + r (n4 = n0 + 16 v + 4 g) of pixel (y0 + u, x0 + pcol)
+    // Pixel rows in groups of four: values, then ALL operand loads of the group together, then the arithmetic and the stores
+    // (eight rows at a time need 96 registers beside the accumulators and spill the loop's DMA roles).
+    const float xinv = ff::SPLIT_INV;
+    const int x = x0 + pcol;
+    const bool vec_y = (p.y_ld & 3) == 0 && ff::aligned16(p.y);
+    const bool vec_r = !p.res || ((p.res_ld & 3) == 0 && ff::aligned16(p.res));
+    constexpr int UG = 4;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int n4 = n0 + v * 16 + g16 * 4;
+        if (EPI == FF_EP_MOTION_TAIL ? n4 >= p.Cout + 2 : n4 >= p.Cout) continue;
+        const bool full = n4 + 3 < p.Cout;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, cs = {1.f, 1.f, 1.f, 1.f}, ct = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = min(n4 + r, p.Cout - 1);
+            if (p.bias) bias[r] = p.bias[n];
+            if (p.ch_scale) { cs[r] = p.ch_scale[n]; ct[r] = p.ch_shift[n]; }
+        }
+        int nv = min(4, p.Cout - n4);
+        const bool tail = EPI == FF_EP_MOTION_TAIL && n4 + 3 >= p.Cout;       // the group that holds channels Cout, Cout + 1 (Cout % 4 == 2)
+        if (tail) nv = 4;
+        const bool out_full = nv == 4;
+        const bool split_out = p.y_fmt == FF_FMT_SPLIT && n4 >= p.y_fmt_from;
+#pragma unroll
+        for (int ug = 0; ug < TH; ug += UG) {
+            f32x4 vv[UG], rr[UG], zz[UG];
+            long long po[UG];
+#pragma unroll
+            for (int k = 0; k < UG; ++k) {
+                const int y = y0 + ug + k;
+                po[k] = (y < H && x < W) ? ((long long)bimg * H + y) * W + x : -1;
+                f32x4 t = acc[v][ug + k] * xinv + bias;
+                t *= p.out_scale;
+                if (p.ch_scale) t = t * cs + ct;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = ff::apply_act(t[r], p.act);
+                vv[k] = t;
+            }
+            if (p.res) {
+#pragma unroll
+                for (int k = 0; k < UG; ++k) {
+                    rr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (po[k] < 0) continue;
+                    const float* rp2 = p.res + po[k] * p.res_ld + n4;
+                    if (full && vec_r) rr[k] = *reinterpret_cast<const f32x4*>(rp2);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n4 + r < p.Cout) rr[k][r] = rp2[r];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < UG; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[k][r] = ff::apply_act(vv[k][r] + rr[k][r], p.act_res);
+            }
+            if constexpr (EPI == FF_EP_GRU_RH) {          // [z | r] -> [z | r * h] (update.py:47-48)
+                if (n4 >= p.ep_split) {
+#pragma unroll
+                    for (int k = 0; k < UG; ++k) rr[k] = po[k] >= 0 ? *reinterpret_cast<const f32x4*>(p.ep_a + po[k] * p.ep_a_ld + (n4 - p.ep_split)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < UG; ++k)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vv[k][r] = __fmul_rn(vv[k][r], rr[k][r]);
+                }
+            }
+            if constexpr (EPI == FF_EP_GRU_BLEND) {       // v = tanh(q) -> (1 - z) h + z v (update.py:49), z = ep_a, h = ep_b
+#pragma unroll
+                for (int k = 0; k < UG; ++k) {
+                    zz[k] = po[k] >= 0 ? *reinterpret_cast<const f32x4*>(p.ep_a + po[k] * p.ep_a_ld + n4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    rr[k] = po[k] >= 0 ? *reinterpret_cast<const f32x4*>(p.ep_b + po[k] * p.ep_b_ld + n4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int k = 0; k < UG; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        vv[k][r] = __fadd_rn(__fmul_rn(__fsub_rn(1.f, zz[k][r]), rr[k][r]), __fmul_rn(zz[k][r], vv[k][r]));
+            }
+            if constexpr (EPI == FF_EP_MOTION_TAIL) {     // channels Cout, Cout + 1 of the padded buffer = flow = coords1 - grid (raft.py:219)
+                if (tail) {
+#pragma unroll
+                    for (int k = 0; k < UG; ++k) {
+                        if (po[k] < 0) continue;
+                        const float cx = p.ep_a[po[k] * 2], cy = p.ep_a[po[k] * 2 + 1];
+                        vv[k][2] = __fsub_rn(cx, (float)x);
+                        vv[k][3] = __fsub_rn(cy, (float)(y0 + ug + k));
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UG; ++k) {
+                if (po[k] < 0) continue;
+                if (split_out) ff::store_split4(p.y + po[k] * p.y_ld, n4, vv[k], nv);
+                else {
+                    float* d = p.y + po[k] * p.y_ld + n4;
+                    if (out_full && vec_y) *reinterpret_cast<f32x4*>(d) = vv[k];
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (r < nv) d[r] = vv[k][r];
+                    }
+                }
+                if (p.y2) ff::store_split4(p.y2 + po[k] * p.y2_ld, n4, vv[k], nv);
+            }
+        }
+    }
+}
+
+template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_dma_kernel(const DArgs a) {
+    conv_dma_body<KH, KW, TH, NV, TERMS, EPI>(a);
+}
+
+template <int KH, int KW, int TH, int NV, int TERMS, int OCC>
+int launch_ep(const DArgs& a, hipStream_t s) {
+    constexpr int PW = 16 + KW - 1, PH = TH + KH - 1, NPIECE = (PH * PW + 7) / 8;
+    constexpr size_t lds = 2 * NPIECE * 1024;
+    const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    switch (a.p.ep_mode) {
+        case FF_EP_NONE: conv_dma_kernel<KH, KW, TH, NV, TERMS, FF_EP_NONE, OCC><<<(unsigned)blocks, 256, lds, s>>>(a); break;
+        case FF_EP_GRU_RH: conv_dma_kernel<KH, KW, TH, NV, TERMS, FF_EP_GRU_RH, OCC><<<(unsigned)blocks, 256, lds, s>>>(a); break;
+        case FF_EP_GRU_BLEND: conv_dma_kernel<KH, KW, TH, NV, TERMS, FF_EP_GRU_BLEND, OCC><<<(unsigned)blocks, 256, lds, s>>>(a); break;
+        case FF_EP_MOTION_TAIL: conv_dma_kernel<KH, KW, TH, NV, TERMS, FF_EP_MOTION_TAIL, OCC><<<(unsigned)blocks, 256, lds, s>>>(a); break;
+        default: return ff::fail(FF_EINVAL, "ff_conv2d_fwd(dma): ep_mode %d", a.p.ep_mode);
+    }
+    return ff::check_launch("ff_conv2d_fwd(dma)");
+}
+
+template <int KH, int KW, int TERMS>
+int launch_tile(DArgs& a, int th, int nv, hipStream_t s) {
+    a.tiles_y = (a.p.H + th - 1) / th;
+    a.n_tiles = (a.p.Cout + (a.p.ep_mode == FF_EP_MOTION_TAIL ? 2 : 0) + 64 * nv - 1) / (64 * nv);
+    if (th == 8 && nv == 2) return launch_ep<KH, KW, 8, 2, TERMS, 3>(a, s);
+    if (th == 8 && nv == 1) return launch_ep<KH, KW, 8, 1, TERMS, 3>(a, s);      // (two 23 KB patch buffers: three blocks per CU)
+    if (th == 4 && nv == 2) return launch_ep<KH, KW, 4, 2, TERMS, 4>(a, s);
+    return launch_ep<KH, KW, 4, 1, TERMS, 5>(a, s);
+}
+
+}  // namespace
+
+namespace ff {
+// returns FF_OK if launched, 1 if no input segment is in the split-pair format (the caller goes on to the fp32-input
+// kernels); a split-pair input that this kernel cannot take is an error - nothing else can read it
+int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s) {
+    bool any = false, all = true;
+    for (int i = 0; i < FF_MAX_SEG && p.x_c[i]; ++i) {
+        any |= p.x_fmt[i] == FF_FMT_SPLIT;
+        all &= p.x_fmt[i] == FF_FMT_SPLIT;
+    }
+    if (!any) return 1;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
+    const bool k33 = p.KH == 3 && p.KW == 3, k15 = p.KH == 1 && p.KW == 5, k51 = p.KH == 5 && p.KW == 1;
+    if (!all || p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1 || !(k33 || k15 || k51) || p.pad_h != p.KH / 2 || p.pad_w != p.KW / 2 ||
+        (p.w_format != FF_W_F16X3 && p.w_format != FF_W_F16) || p.x_amax || p.in_scale || p.res2 || p.splitk > 1 || p.stats_part || cin % 32)
+        return fail(FF_EINVAL, "ff_conv2d_fwd: split-pair inputs (x_fmt) need a stride-1 3x3 / 1x5 / 5x1 convolution in a split weight format "
+                               "with every segment split and none of x_amax / in_scale / res2 / splitk / stats_part (got %dx%d stride %d, format %d)",
+                    p.KH, p.KW, p.stride, p.w_format);
+    long long max_bytes = 0;
+    for (int i = 0; i < FF_MAX_SEG && p.x_c[i]; ++i) {
+        if (p.x_c[i] % 32) return fail(FF_EINVAL, "ff_conv2d_fwd: split-pair segment %d has %d channels (multiples of 32 only)", i, p.x_c[i]);
+        max_bytes = std::max(max_bytes, (long long)p.B * p.H * p.W * p.x_ld[i] * 4);
+    }
+    DArgs a;
+    a.p = p;
+    a.Cin = cin;
+    a.nci = cin / 32;
+    a.tiles_x = (p.W + 15) / 16;
+    a.w_row_bytes = (long long)((p.KH * p.KW * cin + 31) / 32) * 128;
+    max_bytes = std::max(max_bytes, (long long)p.Cout * a.w_row_bytes);
+    if (max_bytes >= (1ll << 31) || (long long)p.B * p.H * p.W >= (1ll << 24))
+        return fail(FF_EINVAL, "ff_conv2d_fwd: split-pair convolution: a buffer of 2 GiB or more, or 2^24 pixels or more");
+    if (p.ep_mode == FF_EP_COORDS) return fail(FF_EINVAL, "ff_conv2d_fwd: FF_EP_COORDS belongs to the fp32 flow head");
+    if (p.ep_mode == FF_EP_MOTION_TAIL && (p.Cout % 4 != 2 || p.y_ld < p.Cout + 2 || !p.ep_a || (p.y2 && p.y2_ld < p.Cout + 2)))
+        return fail(FF_EINVAL, "ff_conv2d_fwd: FF_EP_MOTION_TAIL: Cout %% 4 == 2, room for two more channels and ep_a = coords1");
+    if ((p.y_fmt == FF_FMT_SPLIT && (p.y_fmt_from % 32 || p.y_ld % 4 || !aligned16(p.y))) || (p.y2 && (p.y2_ld % 4 || !aligned16(p.y2))))
+        return fail(FF_EINVAL, "ff_conv2d_fwd: split-pair output: y_fmt_from %% 32, ld %% 4 and 16-byte alignment");
+    // Tile choice: 8 x 16 pixels x 128 channels per block where that still gives every CU its blocks, else smaller tiles
+    // (the update block at 8 pairs is 192 tiles of 8 x 16 pixels on 256 CUs).  FF_DMA_TILE = th * 10 + nv overrides (tuning).
+    const int couts = p.Cout + (p.ep_mode == FF_EP_MOTION_TAIL ? 2 : 0);
+    auto nblocks = [&](int th, int nv) { return (long long)p.B * ((p.H + th - 1) / th) * a.tiles_x * ((couts + 64 * nv - 1) / (64 * nv)); };
+    int th = 8, nv = couts > 64 ? 2 : 1;
+    if (nblocks(th, nv) < 640 && nv == 2 && couts % 128 != 0 && couts % 128 <= 64) nv = 1;       // a half-empty second channel tile
+    if (nblocks(th, nv) < 640) th = 4;
+    if (nblocks(th, nv) < 640 && nv == 2) nv = 1;
+    if (const char* e = getenv("FF_DMA_TILE")) {
+        const int v = atoi(e);
+        if (v > 0) { th = v / 10; nv = v % 10; }
+        if ((th != 4 && th != 8) || (nv != 1 && nv != 2)) return fail(FF_EINVAL, "FF_DMA_TILE: th * 10 + nv with th in {4, 8}, nv in {1, 2}");
+    }
+    const bool t3 = p.w_format == FF_W_F16X3;
+    if (k33) return t3 ? launch_tile<3, 3, 3>(a, th, nv, s) : launch_tile<3, 3, 1>(a, th, nv, s);
+    if (k15) return t3 ? launch_tile<1, 5, 3>(a, th, nv, s) : launch_tile<1, 5, 1>(a, th, nv, s);
+    return t3 ? launch_tile<5, 1, 3>(a, th, nv, s) : launch_tile<5, 1, 1>(a, th, nv, s);
+}
+}  // namespace ff

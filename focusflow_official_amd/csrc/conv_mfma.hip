@@ -306,11 +306,25 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
                "ff_conv2d_fwd: res2 needs res, a split weight format and a 1x1 kernel (0 < res_split < Cout)");
     FF_REQUIRE(!p.stats_part || (ff::aligned16(p.stats_part) && ff_conv2d_stats_parts(pp) > 0),
                "ff_conv2d_fwd: stats_part: this convolution cannot produce statistics (ff_conv2d_stats_parts returned 0) or the buffer is misaligned");
-    FF_REQUIRE(p.ep_mode >= FF_EP_NONE && p.ep_mode <= FF_EP_COORDS, "ff_conv2d_fwd: bad ep_mode %d", p.ep_mode);
+    FF_REQUIRE(p.ep_mode >= FF_EP_NONE && p.ep_mode <= FF_EP_MOTION_TAIL, "ff_conv2d_fwd: bad ep_mode %d", p.ep_mode);
+    bool split_in = false;
+    for (int s = 0; s < FF_MAX_SEG && p.x_c[s]; ++s) {
+        FF_REQUIRE(p.x_fmt[s] == FF_FMT_F32 || p.x_fmt[s] == FF_FMT_SPLIT, "ff_conv2d_fwd: bad x_fmt[%d] = %d", s, p.x_fmt[s]);
+        split_in |= p.x_fmt[s] == FF_FMT_SPLIT;
+    }
+    FF_REQUIRE(p.y_fmt == FF_FMT_F32 || p.y_fmt == FF_FMT_SPLIT, "ff_conv2d_fwd: bad y_fmt %d", p.y_fmt);
+    FF_REQUIRE(!(split_in || p.y_fmt || p.y2) || (p.w_format != FF_W_F32 && p.groups == 1 && !p.splitk && !p.stats_part),
+               "ff_conv2d_fwd: the split-pair activation format needs a split weight format, groups == 1, no splitk / stats_part");
+    FF_REQUIRE(!p.y2 || split_in, "ff_conv2d_fwd: y2 (second output) belongs to convolutions over split-pair inputs");
+    FF_REQUIRE(p.ep_mode != FF_EP_MOTION_TAIL || split_in, "ff_conv2d_fwd: FF_EP_MOTION_TAIL belongs to convolutions over split-pair inputs");
+    FF_REQUIRE(p.y_fmt != FF_FMT_SPLIT || (p.y_fmt_from >= 0 && p.y_fmt_from % 32 == 0 && p.y_ld % 4 == 0 && ff::aligned16(p.y) && !p.res2),
+               "ff_conv2d_fwd: split-pair output: y_fmt_from %% 32 == 0, y_ld %% 4 == 0, 16-byte aligned y, no res2");
     if (p.ep_mode == FF_EP_COORDS) {
         FF_REQUIRE(p.w_format == FF_W_F32 && p.Cout == 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 && p.groups == 1 &&
                    dlh == 1 && dlw == 1 && p.act == FF_ACT_NONE && !p.res && p.ep_a && p.ep_b && ff::aligned16(p.ep_b) && (reinterpret_cast<uintptr_t>(p.ep_a) & 7) == 0,
                    "ff_conv2d_fwd: FF_EP_COORDS belongs to the 2-channel 3x3 flow head in fp32 rows (ep_a = coords1, ep_b = flow4)");
+    } else if (p.ep_mode == FF_EP_MOTION_TAIL) {
+        FF_REQUIRE(p.ep_a && (reinterpret_cast<uintptr_t>(p.ep_a) & 7) == 0, "ff_conv2d_fwd: FF_EP_MOTION_TAIL: ep_a = coords1");
     } else if (p.ep_mode) {
         FF_REQUIRE((p.w_format == FF_W_F16X3 || p.w_format == FF_W_F16) && p.groups == 1 && p.stride == 1 && cin % 32 == 0 && p.KH * p.KW >= 3 && !p.res2 && !p.in_scale &&
                    p.Cout % 4 == 0 && p.y_ld % 4 == 0 && ff::aligned16(p.y),

@@ -307,10 +307,23 @@ __device__ __forceinline__ void conv_split_body(const KernArgs& a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) vv[r] = ff::apply_act(vv[r] + rr[r], p.act_res);
             }
+            if (p.y_fmt == FF_FMT_SPLIT && n >= p.y_fmt_from) {       // FF_FMT_SPLIT: the lane's channel as one half in x0 and one in x1 of its chunk
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.M) yb[(long long)m * p.y_ld + n] = vv[r];
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m >= a.M) continue;
+                    const float sv = vv[r] * ff::XSPLIT;
+                    const _Float16 h0 = (_Float16)sv, h1 = (_Float16)(sv - (float)h0);
+                    char* c = reinterpret_cast<char*>(yb + (long long)m * p.y_ld + (n & ~31)) + (n & 31) * 2;
+                    *reinterpret_cast<_Float16*>(c) = h0;
+                    *reinterpret_cast<_Float16*>(c + 64) = h1;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < a.M) yb[(long long)m * p.y_ld + n] = vv[r];
+                }
             }
         }
     }
@@ -443,9 +456,12 @@ __global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __res
 namespace ff {
 // called from ff_conv2d_fwd after argument validation
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s) {
-    int rc = conv2d_fwd_stem(p, cin, s);              // the encoders' 7x7 stride-2 stems over NHWC4 (conv_stem.hip)
+    int rc = conv2d_fwd_dma(p, cin, s);               // split-pair inputs: patch by LDS-DMA, weights straight into registers (conv_dma.hip)
     if (rc != 1) return rc;
-    rc = conv2d_fwd_patch(p, cin, s);                // stride-1 "same" convolutions: patch-stationary kernel
+    const bool split_out = p.y_fmt != FF_FMT_F32 || p.y2;      // fp32 in, split-pair out: the im2col kernel's epilogue writes it
+    rc = split_out ? 1 : conv2d_fwd_stem(p, cin, s);  // the encoders' 7x7 stride-2 stems over NHWC4 (conv_stem.hip)
+    if (rc != 1) return rc;
+    rc = split_out ? 1 : conv2d_fwd_patch(p, cin, s); // stride-1 "same" convolutions: patch-stationary kernel
     if (rc != 1) return rc;
     if (p.in_scale) return fail(FF_EINVAL, "ff_conv2d_fwd: in_scale/in_shift: the patch kernel declined this shape");
     if (p.ep_mode) return fail(FF_EINVAL, "ff_conv2d_fwd: ep_mode: the patch kernel declined this shape");

@@ -57,6 +57,38 @@ __device__ __forceinline__ void input_scale(const unsigned int* x_amax, float& x
         }
     }
 }
+// FF_FMT_SPLIT activations (focusflow_hip.h): the pair a convolution loader makes of an fp32 value, written by a producer.
+// 4 consecutive channels n4 .. n4 + 3 (n4 % 4 == 0) of one pixel -> two 8-byte stores into the pixel's 128-byte chunk.
+typedef _Float16 ff_f16x4 __attribute__((ext_vector_type(4)));
+typedef float ff_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_pair4(const ff_f32x4 v, ff_f16x4& h0, ff_f16x4& h1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sv = v[j] * XSPLIT;
+        const _Float16 a = (_Float16)sv;
+        h0[j] = a;
+        h1[j] = (_Float16)(sv - (float)a);
+    }
+}
+// pixel_row = base of the pixel's channels (fp32 addressing: y + pixel * ld); n4 = first of the four channels; nvalid = how
+// many of them exist (partial groups at Cout's edge store half by half)
+__device__ __forceinline__ void store_split4(float* pixel_row, int n4, const ff_f32x4 v, int nvalid = 4) {
+    ff_f16x4 h0, h1;
+    split_pair4(v, h0, h1);
+    char* c = reinterpret_cast<char*>(pixel_row + (n4 & ~31)) + (n4 & 31) * 2;
+    if (nvalid >= 4) {
+        *reinterpret_cast<ff_f16x4*>(c) = h0;
+        *reinterpret_cast<ff_f16x4*>(c + 64) = h1;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nvalid) {
+                reinterpret_cast<_Float16*>(c)[j] = h0[j];
+                reinterpret_cast<_Float16*>(c + 64)[j] = h1[j];
+            }
+    }
+}
+int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s);           // conv_dma.hip (split-pair inputs by LDS-DMA); 1 = not eligible
 int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int cin, hipStream_t s);   // conv_wgrad_split.hip
 int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hipStream_t s);          // conv_wgrad_patch.hip; 1 = not eligible
 int conv2d_fwd_small(const FFConvParams& p, int cin, hipStream_t s);         // conv_small.hip (Cout <= 2, 3x3); 1 = not eligible

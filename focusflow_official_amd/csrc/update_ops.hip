@@ -44,6 +44,30 @@ __global__ void act_copy_kernel(const float* __restrict__ src, int src_ld, float
     }
 }
 
+// fp32 <-> FF_FMT_SPLIT (focusflow_hip.h), one thread = 4 channels of a pixel
+__global__ void split_copy_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld,
+                                  long long npix, int C, int act, int to_split) {
+    const int cg = C >> 2;
+    const long long total = npix * cg;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / cg;
+        const int n4 = (int)(i - p * cg) * 4;
+        if (to_split) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + p * src_ld + n4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ff::apply_act(v[j], act);
+            ff::store_split4(dst + p * dst_ld, n4, v);
+        } else {
+            const char* c = reinterpret_cast<const char*>(src + p * src_ld + (n4 & ~31)) + (n4 & 31) * 2;
+            const ff::ff_f16x4 h0 = *reinterpret_cast<const ff::ff_f16x4*>(c), h1 = *reinterpret_cast<const ff::ff_f16x4*>(c + 64);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((float)h0[j] + (float)h1[j]) * 0.25f;
+            *reinterpret_cast<f32x4*>(dst + p * dst_ld + n4) = v;
+        }
+    }
+}
+
 __global__ void coords_init_kernel(float* __restrict__ coords, const float* __restrict__ finit, int B, int H, int W) {
     const int HW = H * W;
     const long long total = (long long)B * HW;
@@ -269,6 +293,14 @@ extern "C" int ff_act_copy(const float* src, int src_ld, float* dst, int dst_ld,
     FF_REQUIRE(src_ld % 4 == 0 && dst_ld % 4 == 0 && ff::aligned16(src) && ff::aligned16(dst), "ff_act_copy: alignment");
     act_copy_kernel<<<grid_for(npix * (C / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(src, src_ld, dst, dst_ld, npix, C, act);
     return ff::check_launch("ff_act_copy");
+}
+
+extern "C" int ff_split_copy(const float* src, int src_ld, float* dst, int dst_ld, long long npix, int C, int act, int to_split, void* stream) {
+    FF_REQUIRE(src && dst && npix > 0 && C > 0 && C % 32 == 0, "ff_split_copy: bad argument (C must be a multiple of 32)");
+    FF_REQUIRE(src_ld % 4 == 0 && dst_ld % 4 == 0 && src_ld >= C && dst_ld >= C && ff::aligned16(src) && ff::aligned16(dst), "ff_split_copy: alignment / ld");
+    FF_REQUIRE(to_split || act == FF_ACT_NONE, "ff_split_copy: no activation on the way back");
+    split_copy_kernel<<<grid_for(npix * (C / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(src, src_ld, dst, dst_ld, npix, C, act, to_split);
+    return ff::check_launch("ff_split_copy");
 }
 
 extern "C" int ff_coords_init(float* coords, const float* flow_init, int B, int H, int W, void* stream) {

@@ -174,6 +174,54 @@ def empty_nhwc(b, h, w, c, like: Tensor) -> Tensor:
     return torch.empty((b, h, w, c), dtype=torch.float32, device=like.device)
 
 
+class SplitT:
+    """An NHWC activation in the split-pair format (FF_FMT_SPLIT, include/focusflow_hip.h): shape, strides and bytes of its
+    fp32 form, but every 32-channel chunk of a pixel holds [x0: 32 fp16 | x1: 32 fp16] - what a convolution loader makes
+    of the fp32 values, written by the producer so that the consumer's patch goes L2 -> LDS by LDS-DMA.  Only convolutions
+    read it (ops.conv2d sets FFConvParams.x_fmt); `.t` is the raw storage and means nothing as floats."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: Tensor):
+        self.t = t
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def __getitem__(self, idx):
+        r = self.t[idx]
+        off = (r.data_ptr() - self.t.data_ptr()) // 4
+        ld = _ld(self.t)
+        if (off % ld) % 32 or r.shape[3] % 32:
+            raise _hip.FocusFlowHipError("a split-pair tensor can only be sliced at multiples of 32 channels")
+        return SplitT(r)
+
+    def record_stream(self, s):
+        self.t.record_stream(s)
+
+    def float(self) -> Tensor:
+        """Back to fp32 ((x0 + x1) / 4: 22 significant bits) - tests and debugging."""
+        return split_copy(self.t, to_split=False)
+
+
+def _raw(x):
+    return x.t if isinstance(x, SplitT) else x
+
+
+def split_copy(x: Tensor, act: int = ACT_NONE, to_split: bool = True, out: Optional[Tensor] = None):
+    """fp32 NHWC -> SplitT (ff_split_copy; an activation on the way), or - to_split=False - the raw storage of a SplitT back
+    to fp32."""
+    b, h, w, c = x.shape
+    if out is None:
+        out = empty_nhwc(b, h, w, c, x)
+    _hip.call("ff_split_copy", _p(x), _ld(x), _p(out), _ld(out), b * h * w, c, act, 1 if to_split else 0, _stream())
+    return SplitT(out) if to_split else out
+
+
 # ----------------------------------------------------------------------------
 def pack_conv_weight(w_oihw: Tensor, dst: Tensor, cin_pad: int, cout_offset: int = 0):
     """OIHW parameter -> rows [cout_offset, cout_offset+Cout) of dst [rows][KH*KW*cin_pad]."""
@@ -189,7 +237,8 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
            ch_shift: Optional[Tensor] = None, out_scale: float = 1.0, w_fmt: int = 0, dilation: int = 1,
            x_amax: Optional[Tensor] = None, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None,
            in_act: int = ACT_NONE, res2: Optional[Tensor] = None, res_split: int = 0,
-           ep_rh: Optional[Tensor] = None, ep_split: int = 0, ep_blend=None, want_stats: bool = False, ep_coords=None):
+           ep_rh: Optional[Tensor] = None, ep_split: int = 0, ep_blend=None, want_stats: bool = False, ep_coords=None,
+           y_split=False, y2_split: bool = False, ep_motion_tail: Optional[Tensor] = None):
     """Convolution over the channel-concatenation of `xs` (see FFConvParams).  want_stats: -> (out, stats) with the
     per-sample {sum, sum of squares} table of the output (what norm_stats(out, True) returns): from the convolution's own
     epilogue where the kernel can (FFConvParams.stats_part), else from a norm_stats pass.  res2 / res_split: output channels
@@ -198,6 +247,8 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     max|x| (act_bwd): the split formats then scale the input by a power of two so that gradients fit fp16."""
     if isinstance(pad, int):
         pad = (pad, pad)
+    fmts = [1 if isinstance(x, SplitT) else 0 for x in xs]
+    xs = [_raw(x) for x in xs]
     x0 = xs[0]
     b, h, w, _ = x0.shape
     ho = (h + 2 * pad[0] - dilation * (kh - 1) - 1) // stride + 1
@@ -212,6 +263,7 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
         p.x_ld[i] = _ld(x)
         p.x_c[i] = x.shape[3]
         p.x_gstride[i] = 0
+        p.x_fmt[i] = fmts[i]
         cin += x.shape[3]
     kdim = kh * kw * cin if w_fmt == 0 else (kh * kw * cin + 31) // 32 * 128
     assert wpack.is_contiguous() and wpack.shape[-1] == kdim and wpack.shape[0] >= cout, \
@@ -235,7 +287,16 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     elif ep_blend is not None:  # FF_EP_GRU_BLEND: (z, h) -> the output is (1 - z) h + z v (the q conv writes the new state)
         z, hprev = ep_blend
         p.ep_mode, p.ep_a, p.ep_a_ld, p.ep_b, p.ep_b_ld = 2, z.data_ptr(), _ld(z), hprev.data_ptr(), _ld(hprev)
+    elif ep_motion_tail is not None:   # FF_EP_MOTION_TAIL: channels Cout, Cout + 1 of the padded output = coords1 - pixel grid
+        assert ep_motion_tail.is_contiguous() and ep_motion_tail.shape == (b, ho, wo, 2)
+        p.ep_mode, p.ep_a = 4, ep_motion_tail.data_ptr()
     p.y, p.y_ld, p.y_gstride = out.data_ptr(), _ld(out), 0
+    if y_split is not False:
+        p.y_fmt, p.y_fmt_from = 1, (0 if y_split is True else int(y_split))
+    out2 = None
+    if y2_split:
+        out2 = empty_nhwc(b, ho, wo, (cout + 31) // 32 * 32, x0)
+        p.y2, p.y2_ld = out2.data_ptr(), _ld(out2)
     p.Ho, p.Wo, p.Cout = ho, wo, cout
     p.KH, p.KW, p.stride, p.pad_h, p.pad_w = kh, kw, stride, pad[0], pad[1]
     p.act, p.act_res, p.w_format = act, act_res, w_fmt
@@ -246,10 +307,12 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
         p.in_scale, p.in_shift, p.in_act = in_scale.data_ptr(), in_shift.data_ptr(), in_act
     assert out.shape[:3] == (b, ho, wo) and out.shape[3] >= cout
     if _range_word is not None and w_fmt and x_amax is None and in_scale is None:
-        for x in xs:
-            _range_probe(x)
+        for x, f in zip(xs, fmts):
+            if not f:          # (a split-pair tensor was range-checked as the fp32 values its producer held)
+                _range_probe(x)
     klen = cin * kh * kw
-    if w_fmt and not p.ep_mode and b * ho * wo <= 16384 and klen > 1152:       # small plane, long reduction: ask the library whether K splits pay
+    plain = not any(fmts) and y_split is False and not y2_split                # (the split-pair kernels have no K splits)
+    if plain and w_fmt and not p.ep_mode and b * ho * wo <= 16384 and klen > 1152:       # small plane, long reduction: ask the library whether K splits pay
         # reductions of 36-72 tap steps are split only when no host time is at stake: while a hipGraph is being captured
         short = klen <= 2304
         if not short or torch.cuda.is_current_stream_capturing():
@@ -270,6 +333,10 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     _timed_call("conv", "ff_conv2d_fwd", C.byref(p), _stream(), note=(2.0 * b * ho * wo * cout * kh * kw * cin, w_fmt))
     if want_stats:
         return out, norm_stats(out, per_sample=True)
+    if y_split is True:
+        out = SplitT(out)
+    if y2_split:
+        return out, SplitT(out2)
     return out
 
 

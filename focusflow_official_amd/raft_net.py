@@ -8,7 +8,7 @@ from . import _hip, cce, fn, ops
 from .cce import BasicParallelFusionLayer, train_streams
 from .corr_block import CorrBlock
 from .ops import ACT_RELU, ACT_TANH
-from .update_block import BasicUpdateBlock
+from .update_block import BasicUpdateBlock, split_activations
 
 _COORDS_EPILOGUE = os.environ.get("FF_COORDS_EPILOGUE", "1") != "0"   # A/B switch: coords1 += delta inside the flow head's last convolution (inference)
 _MASK_UPSAMPLE = os.environ.get("FF_MASK_UPSAMPLE", "1") != "0"   # A/B switch: mask conv 2 + convex up-sampling as one kernel (inference)
@@ -163,6 +163,10 @@ class RAFT(nn.Module):
         # inference: the mask head's 1x1 convolution and the convex up-sampling run as one kernel (no 576-channel mask tensor)
         fused_coords = _COORDS_EPILOGUE and not taped and not torch.is_grad_enabled() and coords1.is_contiguous()
         fused_up = _MASK_UPSAMPLE and not taped and not torch.is_grad_enabled() and ops.w_format() in (_hip.W_F16X3, _hip.W_F16)
+        if split_activations() and gru_pre is not None and not taped and coords1.is_contiguous():
+            # inference: split-pair activations between the update block's convolutions (update_block.split_activations);
+            # the state travels as (fp32 for the element-wise steps, split-pair for the convolutions, coords1)
+            net = (net, ops.split_copy(net), coords1)
         for it in range(iters):
             # coords1 is advanced in place by ff_coords_step (raw pointer: autograd cannot see it), so a
             # recorded lookup keeps its own snapshot for the backward scatter

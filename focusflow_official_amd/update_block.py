@@ -19,6 +19,14 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 
 _SIDE_STREAM = os.environ.get("FF_SIDE_STREAM", "1") != "0"      # measurement switch (BasicMotionEncoder.run)
 _GRU_EPILOGUE = os.environ.get("FF_GRU_EPILOGUE", "1") != "0"    # r*h and the state blend in the conv epilogues (inference); 0: ff_gru_rh / ff_gru_blend launches
+# Inference: the activations BETWEEN the convolutions of the update block travel in the split-pair format (ops.SplitT) - the
+# producers' epilogues write what the consumers' loaders would have made of fp32, the consumers take their patches by LDS-DMA
+# (csrc/conv_dma.hip).  Same bits as the fp32 route.  FF_SPLIT_ACT=0: A/B switch back to fp32 tensors and conv_patch.hip.
+_SPLIT_ACT = os.environ.get("FF_SPLIT_ACT", "1") != "0"
+
+
+def split_activations() -> bool:
+    return (_SPLIT_ACT and _GRU_EPILOGUE and not torch.is_grad_enabled() and ops.w_format() in (_hip.W_F16X3, _hip.W_F16))
 _side_streams = {}
 
 
@@ -66,6 +74,18 @@ class SepConvGRU(nn.Module):
         input gradient ONCE (sum_t inp (x) g_t = inp (x) sum_t g_t)."""
         assert inp.shape[3] == 128
         return [(fn.conv(zc, inp), fn.conv(qc, inp)) for zc, qc in zip(self._zr_ctx, self._q_ctx)]
+
+    def run_split(self, h, hs, motion, pre):
+        """Inference on split-pair activations: h fp32 (the element-wise steps read it), hs = the same state as ops.SplitT
+        (the convolutions read it), motion SplitT, pre = prepare(inp).  -> (h, hs).  update.py:45-60; the same sequence
+        of operations as run()'s fused branch - bit-identical states."""
+        c = self.hidden_dim
+        for zr_conv, q_conv, (zr_pre, q_pre) in zip(self._zr_hm, self._q_hm, pre):
+            # [z | r * h]: z stays fp32 (the blend reads it), r * h leaves in the split-pair format (only the q convolution reads it)
+            zr = zr_conv([hs, motion], res=zr_pre, act_res=ACT_SIGMOID, ep_rh=h, ep_split=c, y_split=c)
+            # the new state twice: fp32 for the next element-wise steps, split-pair for the next convolutions
+            h, hs = q_conv([ops.SplitT(zr[..., c:]), motion], res=q_pre, act_res=ACT_TANH, ep_blend=(zr[..., :c], h), y2_split=True)
+        return h, hs
 
     def run(self, h, xs, pre=None):
         """h: (B,H,W,128); xs: list of NHWC segments forming x.  update.py:45-60.  pre: prepare(xs[0]) - then
@@ -118,10 +138,22 @@ class BasicMotionEncoder(nn.Module):
         self._f1, self._f2 = PackedConv([self.convf1], 4), PackedConv([self.convf2])
         self._cv = PackedConv([self.conv])
 
-    def run(self, flow4, corr, fill_flow):
+    def run(self, flow4, corr, fill_flow, coords1=None):
         """flow4: (B,H,W,4) zero-padded flow.  Returns motion (B,H,W,128): 126 conv channels, and
-        `fill_flow(motion)` writes the flow into channels 126:128 (torch.cat([out, flow]), update.py:97)."""
+        `fill_flow(motion)` writes the flow into channels 126:128 (torch.cat([out, flow]), update.py:97).
+        coords1 given (inference, split_activations()): every tensor between the five convolutions is an ops.SplitT, the
+        result too, and the last convolution writes the two flow channels itself (FF_EP_MOTION_TAIL: no fill launch)."""
         c1 = self._c1p if corr.shape[3] == self._c1p.cin_pad else self._c1
+        sp = coords1 is not None
+        ys = dict(y_split=True) if sp else {}
+
+        def last(cor, flo):
+            if not sp:
+                return fn.conv(self._cv, [cor, flo], act=ACT_RELU, pad_out=True, fill_tail=fill_flow)
+            b, h, w, _ = flow4.shape
+            full = ops.empty_nhwc(b, h, w, 128, flow4)
+            self._cv([cor, flo], act=ACT_RELU, out=full[..., :126], y_split=True, ep_motion_tail=coords1)
+            return ops.SplitT(full)
         if _SIDE_STREAM and not ops.policy.single_stream and not torch.is_grad_enabled():
             # Inference: the flow branch (convf1 -> convf2) does not depend on the lookup and neither branch fills the
             # chip at 1/8 resolution (576 and 384 blocks on 1024 slots): run it on a second HIP stream beside
@@ -132,17 +164,19 @@ class BasicMotionEncoder(nn.Module):
             fork.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(fork)
-                flo = self._f2(self._f1(flow4, act=ACT_RELU), act=ACT_RELU)
+                flo = self._f2(self._f1(flow4, act=ACT_RELU, **ys), act=ACT_RELU, **ys)
                 join = torch.cuda.Event()
                 join.record(side)
             flow4.record_stream(side)          # allocated on the main stream, read on the side stream
-            cor = self._c2(c1(corr, act=ACT_RELU), act=ACT_RELU)
+            cor = self._c2(c1(corr, act=ACT_RELU, **ys), act=ACT_RELU, **ys)
             main.wait_event(join)
             flo.record_stream(main)            # allocated on the side stream, read on the main stream
-            return fn.conv(self._cv, [cor, flo], act=ACT_RELU, pad_out=True, fill_tail=fill_flow)
+            return last(cor, flo)
+        if sp:
+            return last(self._c2(c1(corr, act=ACT_RELU, **ys), act=ACT_RELU, **ys), self._f2(self._f1(flow4, act=ACT_RELU, **ys), act=ACT_RELU, **ys))
         cor = fn.conv(self._c2, fn.conv(c1, corr, act=ACT_RELU), act=ACT_RELU)
         flo = fn.conv(self._f2, fn.conv(self._f1, flow4, act=ACT_RELU), act=ACT_RELU)
-        return fn.conv(self._cv, [cor, flo], act=ACT_RELU, pad_out=True, fill_tail=fill_flow)
+        return last(cor, flo)
 
 
 class BasicUpdateBlock(nn.Module):
@@ -164,11 +198,16 @@ class BasicUpdateBlock(nn.Module):
         comes back as the mask head's HIDDEN tensor (B,H,W,256) - the caller finishes it with upsample() below (the
         second mask convolution and the convex up-sampling as one launch).  coords_out = (coords1, flow4_next) (inference):
         the flow head's last convolution also takes the coordinate step coords1 += delta, flow4_next = coords1 - grid."""
-        motion = self.encoder.run(flow4, corr, fill_flow)
-        net = self.gru.run(net, [inp, motion], gru_pre)
+        if isinstance(net, tuple):          # (h fp32, h split-pair): inference on split-pair activations (RAFT._loop_steps decides)
+            motion = self.encoder.run(flow4, corr, fill_flow, coords1=net[2])
+            h, hs = self.gru.run_split(net[0], net[1], motion, gru_pre)
+            net, head_in = (h, hs, net[2]), hs
+        else:
+            motion = self.encoder.run(flow4, corr, fill_flow)
+            net = head_in = self.gru.run(net, [inp, motion], gru_pre)
         if not need_mask:
-            return net, None, fn.conv(self._flow2, fn.conv(self._head1, net, act=ACT_RELU))
-        hid = fn.conv(self._heads, net, act=ACT_RELU)                      # [flow-head 256 | mask-head 256]
+            return net, None, fn.conv(self._flow2, self._head1(head_in, act=ACT_RELU) if isinstance(net, tuple) else fn.conv(self._head1, head_in, act=ACT_RELU))
+        hid = self._heads(head_in, act=ACT_RELU) if isinstance(net, tuple) else fn.conv(self._heads, head_in, act=ACT_RELU)   # [flow-head 256 | mask-head 256]
         if coords_out is not None:
             delta = self._flow2(hid[..., :256], ep_coords=coords_out)
         else:

@@ -52,8 +52,10 @@ const char* ff_last_error(void);
  *                ff_corr_pyramid_bwd (row-major) removed
  *   3 (round 3): FFConvParams + ep_mode, ep_split, ep_a, ep_a_ld, ep_b, ep_b_ld, stats_part; + ff_conv2d_stats_parts,
  *                ff_norm_stats_finish, ff_launch_timing_begin / _end, ff_mask_upsample_pack / _fwd,
- *                ff_corr_lookup_tiled_bwd_all */
-#define FF_ABI_VERSION 4
+ *                ff_corr_lookup_tiled_bwd_all
+ *   5 (round 4): FFConvParams + x_fmt[], y_fmt, y_fmt_from, y2, y2_ld (the split-pair activation format between the
+ *                layers of the update block); + ff_split_copy; FF_EP_MOTION_TAIL */
+#define FF_ABI_VERSION 5
 int ff_abi_version(void);
 
 /* Kernel-timestamp timing of one class of the library's launches (measurement only; bench.py's roofline uses it).
@@ -147,11 +149,28 @@ typedef struct FFConvParams {
                                        /* ff_conv2d_stats_parts(p) > 0): the convolution's epilogue replaces the ff_norm_stats  */
                                        /* pass over its output (extractor.py:48-56: every conv of the encoder is followed by a  */
                                        /* norm); ff_norm_stats_finish turns the parts into the {sum, sum of squares} table.    */
+    /* --- split-pair activations (round 4) ------------------------------------------------------------------------------
+     * A tensor in FF_FMT_SPLIT has the same shape, `ld` and size as its fp32 form, but every 32-channel chunk of a pixel
+     * (128 bytes, chunk k at byte (pixel * ld + 32 k) * 4) holds [x0: 32 fp16 | x1: 32 fp16] with x0 = fp16(4 v),
+     * x1 = fp16(4 v - x0): exactly what the convolution loaders make of an fp32 value on their way to LDS, so a convolution
+     * that reads a split tensor computes bit for bit what it computes from the fp32 tensor - but its input patch travels
+     * L2 -> LDS by LDS-DMA (conv_dma.hip) instead of load -> convert -> split -> ds_write through registers.  Element-wise
+     * consumers keep fp32 (the GRU state is written in both forms: y and y2).                                              */
+    int x_fmt[FF_MAX_SEG];             /* FF_FMT_F32 / FF_FMT_SPLIT per input segment (x_c % 32 == 0 for split segments)     */
+    int y_fmt;                         /* FF_FMT_SPLIT: output channels >= y_fmt_from are written in the split format         */
+    int y_fmt_from;                    /* (multiple of 32; the z|r convolution keeps z in fp32 and writes r*h split)          */
+    float* y2;                         /* NULL, or a second copy of the WHOLE output in FF_FMT_SPLIT (the GRU's new state:    */
+    int y2_ld;                         /* fp32 for the next blend, split for the next convolutions)                           */
 } FFConvParams;
+#define FF_FMT_F32 0
+#define FF_FMT_SPLIT 1
 #define FF_EP_NONE 0
 #define FF_EP_GRU_RH 1
 #define FF_EP_GRU_BLEND 2
 #define FF_EP_COORDS 3
+#define FF_EP_MOTION_TAIL 4   /* the motion encoder's last convolution (update.py:95-97, Cout = 126 into a 128-channel buffer) also
+                               * writes torch.cat([out, flow])'s two flow channels: ep_a = coords1 [B][H][W][2] (read),
+                               * flow = coords1 - pixel grid (raft.py:219) into output channels Cout, Cout + 1 */
 
 int ff_conv2d_fwd(const FFConvParams* p, void* stream);
 
@@ -279,6 +298,10 @@ int ff_corr_pyramid_tiled_bwd(float* d0, float* d1, float* d2, const float* d3, 
 /* dst[pix][0..C) = act(src[pix][0..C))  with independent lds (torch.split + tanh/relu) */
 int ff_act_copy(const float* src, int src_ld, float* dst, int dst_ld, long long npix, int C,
                 int act, void* stream);
+/* fp32 -> FF_FMT_SPLIT (FFConvParams: x0 = fp16(4 v), x1 = fp16(4 v - x0) per 32-channel chunk) with an activation on the
+ * way (the hidden state's tanh, raft.py:208).  C % 32 == 0, 16-byte aligned pointers, lds % 4 == 0.  to_split = 0 converts
+ * back, v = (x0 + x1) / 4 (22 significant bits; act must be FF_ACT_NONE) - tests and debugging. */
+int ff_split_copy(const float* src, int src_ld, float* dst, int dst_ld, long long npix, int C, int act, int to_split, void* stream);
 /* coords_grid (utils.py:74-77): coords[b][y][x] = (x, y) (+ flow_init NHWC2 if given) */
 int ff_coords_init(float* coords, const float* flow_init_nchw, int B, int H, int W, void* stream);
 /* coords1 += delta (if delta) ; flow = coords1 - coords0 written to
