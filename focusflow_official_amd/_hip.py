@@ -9,6 +9,10 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libfocusflow_hip.so")
+# lab builds (tools/build_lab.sh: in-kernel stamps, timing-only ablations) live in their own libraries and are loaded
+# only when named explicitly; bench.py refuses to run with the variable set
+if os.environ.get("FF_LAB_LIB"):
+    LIB_PATH = os.path.join(_PKG, "lib", os.environ["FF_LAB_LIB"])
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 W_F32, W_F16X3, W_F16 = 0, 1, 2
@@ -33,6 +37,7 @@ class FFConvParams(C.Structure):
         ("ep_mode", C.c_int), ("ep_split", C.c_int), ("ep_a", _fp), ("ep_a_ld", C.c_int), ("ep_b", _fp), ("ep_b_ld", C.c_int),
         ("stats_part", _fp),
         ("x_fmt", C.c_int * MAX_SEG), ("y_fmt", C.c_int), ("y_fmt_from", C.c_int), ("y2", _fp), ("y2_ld", C.c_int),
+        ("w_frag", _fp),
     ]
 
 
@@ -61,6 +66,7 @@ _SIGS = {
     "ff_conv2d_fwd": [C.POINTER(FFConvParams), _fp],
     "ff_pack_conv_weight": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp],
     "ff_pack_split_f16": [_fp, _fp, _ll, C.c_int, _fp],
+    "ff_pack_frag16": [_fp, _fp, C.c_int, C.c_int, _fp],
     "ff_norm_stats": [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "ff_norm_stats_finish": [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp],
     "ff_mask_upsample_pack": [_fp, _fp, _fp],
@@ -153,7 +159,7 @@ _ABLATION_VARS = ("FF_LOOKUP_ABLATE", "FF_LOOKUP_ABLATE3", "FF_CORR_BUILD_ABLATE
 # tuning overrides: results stay right, measurements change - bench.py refuses these too
 _TUNING_VARS = ("FF_PATCH_TH", "FF_PATCH_TN", "FF_PATCH_WB1", "FF_PATCH_LDS_PAD", "FF_PATCH_PIN", "FF_SPLIT_TILE", "FF_SPLIT_NST", "FF_SPLIT_OCC",
                 "FF_SPLIT_NO_UNI", "FF_SPLIT_F16_128", "FF_NO_PATCH_CONV", "FF_CORR_BUILD_LDS_PAD", "FF_LOOKUP_IMPL",
-                "FF_LOOKUP_DEPTH", "FF_LOOKUP_BLOCK_WAVES", "FF_LOOKUP_WAVES_PER_CU", "FF_MFMA16", "FF_WGRAD_BLOCKS", "FF_DMA_CONV")
+                "FF_LOOKUP_DEPTH", "FF_LOOKUP_BLOCK_WAVES", "FF_LOOKUP_WAVES_PER_CU", "FF_MFMA16", "FF_WGRAD_BLOCKS", "FF_DMA_TILE", "FF_DMA_OCC4", "FF_LAB_LIB")
 
 
 def lab_variables_set():

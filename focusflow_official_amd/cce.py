@@ -25,6 +25,7 @@ _NORM_ON_LOAD = os.environ.get("FF_NORM_ON_LOAD", "1") != "0"      # measurement
 
 
 _ALL_PACKED = weakref.WeakSet()      # every PackedConv alive: prepack() finds the ones of a model here
+_DMA_FRAG = os.environ.get("FF_DMA_FRAG", "1") != "0"   # A/B switch: fragment-order weights for the split-pair convolutions
 _PREPACK = os.environ.get("FF_PREPACK", "1") != "0"     # A/B switch: all stale weight layouts of a training step in one launch
 _serial = [0]
 
@@ -41,6 +42,7 @@ class PackedConv:
     _w_raw = _wd_raw = _w_split = _wd_split = None
     _used_f = _used_d = False      # get() / get_dgrad() have been asked for: prepack() keeps these layouts fresh
     _gen = 0
+    _frag = _frag_of = None
 
     def __init__(self, convs: Sequence[nn.Conv2d], cin_pad: Optional[int] = None,
                  cin_slices: Optional[Sequence[Tuple[int, int]]] = None, use_bias: bool = True):
@@ -145,10 +147,20 @@ class PackedConv:
             self._dkey = key
         return self.wd, self.dfmt
 
+    def frag(self):
+        """The forward rows in MFMA-fragment order (ops.pack_frag16) for the split-pair kernel; re-made per repack."""
+        w, _ = self.get()
+        key = (self._gen, w.data_ptr())
+        if self._frag_of != key:
+            self._frag, self._frag_of = ops.pack_frag16(w, self.cout), key
+        return self._frag
+
     def __call__(self, xs, act=ACT_NONE, **kw):
         w, b = self.get()
         if not isinstance(xs, (list, tuple)):
             xs = [xs]
+        if _DMA_FRAG and self.fmt != 0 and any(isinstance(x, ops.SplitT) for x in xs):
+            kw["w_frag"] = self.frag()
         return ops.conv2d(xs, w, b, self.cout, self.kh, self.kw, self.stride, self.pad, act=act, w_fmt=self.fmt,
                           dilation=self.dil, **kw)
 

@@ -26,6 +26,10 @@
 // on even columns, i.e. on different halves of the 64 banks (PW even), and eight same-parity consecutive columns differ in
 // (px >> 1) & 7.  Because the key depends on px only, a tap's dy and the pixel row u are plain immediate offsets: the
 // main loop has no address arithmetic at all.
+// The epilogue's arithmetic is written as separately rounded operations and must stay that: conv_patch.hip and conv_dma.hip
+// promise the same bits for the same layer (tests/test_hip_split.py), and a multiply-add that one of them contracts into an
+// fma - after the optimiser specialised a path on the activation code - breaks that.  build.py reads the next line.
+// hipcc-flags: -ffp-contract=off
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -41,7 +45,7 @@ __device__ __forceinline__ int PI16(int i) { return (i >= 4 && i < 12) ? 2 * (i 
 
 struct DArgs {
     FFConvParams p;
-    int Cin, nci;
+    int Cin, nci, nkc;        // nkc = 32-k chunks of a packed weight row = KH * KW * nci
     int tiles_x, tiles_y, n_tiles;
     long long w_row_bytes;
 };
@@ -64,7 +68,8 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 // KH x KW taps; TH pixel rows x 16 columns per block; NV 16-channel tiles per wave (block = 4 waves = 64 NV channels)
 // EPI: FFConvParams.ep_mode (GRU steps, motion tail); TERMS 3 (f16x3) or 1 (f16)
-template <int KH, int KW, int TH, int NV, int TERMS, int EPI>
+// UG: pixel rows whose epilogue operands are loaded together
+template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int UG>
 __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
     constexpr int PW = 16 + KW - 1, PH = TH + KH - 1, NPIX = PH * PW, NPIECE = (NPIX + 7) / 8, NPP = (NPIECE + 3) / 4;
     constexpr int PBYTES = NPIECE * 1024, NT = KH * KW, NWL = NV * (TERMS == 3 ? 2 : 1);
@@ -89,7 +94,6 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
     const int y0 = ty * TH, x0 = tx * 16, n0 = nt * (64 * NV) + wave * (16 * NV);    // n0: this WAVE's first output channel
 
     const long long pix_total = (long long)p.B * H * W;
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((long long)p.Cout * a.w_row_bytes), 0x00020000);
     const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
 
     // ---- DMA roles: piece pc = wave + 4 j covers LDS rows 8 pc .. 8 pc + 7; lane -> row (lane >> 3), slot (lane & 7)
@@ -127,11 +131,20 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
     };
     // ---- weights: lane (i, g) holds k-group g of channel n0 + 16 v + i; term 1 = + 64 bytes
     const int i16 = lane & 15, g16 = lane >> 4;
+    // Two sources: the packed rows [Cout][nkc][128 B] (a wave-load = 16 rows x 64 bytes in 16 different lines), or - FFConvParams
+    // w_frag, ff_pack_frag16 - the same bytes in fragment order [tile][nkc][term][lane][16 B]: one contiguous KB per load
+    // (whole lines, no second fetch of a line for its other term)
+    const bool frag = p.w_frag != nullptr;
+    const int ntile16 = (p.Cout + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t rsw = frag ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_frag), 0, ntile16 * a.nkc * 2048, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((long long)p.Cout * a.w_row_bytes), 0x00020000);
+    const int kc_stride = frag ? 2048 : 128, term_off = frag ? 1024 : 64;
     int woff[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int n = n0 + 16 * v + i16;
-        woff[v] = n < p.Cout ? (int)(n * a.w_row_bytes) + g16 * 16 : (int)(OOB - 64);
+        if (frag) woff[v] = (n >> 4) < ntile16 ? ((n >> 4) * a.nkc * 2048 + lane * 16) : (int)(OOB - 2048);
+        else woff[v] = n < p.Cout ? (int)(n * a.w_row_bytes) + g16 * 16 : (int)(OOB - 2048);
     }
     // (ordinary buffer loads: the compiler keeps the registers and counts vmcnt for them - an asm load into a register the
     // compiler believes ready was copied around by the register allocator BEFORE its data had landed.  The LDS-DMA pieces are
@@ -140,11 +153,11 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
     f32x4 wr[2][NV][2];     // [register set][channel tile][term]
     auto issue_w = [&](auto set_tag, int kc) {
         constexpr int SET = decltype(set_tag)::value;
-        const int soff = kc * 128;
+        const int soff = kc * kc_stride;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             wr[SET][v][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[v], soff, 0));
-            if (TERMS == 3) wr[SET][v][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[v] + 64, soff, 0));
+            if (TERMS == 3) wr[SET][v][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, woff[v] + term_off, soff, 0));
         }
     };
 
@@ -169,16 +182,30 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
     // Step (c, t) uses W(c, t), loaded one step earlier.  At a chunk's top everything older than the NWL weight loads of
     // W(c, 0) must have landed - that includes the patch of chunk c, issued a whole chunk ago.
     const int nsteps = nci * NT;
+#ifdef FF_DMA_STAMPS      // lab build (FF_HIPCC_EXTRA_conv_dma=-DFF_DMA_STAMPS): phase stamps of every block into FFConvParams.splitk_ws
+    unsigned long long stamp[4];
+    stamp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     auto step = [&](int s, auto set_tag) {
         constexpr int CUR = decltype(set_tag)::value, NXT = CUR ^ 1;
         const int c = s / NT, t = s - c * NT, dy = t / KW, dx = t - dy * KW;       // (scalar unit; NT, KW are constants)
         const bool more = c + 1 < nci, last_tap = t + 1 == NT;
+#ifdef FF_DMA_ABL      // lab build: timing-only ablations (WRONG results): 1 patch staged once, 2 weights loaded once, 4 one barrier only, 8 no LDS reads
+        if (t == 0 && (!(FF_DMA_ABL & 4) || s == 0)) {
+#else
         if (t == 0) {
+#endif
             wait_vm<NWL>();
             __builtin_amdgcn_s_barrier();      // every wave's pieces of patch c have landed; everybody is done with the other buffer
+#ifdef FF_DMA_STAMPS
+            if (s == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
         }
         // (unconditionally - the last step re-reads chunk 0 for nothing: a load under a condition would leave the compiler's
         // vmcnt bookkeeping with two histories to merge, and it then waits for vmcnt(0), i.e. for the loads just issued)
+#ifdef FF_DMA_ABL
+        if (!(FF_DMA_ABL & 2) || s == 0)
+#endif
         issue_w(std::integral_constant<int, NXT>{}, s + 1 < nsteps ? (last_tap ? c + 1 : (t + 1) * nci + c) : 0);
         __builtin_amdgcn_sched_barrier(0);     // the loads stay HERE: left alone the scheduler sinks them below this tap's MFMAs (fewer live registers) and the next tap starts with their round trip
         // this lane's fragment rows of the tap: column px = pcol + dx (swizzle key (px >> 1) & 7), patch row dy (+ u: immediates)
@@ -186,34 +213,49 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
         const unsigned sw = (unsigned)((px >> 1) & 7);
         const unsigned rowb = lds0 + (unsigned)(c & 1) * PBYTES + (unsigned)((dy * PW + px) * 128);
         const unsigned xa0 = rowb + ((g16 ^ sw) << 4), xa1 = rowb + (((4 + g16) ^ sw) << 4);
+        auto rows = [&](auto lo_tag, auto hi_tag) {
+            constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
 #pragma unroll
-        for (int u = 0; u < TH; ++u) {
-            const f16x8 xa = lds_ld16(xa0 + u * PW * 128);
-            f16x8 xb;
-            if (TERMS == 3) xb = lds_ld16(xa1 + u * PW * 128);
+            for (int u = LO; u < HI; ++u) {
+                const f16x8 xa = lds_ld16(xa0 + u * PW * 128);
+                f16x8 xb;
+                if (TERMS == 3) xb = lds_ld16(xa1 + u * PW * 128);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const f16x8 w0 = __builtin_bit_cast(f16x8, wr[CUR][v][0]);
-                acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa, acc[v][u], 0, 0, 0);
-                if (TERMS == 3) {
-                    const f16x8 w1 = __builtin_bit_cast(f16x8, wr[CUR][v][1]);
-                    acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa, acc[v][u], 0, 0, 0);
-                    acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xb, acc[v][u], 0, 0, 0);
+                for (int v = 0; v < NV; ++v) {
+                    const f16x8 w0 = __builtin_bit_cast(f16x8, wr[CUR][v][0]);
+                    acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa, acc[v][u], 0, 0, 0);
+                    if (TERMS == 3) {
+                        const f16x8 w1 = __builtin_bit_cast(f16x8, wr[CUR][v][1]);
+                        acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa, acc[v][u], 0, 0, 0);
+                        acc[v][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xb, acc[v][u], 0, 0, 0);
+                    }
                 }
             }
-        }
-        // schedule of the tap: the fragment reads run two pixel rows ahead of the MFMAs (three rows of fragments live, not TH)
-        constexpr int RD = TERMS == 3 ? 2 : 1, LEAD = TH < 2 ? TH : 2;
-        __builtin_amdgcn_sched_group_barrier(0x100, RD * LEAD, 0);
+            // schedule: the fragment reads run two pixel rows ahead of the MFMAs (three rows of fragments live, not all)
+            constexpr int RD = TERMS == 3 ? 2 : 1, N = HI - LO, LEAD = N < 2 ? N : 2;
+            __builtin_amdgcn_sched_group_barrier(0x100, RD * LEAD, 0);
 #pragma unroll
-        for (int u = 0; u < TH; ++u) {
-            if (u + LEAD < TH) __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NV * TERMS, 0);
+            for (int u = 0; u < N; ++u) {
+                if (u + LEAD < N) __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NV * TERMS, 0);
+            }
+        };
+        // The next chunk's patch, once per chunk, is issued BEHIND the first rows of tap 0 - i.e. behind the compiler's vmcnt
+        // wait for this tap's weights.  That count does not know the DMA pieces: every later weight wait (one per tap) also
+        // waits for every piece older than the loads it leaves in flight, so the pieces must be as old as possible when
+        // the next wait comes - here they have the rest of this tap.  (At the end of the tap they had nothing: stamps
+        // showed 7 % of the main loop waiting for pieces issued a moment earlier.)
+        constexpr int SPLIT = TH >= 4 ? 2 : TH;
+        if (t == 0 && more) {
+            rows(std::integral_constant<int, 0>{}, std::integral_constant<int, SPLIT>{});
+#ifdef FF_DMA_ABL
+            if (!(FF_DMA_ABL & 1))
+#endif
+            issue_patch(c + 1, (c + 1) & 1);
+            rows(std::integral_constant<int, SPLIT>{}, std::integral_constant<int, TH>{});
+        } else {
+            rows(std::integral_constant<int, 0>{}, std::integral_constant<int, TH>{});
         }
-        // the next chunk's patch, once per chunk, BEHIND this tap's waits: the compiler's vmcnt(N) for the weights does not
-        // know the DMA pieces and would otherwise wait for pieces (or weight loads) issued a moment ago; from here they have
-        // the whole of tap 1 to land before a weight wait reaches back to them
-        if (t == 0 && more) issue_patch(c + 1, (c + 1) & 1);
     };
     int s = 0;
     for (; s + 1 < nsteps; s += 2) {
@@ -221,15 +263,19 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
         step(s + 1, std::integral_constant<int, 1>{});
     }
     if (s < nsteps) step(s, std::integral_constant<int, 0>{});
+#ifdef FF_DMA_STAMPS
+    stamp[2] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- epilogue (conv_patch.hip's 16x16x32 form): acc[v][u][r] = channel n4 + r (n4 = n0 + 16 v + 4 g) of pixel (y0 + u, x0 + pcol)
-    // Pixel rows in groups of four: values, then ALL operand loads of the group together, then the arithmetic and the stores
-    // (eight rows at a time need 96 registers beside the accumulators and spill the loop's DMA roles).
+    // Per channel tile: ALL operand loads of its UG pixel rows first (residual, GRU operands: up to 3 x UG 16-byte loads in
+    // flight), then the arithmetic, then the stores.  In-kernel stamps (tools/dma_stamps.py) had shown the z|r and q blocks
+    // spending 12 us of their 48 behind the main loop - every block of the launch in that phase at the same time, each
+    // running load -> use -> load -> use chains of four memory round trips.
     const float xinv = ff::SPLIT_INV;
     const int x = x0 + pcol;
     const bool vec_y = (p.y_ld & 3) == 0 && ff::aligned16(p.y);
     const bool vec_r = !p.res || ((p.res_ld & 3) == 0 && ff::aligned16(p.res));
-    constexpr int UG = 4;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int n4 = n0 + v * 16 + g16 * 4;
@@ -247,26 +293,19 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
         if (tail) nv = 4;
         const bool out_full = nv == 4;
         const bool split_out = p.y_fmt == FF_FMT_SPLIT && n4 >= p.y_fmt_from;
+        const bool rh = EPI == FF_EP_GRU_RH && n4 >= p.ep_split;
 #pragma unroll
         for (int ug = 0; ug < TH; ug += UG) {
-            f32x4 vv[UG], rr[UG], zz[UG];
+            f32x4 rr[UG], aa[UG], bb[UG];
             long long po[UG];
+            // -- loads
 #pragma unroll
             for (int k = 0; k < UG; ++k) {
                 const int y = y0 + ug + k;
                 po[k] = (y < H && x < W) ? ((long long)bimg * H + y) * W + x : -1;
-                f32x4 t = acc[v][ug + k] * xinv + bias;
-                t *= p.out_scale;
-                if (p.ch_scale) t = t * cs + ct;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] = ff::apply_act(t[r], p.act);
-                vv[k] = t;
-            }
-            if (p.res) {
-#pragma unroll
-                for (int k = 0; k < UG; ++k) {
-                    rr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (po[k] < 0) continue;
+                rr[k] = aa[k] = bb[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (po[k] < 0) continue;
+                if (p.res) {
                     const float* rp2 = p.res + po[k] * p.res_ld + n4;
                     if (full && vec_r) rr[k] = *reinterpret_cast<const f32x4*>(rp2);
                     else {
@@ -275,44 +314,45 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
                             if (n4 + r < p.Cout) rr[k][r] = rp2[r];
                     }
                 }
-#pragma unroll
-                for (int k = 0; k < UG; ++k)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[k][r] = ff::apply_act(vv[k][r] + rr[k][r], p.act_res);
-            }
-            if constexpr (EPI == FF_EP_GRU_RH) {          // [z | r] -> [z | r * h] (update.py:47-48)
-                if (n4 >= p.ep_split) {
-#pragma unroll
-                    for (int k = 0; k < UG; ++k) rr[k] = po[k] >= 0 ? *reinterpret_cast<const f32x4*>(p.ep_a + po[k] * p.ep_a_ld + (n4 - p.ep_split)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < UG; ++k)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) vv[k][r] = __fmul_rn(vv[k][r], rr[k][r]);
+                if (rh) aa[k] = *reinterpret_cast<const f32x4*>(p.ep_a + po[k] * p.ep_a_ld + (n4 - p.ep_split));     // h (update.py:47-48)
+                if constexpr (EPI == FF_EP_GRU_BLEND) {
+                    aa[k] = *reinterpret_cast<const f32x4*>(p.ep_a + po[k] * p.ep_a_ld + n4);      // z
+                    bb[k] = *reinterpret_cast<const f32x4*>(p.ep_b + po[k] * p.ep_b_ld + n4);      // h
+                }
+                if constexpr (EPI == FF_EP_MOTION_TAIL) {
+                    if (tail) { aa[k][0] = p.ep_a[po[k] * 2]; aa[k][1] = p.ep_a[po[k] * 2 + 1]; }      // coords1
                 }
             }
-            if constexpr (EPI == FF_EP_GRU_BLEND) {       // v = tanh(q) -> (1 - z) h + z v (update.py:49), z = ep_a, h = ep_b
+            // -- arithmetic (the roundings of the separate kernels: ff_gru_rh / ff_gru_blend / ff_coords_step)
+            f32x4 vv[UG];
 #pragma unroll
-                for (int k = 0; k < UG; ++k) {
-                    zz[k] = po[k] >= 0 ? *reinterpret_cast<const f32x4*>(p.ep_a + po[k] * p.ep_a_ld + n4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    rr[k] = po[k] >= 0 ? *reinterpret_cast<const f32x4*>(p.ep_b + po[k] * p.ep_b_ld + n4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < UG; ++k) {
+                f32x4 t = acc[v][ug + k] * xinv + bias;
+                t *= p.out_scale;
+                if (p.ch_scale) t = t * cs + ct;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = ff::apply_act(t[r], p.act);
+                if (p.res) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = ff::apply_act(t[r] + rr[k][r], p.act_res);
                 }
+                if (rh) {
 #pragma unroll
-                for (int k = 0; k < UG; ++k)
+                    for (int r = 0; r < 4; ++r) t[r] = __fmul_rn(t[r], aa[k][r]);
+                }
+                if constexpr (EPI == FF_EP_GRU_BLEND) {       // v = tanh(q) -> (1 - z) h + z v (update.py:49)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        vv[k][r] = __fadd_rn(__fmul_rn(__fsub_rn(1.f, zz[k][r]), rr[k][r]), __fmul_rn(zz[k][r], vv[k][r]));
-            }
-            if constexpr (EPI == FF_EP_MOTION_TAIL) {     // channels Cout, Cout + 1 of the padded buffer = flow = coords1 - grid (raft.py:219)
-                if (tail) {
-#pragma unroll
-                    for (int k = 0; k < UG; ++k) {
-                        if (po[k] < 0) continue;
-                        const float cx = p.ep_a[po[k] * 2], cy = p.ep_a[po[k] * 2 + 1];
-                        vv[k][2] = __fsub_rn(cx, (float)x);
-                        vv[k][3] = __fsub_rn(cy, (float)(y0 + ug + k));
+                    for (int r = 0; r < 4; ++r) t[r] = __fadd_rn(__fmul_rn(__fsub_rn(1.f, aa[k][r]), bb[k][r]), __fmul_rn(aa[k][r], t[r]));
+                }
+                if constexpr (EPI == FF_EP_MOTION_TAIL) {     // channels Cout, Cout + 1 of the padded buffer = flow = coords1 - grid (raft.py:219)
+                    if (tail) {
+                        t[2] = __fsub_rn(aa[k][0], (float)x);
+                        t[3] = __fsub_rn(aa[k][1], (float)(y0 + ug + k));
                     }
                 }
+                vv[k] = t;
             }
+            // -- stores
 #pragma unroll
             for (int k = 0; k < UG; ++k) {
                 if (po[k] < 0) continue;
@@ -330,11 +370,20 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
             }
         }
     }
+#ifdef FF_DMA_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    if (p.splitk_ws && tid == 0) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.splitk_ws) + (size_t)blockIdx.x * 4;
+        d[0] = stamp[0]; d[1] = stamp[1]; d[2] = stamp[2]; d[3] = stamp[3];
+    }
+#endif
 }
 
 template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int OCC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_dma_kernel(const DArgs a) {
-    conv_dma_body<KH, KW, TH, NV, TERMS, EPI>(a);
+    // all TH rows at once where the registers allow: one channel tile per wave (32 accumulator registers) at three waves per SIMD
+    conv_dma_body<KH, KW, TH, NV, TERMS, EPI, (NV == 1 && OCC <= 3) ? TH : (TH < 4 ? TH : 4)>(a);
 }
 
 template <int KH, int KW, int TH, int NV, int TERMS, int OCC>
@@ -357,12 +406,38 @@ int launch_tile(DArgs& a, int th, int nv, hipStream_t s) {
     a.tiles_y = (a.p.H + th - 1) / th;
     a.n_tiles = (a.p.Cout + (a.p.ep_mode == FF_EP_MOTION_TAIL ? 2 : 0) + 64 * nv - 1) / (64 * nv);
     if (th == 8 && nv == 2) return launch_ep<KH, KW, 8, 2, TERMS, 3>(a, s);
-    if (th == 8 && nv == 1) return launch_ep<KH, KW, 8, 1, TERMS, 3>(a, s);      // (two 23 KB patch buffers: three blocks per CU)
+    if (th == 8 && nv == 1) {
+        // 3x3 and 5x1: two 23-24 KB patch buffers, three blocks per CU; 1x5: two 20 KB buffers, four
+        if constexpr (KH == 1) { static const bool occ4 = !(getenv("FF_DMA_OCC4") && atoi(getenv("FF_DMA_OCC4")) == 0); if (occ4) return launch_ep<KH, KW, 8, 1, TERMS, 4>(a, s); }
+        return launch_ep<KH, KW, 8, 1, TERMS, 3>(a, s);
+    }
     if (th == 4 && nv == 2) return launch_ep<KH, KW, 4, 2, TERMS, 4>(a, s);
     return launch_ep<KH, KW, 4, 1, TERMS, 5>(a, s);
 }
 
+// rows -> fragment order: one thread per 16-byte piece of the destination
+__global__ void pack_frag16_kernel(const char* __restrict__ src, char* __restrict__ dst, int rows, int nkc, long long pieces) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < pieces; i += (long long)gridDim.x * 256) {
+        const int lane = (int)(i & 63), term = (int)((i >> 6) & 1);
+        const long long tk = i >> 7;                      // tile * nkc + kc
+        const int kc = (int)(tk % nkc), tile = (int)(tk / nkc);
+        const int row = tile * 16 + (lane & 15), g = lane >> 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < rows) v = *reinterpret_cast<const f32x4*>(src + ((long long)row * nkc + kc) * 128 + term * 64 + g * 16);
+        *reinterpret_cast<f32x4*>(dst + i * 16) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int ff_pack_frag16(const void* split_rows, void* dst, int rows, int nkc, void* stream) {
+    FF_REQUIRE(split_rows && dst && rows > 0 && nkc > 0 && ff::aligned16(split_rows) && ff::aligned16(dst), "ff_pack_frag16: bad argument");
+    const long long pieces = (long long)((rows + 15) / 16) * nkc * 128;
+    FF_REQUIRE(pieces * 16 < (1ll << 31), "ff_pack_frag16: 2 GiB or more");
+    pack_frag16_kernel<<<(unsigned)std::min<long long>((pieces + 255) / 256, 4096), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const char*>(split_rows), static_cast<char*>(dst), rows, nkc, pieces);
+    return ff::check_launch("ff_pack_frag16");
+}
 
 namespace ff {
 // returns FF_OK if launched, 1 if no input segment is in the split-pair format (the caller goes on to the fp32-input
@@ -390,9 +465,11 @@ int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s) {
     a.p = p;
     a.Cin = cin;
     a.nci = cin / 32;
+    a.nkc = p.KH * p.KW * a.nci;
     a.tiles_x = (p.W + 15) / 16;
     a.w_row_bytes = (long long)((p.KH * p.KW * cin + 31) / 32) * 128;
-    max_bytes = std::max(max_bytes, (long long)p.Cout * a.w_row_bytes);
+    max_bytes = std::max(max_bytes, (long long)(p.Cout + 15) * a.w_row_bytes);
+    if (p.w_frag && !aligned16(p.w_frag)) return fail(FF_EINVAL, "ff_conv2d_fwd: w_frag not 16-byte aligned");
     if (max_bytes >= (1ll << 31) || (long long)p.B * p.H * p.W >= (1ll << 24))
         return fail(FF_EINVAL, "ff_conv2d_fwd: split-pair convolution: a buffer of 2 GiB or more, or 2^24 pixels or more");
     if (p.ep_mode == FF_EP_COORDS) return fail(FF_EINVAL, "ff_conv2d_fwd: FF_EP_COORDS belongs to the fp32 flow head");
@@ -400,14 +477,14 @@ int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s) {
         return fail(FF_EINVAL, "ff_conv2d_fwd: FF_EP_MOTION_TAIL: Cout %% 4 == 2, room for two more channels and ep_a = coords1");
     if ((p.y_fmt == FF_FMT_SPLIT && (p.y_fmt_from % 32 || p.y_ld % 4 || !aligned16(p.y))) || (p.y2 && (p.y2_ld % 4 || !aligned16(p.y2))))
         return fail(FF_EINVAL, "ff_conv2d_fwd: split-pair output: y_fmt_from %% 32, ld %% 4 and 16-byte alignment");
-    // Tile choice: 8 x 16 pixels x 128 channels per block where that still gives every CU its blocks, else smaller tiles
-    // (the update block at 8 pairs is 192 tiles of 8 x 16 pixels on 256 CUs).  FF_DMA_TILE = th * 10 + nv overrides (tuning).
+    // Tile choice, measured per layer of the update block (tools/bench_dma_conv.py): 8 x 16 pixels x 64 channels per block
+    // (one 16-channel tile per wave) wins at 8 pairs AND at 32 - 16-25 % over the fp32 route, where two channel tiles per
+    // wave (a third of the LDS reads per MFMA) are 10-40 % slower at 8 pairs (half the blocks on a chip the 64-channel
+    // blocks just fill) and equal at 32; 4-row tiles double the weight traffic per pixel and only pay on tiny planes.
+    // FF_DMA_TILE = th * 10 + nv overrides (tuning).
     const int couts = p.Cout + (p.ep_mode == FF_EP_MOTION_TAIL ? 2 : 0);
     auto nblocks = [&](int th, int nv) { return (long long)p.B * ((p.H + th - 1) / th) * a.tiles_x * ((couts + 64 * nv - 1) / (64 * nv)); };
-    int th = 8, nv = couts > 64 ? 2 : 1;
-    if (nblocks(th, nv) < 640 && nv == 2 && couts % 128 != 0 && couts % 128 <= 64) nv = 1;       // a half-empty second channel tile
-    if (nblocks(th, nv) < 640) th = 4;
-    if (nblocks(th, nv) < 640 && nv == 2) nv = 1;
+    int th = nblocks(8, 1) >= 384 ? 8 : 4, nv = 1;
     if (const char* e = getenv("FF_DMA_TILE")) {
         const int v = atoi(e);
         if (v > 0) { th = v / 10; nv = v % 10; }

@@ -11,6 +11,10 @@
 //
 // Block = 256 threads = 4 waves (2 x 2): wave (wm, wn) computes output rows 4wm..4wm+3 of the tile
 // (two 32-pixel MFMA tiles: rows 2t, 2t+1 x 16 columns) for 32 of the block's 64 output channels.
+// The epilogue's arithmetic is written as separately rounded operations and must stay that: conv_patch.hip and conv_dma.hip
+// promise the same bits for the same layer (tests/test_hip_split.py), and a multiply-add that one of them contracts into an
+// fma - after the optimiser specialised a path on the activation code - breaks that.  build.py reads the next line.
+// hipcc-flags: -ffp-contract=off
 #include <algorithm>
 #include <cstdlib>
 #include "ff_common.h"

@@ -103,11 +103,21 @@ int lookup_dma_fwd(const void* const* levels, int half, const float* coords, lon
 
 __host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// sigmoid / tanh of the GRU gates (update.py:47-49) on the hardware's exp2 and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each):
+// absolute error < 2e-7 on values in (-1, 1) - below the 2^-22 of the split format the results are stored in - for 6 / 9
+// vector instructions instead of the ~35 / ~50 of expf + IEEE division / tanhf.  (A z|r block's epilogue was a quarter
+// of its main loop: 32 sigmoids per thread.)  exp2 overflows to inf for v < -88: rcp(inf) = 0, the right limit.
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.44269504f)); }
+__device__ __forceinline__ float fast_tanh(float v) {
+    const float t = __builtin_amdgcn_exp2f(fabsf(v) * -2.88539008f);          // exp(-2 |v|) in (0, 1]
+    return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), v);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case FF_ACT_RELU: return v > 0.f ? v : 0.f;
-        case FF_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        case FF_ACT_TANH: return tanhf(v);
+        case FF_ACT_SIGMOID: return fast_sigmoid(v);
+        case FF_ACT_TANH: return fast_tanh(v);
         case FF_ACT_LEAKY: return v > 0.f ? v : 0.1f * v;
         default: return v;
     }

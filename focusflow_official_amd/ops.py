@@ -64,6 +64,14 @@ def pack_split(rows_f32: Tensor) -> Tensor:
     return dst
 
 
+def pack_frag16(w_split: Tensor, rows: int) -> Tensor:
+    """Split rows (pack_split) -> MFMA-fragment order (ff_pack_frag16) for FFConvParams.w_frag."""
+    nkc = w_split.shape[1] // 128
+    dst = torch.empty(((rows + 15) // 16) * nkc * 2048, dtype=torch.uint8, device=w_split.device)
+    _hip.call("ff_pack_frag16", _p(w_split), _p(dst), rows, nkc, _stream())
+    return dst
+
+
 class _StreamPolicy(threading.local):
     """Per-THREAD stream policy of the forward passes (two models driven from two threads do not see each other's).
     single_stream: set by a caller that brackets single launches with events (bench.py's roofline_conv leg) - every
@@ -238,7 +246,7 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
            x_amax: Optional[Tensor] = None, in_scale: Optional[Tensor] = None, in_shift: Optional[Tensor] = None,
            in_act: int = ACT_NONE, res2: Optional[Tensor] = None, res_split: int = 0,
            ep_rh: Optional[Tensor] = None, ep_split: int = 0, ep_blend=None, want_stats: bool = False, ep_coords=None,
-           y_split=False, y2_split: bool = False, ep_motion_tail: Optional[Tensor] = None):
+           y_split=False, y2_split: bool = False, ep_motion_tail: Optional[Tensor] = None, w_frag: Optional[Tensor] = None):
     """Convolution over the channel-concatenation of `xs` (see FFConvParams).  want_stats: -> (out, stats) with the
     per-sample {sum, sum of squares} table of the output (what norm_stats(out, True) returns): from the convolution's own
     epilogue where the kernel can (FFConvParams.stats_part), else from a norm_stats pass.  res2 / res_split: output channels
@@ -270,6 +278,8 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
         f"packed weight {tuple(wpack.shape)} vs Cout {cout}, K {kh * kw * cin} (format {w_fmt})"
     p.groups, p.B, p.H, p.W = 1, b, h, w
     p.w, p.w_gstride = wpack.data_ptr(), 0
+    if w_frag is not None and any(fmts):      # the same weights in fragment order (pack_frag16): split-pair kernel only
+        p.w_frag = w_frag.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None
     p.ch_scale = ch_scale.data_ptr() if ch_scale is not None else None
     p.ch_shift = ch_shift.data_ptr() if ch_shift is not None else None

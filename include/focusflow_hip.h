@@ -161,6 +161,8 @@ typedef struct FFConvParams {
     int y_fmt_from;                    /* (multiple of 32; the z|r convolution keeps z in fp32 and writes r*h split)          */
     float* y2;                         /* NULL, or a second copy of the WHOLE output in FF_FMT_SPLIT (the GRU's new state:    */
     int y2_ld;                         /* fp32 for the next blend, split for the next convolutions)                           */
+    const void* w_frag;                /* NULL, or the same split weights as `w` in MFMA-fragment order (ff_pack_frag16): the  */
+                                       /* split-pair kernel then loads a wave's 16-channel x 32-k operand as ONE contiguous KB */
 } FFConvParams;
 #define FF_FMT_F32 0
 #define FF_FMT_SPLIT 1
@@ -184,6 +186,11 @@ int ff_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW,
  * same scale (one accumulator serves all three product terms).  Values must satisfy |v| < 4094; the convolutions'
  * activations (split the same way at scale 4 inside the kernels) |x| < 16376. */
 int ff_pack_split_f16(const float* src_rows, void* dst, long long rows, int K, void* stream);
+/* Split rows (ff_pack_split_f16: [rows][nkc][x0: 32 fp16 | x1: 32 fp16]) -> MFMA-fragment order for FFConvParams.w_frag:
+ * [ceil(rows / 16)][nkc][term][lane 0..63][16 bytes], lane = 16 g + i holding k-group g (8 halfs) of row 16 tile + i -
+ * the A operand of v_mfma_f32_16x16x32_f16 as it sits in registers; rows past the end are zero.
+ * dst: ceil(rows / 16) * nkc * 2048 bytes, 16-byte aligned. */
+int ff_pack_frag16(const void* split_rows, void* dst, int rows, int nkc, void* stream);
 /* Number of K splits ff_conv2d_fwd would put to use for this convolution (0: none - leave splitk_ws NULL).  A plain
  * return value, not a status.  Does not launch anything. */
 int ff_conv2d_splitk_hint(const FFConvParams* p);
