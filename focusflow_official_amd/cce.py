@@ -159,7 +159,7 @@ class PackedConv:
         w, b = self.get()
         if not isinstance(xs, (list, tuple)):
             xs = [xs]
-        if _DMA_FRAG and self.fmt != 0 and any(isinstance(x, ops.SplitT) for x in xs):
+        if _DMA_FRAG and self.fmt != 0 and any(isinstance(x, ops.SplitT) for x in xs):     # conv_dma.hip loads its weights in fragment order
             kw["w_frag"] = self.frag()
         return ops.conv2d(xs, w, b, self.cout, self.kh, self.kw, self.stride, self.pad, act=act, w_fmt=self.fmt,
                           dilation=self.dil, **kw)

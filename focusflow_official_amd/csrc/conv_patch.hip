@@ -156,7 +156,7 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
                 f16x4 h0, h1;
                 f32x4 v = rp[i];
                 if (INORM) {                // the producer's normalisation (+ ReLU) on the way in; padding is zero AFTER it
-                    v = v * nmul + nadd;
+                    v = __builtin_elementwise_fma(v, nmul, nadd);      // (one fused operation, as norm_apply_kernel's: the two give the same bits)
                     if (p.in_act == FF_ACT_RELU) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         if (rb) r = *reinterpret_cast<const f32x4*>(rb + p * res_ld + g * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float o = v[j] * s_mul[g * 4 + j] + s_add[g * 4 + j];
+            float o = fmaf(v[j], s_mul[g * 4 + j], s_add[g * 4 + j]);       // (one fused operation: the normalise-on-load loaders of conv_patch.hip / conv_dma.hip do the same)
             o = ff::apply_act(o, act);
             if (rb) { o += r[j]; o = o > 0.f ? o : 0.f; }
             v[j] = o;

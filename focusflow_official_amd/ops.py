@@ -278,7 +278,7 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
         f"packed weight {tuple(wpack.shape)} vs Cout {cout}, K {kh * kw * cin} (format {w_fmt})"
     p.groups, p.B, p.H, p.W = 1, b, h, w
     p.w, p.w_gstride = wpack.data_ptr(), 0
-    if w_frag is not None and any(fmts):      # the same weights in fragment order (pack_frag16): split-pair kernel only
+    if w_frag is not None:      # the same weights in fragment order (pack_frag16): read by conv_dma.hip only
         p.w_frag = w_frag.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None
     p.ch_scale = ch_scale.data_ptr() if ch_scale is not None else None

@@ -48,7 +48,7 @@ def main():
     g = torch.Generator().manual_seed(0)
     tot_old = tot_best = 0.0
     only = os.environ.get("LAYER")            # substring filter (profiling runs)
-    tiles = [int(t) for t in os.environ.get("TILES", "0,82,81,42,41").split(",")]
+    tiles = [int(t) for t in os.environ.get("TILES", "0,8,8,4").split(",")]
     for name, segs, cout, kh, kw, ep in LAYERS:
         if only and only not in name:
             continue

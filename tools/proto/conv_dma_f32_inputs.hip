@@ -1,3 +1,8 @@
+// PROTOTYPE (round 4, not built): conv_dma.hip with an fp32-input mode (XMODE 1 / 2: the patch staged through registers, weights
+// straight into registers in fragment order, one barrier per chunk, statistics epilogue) that took the encoders' 3x3 layers from
+// conv_patch.hip.  Measured end to end, same box, 20 steps each: 551.5 / 552.3 pairs/s with it against 564.4 / 568.1 without
+// (-2.5 %): at 162-168 registers it runs three blocks per CU where conv_patch.hip runs four, and the convert-and-store of the
+// next patch is a serial phase of all four waves.  It also failed five gradient / multi-sample tests when it was dropped.
 // Convolutions over SPLIT-PAIR activations (FF_FMT_SPLIT, focusflow_hip.h): stride-1 "same" 3x3 / 1x5 / 5x1 layers whose
 // inputs were written by their producers as [x0: 32 fp16 | x1: 32 fp16] per 32-channel chunk - the update block's
 // motion encoder, SepConvGRU and heads (update.py:45-60, 89-97, 121-135), twelve times per forward.
@@ -72,10 +77,14 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // KH x KW taps; TH pixel rows x 16 columns per block; NV 16-channel tiles per wave (block = 4 waves = 64 NV channels)
 // EPI: FFConvParams.ep_mode (GRU steps, motion tail); TERMS 3 (f16x3) or 1 (f16)
 // UG: pixel rows whose epilogue operands are loaded together
-// (An fp32-input mode of this kernel - patch staged through registers - for the encoders' 3x3 layers was built and measured:
-// 2.5 % slower end to end than conv_patch.hip at four blocks per CU; tools/proto/conv_dma_f32_inputs.hip.)
-template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int UG, int NSET>
+// XMODE: 0 split-pair inputs (LDS-DMA); 1 fp32 inputs, staged through registers (load -> split -> ds_write, the next chunk's
+//        loads in flight during this chunk's taps); 2 = 1 + the producer's normalisation applied on the way (FFConvParams
+//        in_scale / in_shift / in_act).  The fp32 modes keep everything else of this kernel - no weights in LDS, one barrier per
+//        chunk - for the encoders' 3x3 layers, whose inputs pass through InstanceNorm and cannot be written split by a producer.
+// STATS: FFConvParams.stats_part (partial InstanceNorm statistics of the output from the epilogue)
+template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int UG, int NSET, int XMODE, bool STATS>
 __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
+    constexpr bool XF32 = XMODE != 0, INORM = XMODE == 2;
     constexpr int PW = 16 + KW - 1, PH = TH + KH - 1, NPIX = PH * PW, NPIECE = (NPIX + 7) / 8, NPP = (NPIECE + 3) / 4;
     constexpr int PBYTES = NPIECE * 1024, NT = KH * KW, NWL = NV * (TERMS == 3 ? 2 : 1);
     static_assert(PW % 2 == 0, "the bank argument needs an even patch width");
@@ -134,6 +143,66 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
             }
         }
     };
+    // ---- fp32 inputs (XMODE 1 / 2): item = tid + 256 i -> (patch row item >> 3, 16-byte channel group kq = item & 7)
+    constexpr int NITEM = XF32 ? (NPIX * 8 + 255) / 256 : 1;
+    float xs = 1.f, xinv_in = 1.f;
+    if constexpr (XF32) ff::input_scale(p.x_amax, xs, xinv_in);     // gradients (dgrad on the f16 pipe): the input times 2^k, undone in the epilogue
+    int ipix[NITEM];           // image pixel of the item's patch row, -1 outside the image, -2 past the patch (no item)
+    f32x4 rp[NITEM];
+    f32x4 nmul = {1.f, 1.f, 1.f, 1.f}, nadd = {0.f, 0.f, 0.f, 0.f};
+    const int kq = tid & 7;
+    if constexpr (XF32) {
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            const int r = (tid + 256 * i) >> 3;
+            const int py = r / PW, px = r - py * PW;
+            const int yy = y0 - p.pad_h + py, xx = x0 - p.pad_w + px;
+            ipix[i] = r >= NPIX ? -2 : ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? (bimg * H + yy) * W + xx : -1;
+        }
+    }
+    auto load_patch = [&](int c) {
+        const int ci = c * 32;
+        const int in0 = -(int)(ci < c0), in1 = -(int)(ci >= c0 && ci < c01), in2 = -(int)(ci >= c01);
+        const int ldb = (ld0 & in0) | (ld1 & in1) | (ld2 & in2);
+        const int cib = (ci - (c0 & (in1 | in2)) - ((c01 - c0) & in2) + kq * 4) * 4;
+        const unsigned long long xp = (xp0 & (unsigned long long)(long long)in0) | (xp1 & (unsigned long long)(long long)in1) | (xp2 & (unsigned long long)(long long)in2);
+        const unsigned long long xpu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)xp);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(xpu), 0, __builtin_amdgcn_readfirstlane((int)(pix_total * ldb)), 0x00020000);
+        if constexpr (INORM) {
+            const long long t = (long long)bimg * a.Cin + ci + kq * 4;
+            nmul = *reinterpret_cast<const f32x4*>(p.in_scale + t);
+            nadd = *reinterpret_cast<const f32x4*>(p.in_shift + t);
+        }
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            const int off = ipix[i] >= 0 ? ipix[i] * ldb + cib : (int)OOB;
+            rp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        }
+    };
+    auto store_patch = [&](int buf) {
+        const unsigned base = lds0 + buf * PBYTES;
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            if (ipix[i] == -2) continue;
+            // LDS place of the item (recomputed here, once per chunk, rather than kept in six registers through the tap loop):
+            // row r, 16-byte slot (kq >> 1) ^ key(px), half kq & 1; the x1 part sits 4 slots on: address ^ 64
+            const int r = (tid + 256 * i) >> 3, px = r % PW;
+            const int il = r * 128 + ((((kq >> 1) ^ ((px >> 1) & 7))) << 4) + (kq & 1) * 8;
+            f32x4 v = rp[i];
+            if constexpr (INORM) {              // the producer's normalisation (+ ReLU) on the way in; padding is zero AFTER it
+                v = __builtin_elementwise_fma(v, nmul, nadd);
+                if (p.in_act == FF_ACT_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (ipix[i] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            ff::ff_f16x4 h0, h1;
+            ff::split_pair4(v * xs, h0, h1);
+            *(__attribute__((address_space(3))) ff::ff_f16x4*)(unsigned long)(base + il) = h0;
+            if (TERMS == 3) *(__attribute__((address_space(3))) ff::ff_f16x4*)(unsigned long)(base + (il ^ 64)) = h1;
+        }
+    };
     // ---- weights: lane (i, g) holds k-group g of channel n0 + 16 v + i; term 1 = + 64 bytes
     const int i16 = lane & 15, g16 = lane >> 4;
     // Two sources: the packed rows [Cout][nkc][128 B] (a wave-load = 16 rows x 64 bytes in 16 different lines), or - FFConvParams
@@ -179,7 +248,8 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
 
     const int nci = a.nci;
 
-    issue_patch(0, 0);
+    if constexpr (XF32) { load_patch(0); store_patch(0); }
+    else issue_patch(0, 0);
     static_assert(NT >= 3, "the chunk-top wait assumes that a patch is older than the newest weight loads (1x1 kernels need vmcnt(0) there)");
     issue_w(std::integral_constant<int, 0>{}, 0);
     if constexpr (NSET == 3) issue_w(std::integral_constant<int, 1>{}, a.nci * NT > 1 ? (NT > 1 ? a.nci : 1) : 0);      // step 1 = (chunk 0, tap 1)
@@ -204,8 +274,9 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
 #else
         if (t == 0) {
 #endif
-            wait_vm<NWL>();
-            __builtin_amdgcn_s_barrier();      // every wave's pieces of patch c have landed; everybody is done with the other buffer
+            if constexpr (!XF32) wait_vm<NWL>();
+            if constexpr (XF32) __syncthreads();     // (the patch stores of chunk c: lgkmcnt(0) + barrier)
+            else __builtin_amdgcn_s_barrier();       // every wave's pieces of patch c have landed; everybody is done with the other buffer
 #ifdef FF_DMA_STAMPS
             if (s == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -263,10 +334,16 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
 #ifdef FF_DMA_ABL
             if (!(FF_DMA_ABL & 1))
 #endif
-            issue_patch(c + 1, (c + 1) & 1);
+            {
+                if constexpr (XF32) load_patch(c + 1);
+                else issue_patch(c + 1, (c + 1) & 1);
+            }
             rows(std::integral_constant<int, SPLIT>{}, std::integral_constant<int, TH>{});
         } else {
             rows(std::integral_constant<int, 0>{}, std::integral_constant<int, TH>{});
+        }
+        if constexpr (XF32) {
+            if (t == NT - 1 && more) store_patch((c + 1) & 1);     // into the other buffer: nobody reads it before the next chunk's barrier
         }
     };
     int s = 0;
@@ -294,7 +371,7 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
     // flight), then the arithmetic, then the stores.  In-kernel stamps (tools/dma_stamps.py) had shown the z|r and q blocks
     // spending 12 us of their 48 behind the main loop - every block of the launch in that phase at the same time, each
     // running load -> use -> load -> use chains of four memory round trips.
-    const float xinv = ff::SPLIT_INV;
+    const float xinv = ff::SPLIT_INV * xinv_in;
     const int x = x0 + pcol;
     const bool vec_y = (p.y_ld & 3) == 0 && ff::aligned16(p.y);
     const bool vec_r = !p.res || ((p.res_ld & 3) == 0 && ff::aligned16(p.res));
@@ -316,6 +393,8 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
         const bool out_full = nv == 4;
         const bool split_out = p.y_fmt == FF_FMT_SPLIT && n4 >= p.y_fmt_from;
         const bool rh = EPI == FF_EP_GRU_RH && n4 >= p.ep_split;
+        f32x4 st_p = {0.f, 0.f, 0.f, 0.f}, st_s1 = st_p, st_s2 = st_p;      // STATS: this lane's four channels over its pixels
+        float st_n = 0.f;
 #pragma unroll
         for (int ug = 0; ug < TH; ug += UG) {
             f32x4 rr[UG], aa[UG], bb[UG];
@@ -374,6 +453,17 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
                 }
                 vv[k] = t;
             }
+            if constexpr (STATS) {       // around a pivot (the lane's first value): fp32 sums without cancellation on nearly constant planes
+#pragma unroll
+                for (int k = 0; k < UG; ++k) {
+                    if (po[k] < 0) continue;
+                    if (st_n == 0.f) st_p = vv[k];
+                    const f32x4 d = vv[k] - st_p;
+                    st_s1 += d;
+                    st_s2 = __builtin_elementwise_fma(d, d, st_s2);
+                    st_n += 1.f;
+                }
+            }
             // -- stores
 #pragma unroll
             for (int k = 0; k < UG; ++k) {
@@ -391,6 +481,32 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
                 if (p.y2) ff::store_split4(p.y2 + po[k] * p.y2_ld, n4, vv[k], nv);
             }
         }
+        if constexpr (STATS) {
+            // the sixteen lanes i16 of a k-group hold the same four channels over other pixel columns: butterfly merge, every
+            // partial re-centred on the receiving lane's pivot (sum(v - p) = s + n d, sum((v - p)^2) = q + 2 d s + n d^2 for
+            // entries around p + d); lane i16 == 0 writes the entry [image][part = tile][channel] = {pivot, s1, s2, n}
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                f32x4 p2, t1, t2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p2[r] = __shfl_xor(st_p[r], off); t1[r] = __shfl_xor(st_s1[r], off); t2[r] = __shfl_xor(st_s2[r], off); }
+                const float n2 = __shfl_xor(st_n, off);
+                if (st_n == 0.f) { st_p = p2; st_s1 = t1; st_s2 = t2; st_n = n2; }
+                else if (n2 > 0.f) {
+                    const f32x4 d = p2 - st_p;
+                    st_s2 += t2 + 2.f * d * t1 + n2 * d * d;
+                    st_s1 += t1 + n2 * d;
+                    st_n += n2;
+                }
+            }
+            if (i16 == 0) {
+                const int nparts = a.tiles_y * a.tiles_x, part = ty * a.tiles_x + tx;
+                float* e = p.stats_part + (((long long)bimg * nparts + part) * p.Cout + n4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n4 + r < p.Cout) *reinterpret_cast<f32x4*>(e + 4 * r) = (f32x4){st_p[r], st_s1[r], st_s2[r], st_n};
+            }
+        }
     }
 #ifdef FF_DMA_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -402,11 +518,11 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
 #endif
 }
 
-template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int OCC>
+template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int OCC, int XMODE = 0, bool STATS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_dma_kernel(const DArgs a) {
     // all TH rows at once where the registers allow: one channel tile per wave (32 accumulator registers) at three waves per SIMD
     // three weight register sets where three waves per SIMD leave the registers for them
-    conv_dma_body<KH, KW, TH, NV, TERMS, EPI, (NV == 1 && OCC <= 3) ? TH : (TH < 4 ? TH : 4), (OCC <= 3 && NV == 1) ? FF_DMA_NSET : 2>(a);
+    conv_dma_body<KH, KW, TH, NV, TERMS, EPI, (NV == 1 && OCC <= 3) ? TH : (TH < 4 ? TH : 4), (OCC <= 3 && NV == 1) ? FF_DMA_NSET : 2, XMODE, STATS>(a);
 }
 
 template <int KH, int KW, int TH, int NV, int TERMS, int OCC>
@@ -422,6 +538,23 @@ int launch_ep(const DArgs& a, hipStream_t s) {
         default: return ff::fail(FF_EINVAL, "ff_conv2d_fwd(dma): ep_mode %d", a.p.ep_mode);
     }
     return ff::check_launch("ff_conv2d_fwd(dma)");
+}
+
+// fp32 inputs (3x3 only: the encoders' layers): plain / normalise-on-load, with or without the statistics epilogue
+template <int TH, int TERMS>
+int launch_f32(DArgs& a, hipStream_t s) {
+    constexpr int NPIECE = ((TH + 2) * 18 + 7) / 8;
+    constexpr size_t lds = 2 * NPIECE * 1024;
+    a.tiles_y = (a.p.H + TH - 1) / TH;
+    a.n_tiles = (a.p.Cout + 63) / 64;
+    const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    const bool inorm = a.p.in_scale != nullptr, stats = a.p.stats_part != nullptr;
+    constexpr int OCC = TH == 8 ? 3 : 4;
+    if (inorm && stats) conv_dma_kernel<3, 3, TH, 1, TERMS, 0, OCC, 2, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+    else if (inorm) conv_dma_kernel<3, 3, TH, 1, TERMS, 0, OCC, 2, false><<<(unsigned)blocks, 256, lds, s>>>(a);
+    else if (stats) conv_dma_kernel<3, 3, TH, 1, TERMS, 0, OCC, 1, true><<<(unsigned)blocks, 256, lds, s>>>(a);
+    else conv_dma_kernel<3, 3, TH, 1, TERMS, 0, OCC, 1, false><<<(unsigned)blocks, 256, lds, s>>>(a);
+    return ff::check_launch("ff_conv2d_fwd(dma, fp32 inputs)");
 }
 
 template <int KH, int KW, int TERMS>
@@ -463,7 +596,38 @@ extern "C" int ff_pack_frag16(const void* split_rows, void* dst, int rows, int n
     return ff::check_launch("ff_pack_frag16");
 }
 
+namespace {
+// fp32 inputs: which convolutions this kernel takes from conv_patch.hip (3x3 stride-1 "same" layers in a split weight format
+// with Cin % 32 == 0: the encoders' residual blocks, the update block's 3x3 layers in recorded passes, their input
+// gradients), and the tile height it will use.  0 = not this kernel.
+int f32_route_th(const FFConvParams& p, int cin) {
+    static const bool enabled = !(getenv("FF_DMA_F32") && atoi(getenv("FF_DMA_F32")) == 0);
+    if (!enabled) return 0;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1 || p.pad_h != 1 || p.pad_w != 1) return 0;
+    if ((p.w_format != FF_W_F16X3 && p.w_format != FF_W_F16) || cin % 32 || p.res2 || p.splitk > 1 || p.ep_mode || p.y_fmt || p.y2) return 0;
+    long long max_bytes = (long long)(p.Cout + 15) * ((9 * cin + 31) / 32) * 128;
+    for (int i = 0; i < FF_MAX_SEG && p.x_c[i]; ++i) {
+        if (p.x_c[i] % 32 || p.x_fmt[i] != FF_FMT_F32) return 0;
+        max_bytes = std::max(max_bytes, (long long)p.B * p.H * p.W * p.x_ld[i] * 4);
+    }
+    if (max_bytes >= (1ll << 31)) return 0;
+    if (p.in_scale && (p.x_amax || !ff::aligned16(p.in_scale) || !ff::aligned16(p.in_shift))) return 0;
+    if (p.stats_part && (p.x_amax || p.Cout % 4 || !ff::aligned16(p.stats_part))) return 0;
+    const long long blocks8 = (long long)p.B * ((p.H + 7) / 8) * ((p.W + 15) / 16) * ((p.Cout + 63) / 64);
+    // small planes with long reductions keep conv_patch.hip's K splits (FF-PWC's decoders; one-pair forwards under a hipGraph)
+    if (blocks8 < 256 && p.splitk_ws) return 0;
+    return blocks8 >= 384 ? 8 : 4;
+}
+}  // namespace
+
 namespace ff {
+// entries per (image, channel) of FFConvParams.stats_part if THIS kernel runs the convolution (0: it does not)
+int conv2d_dma_stats_parts(const FFConvParams& p, int cin) {
+    const int th = f32_route_th(p, cin);
+    return th ? ((p.H + th - 1) / th) * ((p.W + 15) / 16) : 0;
+}
+
 // returns FF_OK if launched, 1 if this kernel does not take the convolution (the caller goes on to the other kernels); a
 // split-pair input that it cannot take is an error - nothing else can read it
 int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s) {
@@ -472,7 +636,21 @@ int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s) {
         any |= p.x_fmt[i] == FF_FMT_SPLIT;
         all &= p.x_fmt[i] == FF_FMT_SPLIT;
     }
-    if (!any) return 1;
+    if (!any) {
+        const int th = f32_route_th(p, cin);
+        if (!th) return 1;
+        DArgs a;
+        a.p = p;
+        a.Cin = cin;
+        a.nci = cin / 32;
+        a.nkc = 9 * a.nci;
+        a.tiles_x = (p.W + 15) / 16;
+        a.w_row_bytes = (long long)a.nkc * 128;
+        if (p.w_frag && !aligned16(p.w_frag)) return fail(FF_EINVAL, "ff_conv2d_fwd: w_frag not 16-byte aligned");
+        const bool t3 = p.w_format == FF_W_F16X3;
+        if (th == 8) return t3 ? launch_f32<8, 3>(a, s) : launch_f32<8, 1>(a, s);
+        return t3 ? launch_f32<4, 3>(a, s) : launch_f32<4, 1>(a, s);
+    }
     const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
     const bool k33 = p.KH == 3 && p.KW == 3, k15 = p.KH == 1 && p.KW == 5, k51 = p.KH == 5 && p.KW == 1;
     if (!all || p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1 || !(k33 || k15 || k51) || p.pad_h != p.KH / 2 || p.pad_w != p.KW / 2 ||
