@@ -90,6 +90,7 @@ _SIGS = {
     "ff_corr_lookup_tiled_bwd": [C.POINTER(_fp), _fp, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
     "ff_corr_pyramid_tiled_bwd": [_fp, _fp, _fp, _fp, _ll, C.c_int, C.c_int, _fp],
     "ff_act_copy": [_fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, _fp],
+    "ff_range_probe": [_fp, C.c_int, _ll, C.c_int, _fp, _fp],
     "ff_split_copy": [_fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, C.c_int, _fp],
     "ff_coords_init": [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_coords_step": [_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
@@ -173,7 +174,7 @@ def load():
     if _lib is not None:
         return _lib
     abl = [v for v in _ABLATION_VARS if os.environ.get(v) is not None]
-    if abl:
+    if abl and not os.environ.get("FF_LAB_LIB"):
         raise FocusFlowHipError(f"{', '.join(abl)} set in the environment: timing-only ablations return wrong results and are not part of "
                                 "libfocusflow_hip.so; unset them (the lab build under tools/ is where they live)")
     if not os.path.exists(LIB_PATH):

@@ -52,6 +52,9 @@ struct DArgs {
 
 __device__ __forceinline__ f16x8 lds_ld16(unsigned addr) { return *(__attribute__((address_space(3))) const f16x8*)(unsigned long)addr; }
 
+#if defined(FF_LAB) && !defined(FF_DMA_STAMPS)
+#define FF_DMA_STAMPS 1       // the lab build stamps its blocks' phases (tools/dma_stamps.py); FF_DMA_ABL=<bits> adds timing-only ablations
+#endif
 #ifndef FF_DMA_NSET
 #define FF_DMA_NSET 2      // weight register sets of the three-waves-per-SIMD instances.  3 (two taps of lead) was measured with in-kernel
 #endif                     // stamps on the 3x3 layers: main loop 44.4 vs 42.2 us (256->192), 24.5 vs 23.4 us (128->512) - slower; kept as a lab switch

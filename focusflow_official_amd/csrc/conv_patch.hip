@@ -581,7 +581,7 @@ int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
         else conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, false, true, FF_EP_GRU_BLEND><<<(unsigned)blocks, 256, lds, s>>>(a);
         return ff::check_launch("ff_conv2d_fwd(patch, GRU epilogue)");
     }
-    if (mf16 && !getenv("FF_PATCH_ABLATE")) {
+    if (mf16) {
         if (a.p.splitk > 1) {
             const int splits = (a.nci + a.nci_split - 1) / a.nci_split;
             conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, true, true><<<dim3((unsigned)blocks, splits), 256, lds, s>>>(a);
@@ -605,14 +605,16 @@ int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
         conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
         return ff::check_launch("ff_conv2d_fwd(patch)");
     }
-    // Timing-only ablations of the high-occupancy kernels (WRONG results), FF_PATCH_ABLATE = 4 no per-tap barriers,
-    // 11 no weight loads, 12 no weight loads / stores / per-tap barriers, 13 no MFMAs, 15 no LDS fragment reads,
+#ifdef FF_LAB
+    // Timing-only ablations of the high-occupancy kernels (WRONG results; lab build only), FF_PATCH_ABLATE = 4 no per-tap
+    // barriers, 11 no weight loads, 12 no weight loads / stores / per-tap barriers, 13 no MFMAs, 15 no LDS fragment reads,
     // 16 the patch is staged once per block instead of once per chunk.  Measured table: DESIGN.md section 4.
     static const int oabl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;
 #define FF_OCC_ABL(ENV_, ABL_) \
     if (oabl == ENV_) { conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, ABL_><<<(unsigned)blocks, 256, lds, s>>>(a); return ff::check_launch("ff_conv2d_fwd(patch)"); }
     FF_OCC_ABL(4, 4) FF_OCC_ABL(11, 1) FF_OCC_ABL(12, 2) FF_OCC_ABL(13, 3) FF_OCC_ABL(15, 5) FF_OCC_ABL(16, 6)
 #undef FF_OCC_ABL
+#endif
     if (!pin) {
         conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, false><<<(unsigned)blocks, 256, lds, s>>>(a);
         return ff::check_launch("ff_conv2d_fwd(patch)");
@@ -712,12 +714,14 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     const bool occ = (t3 || p.w_format == FF_W_F16) && tn == 1 && ((th == 8 && nitem <= 6 && (wb1 & 1)) || (th == 4 && nitem <= 4 && (wb1 & 2)));
     const size_t lds = ((npix * ROWP + 255) & ~255) + (occ ? 1 : 2) * 64 * tn * ROWP + lds_pad;
     if (lds > 96 * 1024) return 1;
-    static const int abl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;   // timing experiments (wrong results!)
+#ifdef FF_LAB      // timing-only ablations (WRONG results): lab build only (tools/build_lab.sh), not in libfocusflow_hip.so
+    static const int abl = getenv("FF_PATCH_ABLATE") ? atoi(getenv("FF_PATCH_ABLATE")) : 0;
     if (abl >= 1 && abl <= 3 && th == 8 && tn == 1 && nitem <= 6 && t3) {
         if (abl == 1) return launch<3, 6, 2, 1, 1>(a, lds, s);
         if (abl == 2) return launch<3, 6, 2, 1, 2>(a, lds, s);
         return launch<3, 6, 2, 1, 3>(a, lds, s);
     }
+#endif
     // split-K (FFConvParams.splitk, see conv2d_splitk_hint): the 4-row high-occupancy variant only
     if (!(occ && th == 4 && p.splitk > 1 && p.splitk_ws && !p.in_scale && !p.res2)) a.p.splitk = 0;
     a.nci_split = a.p.splitk > 1 ? (a.nci + a.p.splitk - 1) / a.p.splitk : a.nci;
@@ -752,7 +756,7 @@ int conv2d_stats_parts(const FFConvParams& p, int cin) {
     if (cin % 32) return 0;
     for (int i = 0; i < FF_MAX_SEG; ++i)
         if (p.x_c[i] % 32) return 0;
-    if (getenv("FF_PATCH_TH") || getenv("FF_PATCH_TN") || getenv("FF_PATCH_WB1") || getenv("FF_PATCH_ABLATE")) return 0;
+    if (getenv("FF_PATCH_TH") || getenv("FF_PATCH_TN") || getenv("FF_PATCH_WB1")) return 0;
     long long max_bytes = (long long)p.Cout * ((p.KH * p.KW * cin + 31) / 32) * ROWB;
     for (int i = 0; i < FF_MAX_SEG; ++i)
         if (p.x_c[i]) max_bytes = std::max(max_bytes, (long long)p.B * p.H * p.W * p.x_ld[i] * 4);

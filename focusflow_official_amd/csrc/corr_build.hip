@@ -41,6 +41,11 @@ struct BuildArgs {
                             // 8 no stores of levels 1-3, 16 no main loop (epilogue alone)
 };
 
+#ifdef FF_LAB
+#define LAB_ABL(a_) ((a_).ablate)
+#else
+#define LAB_ABL(a_) 0
+#endif
 constexpr int STAGE = 32768;     // J tile 16 KB | I tile 16 KB
 constexpr int NCHUNK = 8;        // C = 256 in chunks of 32 channels
 
@@ -114,10 +119,10 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     issue(0, 0);
-    for (int c = 0; c < ((a.ablate & 16) ? 1 : NCHUNK); ++c) {
+    for (int c = 0; c < ((LAB_ABL(a) & 16) ? 1 : NCHUNK); ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // chunk c landed for every wave; everybody is done with the other stage
-        if (c + 1 < NCHUNK && !(a.ablate & 2)) issue(c + 1, (c + 1) & 1);
+        if (c + 1 < NCHUNK && !(LAB_ABL(a) & 2)) issue(c + 1, (c + 1) & 1);
         const int bo = (c & 1) * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
         }
     }
     __syncthreads();      // operands are dead: each wave now owns 16 KB of LDS for its 32 queries
-    if (a.ablate & 1) {   // timing only: keep the accumulators alive, store nothing
+    if (LAB_ABL(a) & 1) {   // timing only: keep the accumulators alive, store nothing
         if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 12345.f) a.lvl[0][0] = 1;
         return;
     }
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
             const int p = it * 64 + lane, ql = p >> 4, slot = p & 15;      // 16 slots of 16 B per query: 2 tiles
             const f32x4 d = *reinterpret_cast<const f32x4*>(wreg + ql * 256 + ((slot ^ (ql & 7)) * 16));
             const int q = qbase + ql;
-            if (q < a.Q && !(a.ablate & 4)) {
+            if (q < a.Q && !(LAB_ABL(a) & 4)) {
                 char* dst = a.lvl[0] + (plane0 + q) * a.plane_bytes[0] + (size_t)((py * a.ntx[0] + 2 * px + (slot >> 3)) * 128 + (slot & 7) * 16);
                 *reinterpret_cast<f32x4*>(dst) = d;
             }
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
             const int p = it * 64 + lane, ql = p >> 5, slot = p & 31;      // 32 slots per query: 4 tiles
             const f32x4 d = *reinterpret_cast<const f32x4*>(wreg + ql * 512 + ((slot ^ (ql & 7)) * 16));
             const int q = qbase + ql, t = slot >> 3;
-            if (q < a.Q && !(a.ablate & 4)) {
+            if (q < a.Q && !(LAB_ABL(a) & 4)) {
                 char* dst = a.lvl[0] + (plane0 + q) * a.plane_bytes[0] +
                             (size_t)(((2 * py + (t >> 1)) * a.ntx[0] + 2 * px + (t & 1)) * 128 + (slot & 7) * 16);
                 *reinterpret_cast<f32x4*>(dst) = d;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_kernel(const BuildArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (a.ablate & 8) return;
+    if (LAB_ABL(a) & 8) return;
     if (HALF) {
         // level 1: 64 B per query = 4 pieces of 16 B (rows (4py & 7) + 0..3 of the 8 x 8 tile)
 #pragma unroll
@@ -421,8 +426,12 @@ extern "C" int ff_corr_build(const void* f1_split, const void* f2_split, void* c
     a.npy = L.npy;
     a.mtiles = (a.Q + 127) / 128;
     a.scale = 1.f / sqrtf((float)C) / (ff::WSPLIT * ff::WSPLIT);
+#ifdef FF_LAB      // timing-only ablations (WRONG results): lab build only; the product kernel compiles them out (LAB_ABL below)
     static const int ablate = getenv("FF_CORR_BUILD_ABLATE") ? atoi(getenv("FF_CORR_BUILD_ABLATE")) : 0;
     a.ablate = ablate;
+#else
+    a.ablate = 0;
+#endif
     const long long nblk = (long long)B * ((a.mtiles + 7) / 8) * ((L.npx * L.npy + 7) / 8) * 64;   // 8 x 8 super-tiles, ragged ones exit
     FF_REQUIRE(nblk < (1ll << 31), "ff_corr_build: grid too large");
     hipStream_t s = static_cast<hipStream_t>(stream);

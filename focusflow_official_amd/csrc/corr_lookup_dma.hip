@@ -433,8 +433,12 @@ int lookup_dma_fwd(const void* const* levels, int half, const float* coords, lon
     static const int env_wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 0;
     static const int env_depth = getenv("FF_LOOKUP_DEPTH") ? atoi(getenv("FF_LOOKUP_DEPTH")) : 1;      // A/B switch
     static const int env_bw = getenv("FF_LOOKUP_BLOCK_WAVES") ? atoi(getenv("FF_LOOKUP_BLOCK_WAVES")) : 1;
+#ifdef FF_LAB      // timing-only ablations (WRONG results): lab build only (tools/build_lab.sh), not in libfocusflow_hip.so
     const char* abl_s = getenv("FF_LOOKUP_ABLATE3");
     const int abl = abl_s ? atoi(abl_s) : 0;
+#else
+    constexpr int abl = 0;
+#endif
     const bool deep = env_depth == 2 && !taps_dbg && !abl;
     const int max_wpc = deep ? 11 : 16;
     const int wpc = env_wpc > 0 && env_wpc <= max_wpc ? env_wpc : max_wpc;
@@ -452,9 +456,11 @@ int lookup_dma_fwd(const void* const* levels, int half, const float* coords, lon
 #define FF_LAUNCH4(H_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, false, 0, 4, 2>), dim3(blocks), dim3(256), 4 * wave_lds(2), s, ev0, ev1, 0, a)
 #define FF_LAUNCH_DEEP(H_) hipExtLaunchKernelGGL((lookup_dma_kernel<H_, false, 0, 1, 3>), dim3(blocks), dim3(64), wave_lds(3), s, ev0, ev1, 0, a)
 #define FF_LAUNCH(H_, D_) FF_LAUNCH3(H_, D_, 0)
+#ifdef FF_LAB
 #define FF_ABL(V_) if (abl == V_ && !half && !quad) { FF_LAUNCH3(false, false, V_); return check_launch("ff_corr_lookup_tiled_fwd (dma, ablated)"); }
     FF_ABL(1) FF_ABL(4) FF_ABL(8) FF_ABL(16) FF_ABL(20) FF_ABL(28) FF_ABL(12)
 #undef FF_ABL
+#endif
     if (deep) {
         if (half) FF_LAUNCH_DEEP(true); else FF_LAUNCH_DEEP(false);
     } else if (quad) {

@@ -590,7 +590,12 @@ extern "C" int ff_corr_lookup_tiled_fwd(const void* const* levels, int half, con
     // allocates them as one buffer); FF_LOOKUP_IMPL=2 keeps the round-2 kernel below (A/B runs, read at every call)
     {
         const char* impl = getenv("FF_LOOKUP_IMPL");
-        if (!(impl && atoi(impl) == 2) && !getenv("FF_LOOKUP_ABLATE")) {
+#ifdef FF_LAB
+        const bool lab_old = getenv("FF_LOOKUP_ABLATE") != nullptr;      // the round-2 kernel's ablations: lab build only
+#else
+        constexpr bool lab_old = false;
+#endif
+        if (!(impl && atoi(impl) == 2) && !lab_old) {
             const int r = ff::lookup_dma_fwd(levels, half, coords, queries, h0, w0, out, out_ld, taps_dbg, static_cast<hipStream_t>(stream));
             if (r != 1) return r;
         }
@@ -600,16 +605,18 @@ extern "C" int ff_corr_lookup_tiled_fwd(const void* const* levels, int half, con
     a.taps = taps_dbg;
     a.queries = queries;
     a.out_ld = out_ld;
-    static const int abl = getenv("FF_LOOKUP_ABLATE") ? atoi(getenv("FF_LOOKUP_ABLATE")) : 0;
     // one wave per block, 10.1 KB of LDS each: 16 blocks fit a CU
     static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 16;
     const long long blocks = queries < 256ll * wpc ? queries : 256ll * wpc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+#ifdef FF_LAB      // timing-only ablations (WRONG results): lab build only
+    static const int abl = getenv("FF_LOOKUP_ABLATE") ? atoi(getenv("FF_LOOKUP_ABLATE")) : 0;
 #define FF_LK_ABL(V_) if (abl == V_) { if (half) lookup_tiled_kernel<true, V_><<<(unsigned)blocks, 64, 0, s>>>(a); \
                                        else lookup_tiled_kernel<false, V_><<<(unsigned)blocks, 64, 0, s>>>(a); \
                                        return ff::check_launch("ff_corr_lookup_tiled_fwd"); }
     FF_LK_ABL(1) FF_LK_ABL(3) FF_LK_ABL(7) FF_LK_ABL(11) FF_LK_ABL(19) FF_LK_ABL(31)
 #undef FF_LK_ABL
+#endif
     if (half) lookup_tiled_kernel<true><<<(unsigned)blocks, 64, 0, s>>>(a);
     else lookup_tiled_kernel<false><<<(unsigned)blocks, 64, 0, s>>>(a);
     return ff::check_launch("ff_corr_lookup_tiled_fwd");

@@ -1,6 +1,7 @@
 // Small HBM-bound kernels around the update block: input scaling, coordinate
 // bookkeeping, GRU gate arithmetic and the convex upsampler.
 #pragma clang fp contract(off)
+#include <algorithm>
 #include "ff_common.h"
 
 namespace {
@@ -65,6 +66,35 @@ __global__ void split_copy_kernel(const float* __restrict__ src, int src_ld, flo
             for (int j = 0; j < 4; ++j) v[j] = ((float)h0[j] + (float)h1[j]) * 0.25f;
             *reinterpret_cast<f32x4*>(dst + p * dst_ld + n4) = v;
         }
+    }
+}
+
+// max|x| of an NHWC tensor as float bits into *word (atomicMax; non-negative floats order like their bit patterns); a NaN
+// or an infinity anywhere leaves +inf there.  <= 512 blocks, one atomic each.
+__global__ void range_probe_kernel(const float* __restrict__ x, int ld, long long npix, int C, unsigned int* __restrict__ word) {
+    const int cg = C >> 2;
+    const long long total = npix * cg;
+    float mx = 0.f;
+    bool bad = false;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / cg;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * ld + (i - p * cg) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = fabsf(v[j]);
+            bad |= !(a <= 3.402823466e38f);        // inf or NaN (fmaxf would drop a NaN)
+            mx = fmaxf(mx, a);
+        }
+    }
+    if (bad) mx = INFINITY;
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (mx > 0.f && __float_as_uint(mx) > *reinterpret_cast<volatile unsigned int*>(word)) atomicMax(word, __float_as_uint(mx));
     }
 }
 
@@ -301,6 +331,13 @@ extern "C" int ff_split_copy(const float* src, int src_ld, float* dst, int dst_l
     FF_REQUIRE(to_split || act == FF_ACT_NONE, "ff_split_copy: no activation on the way back");
     split_copy_kernel<<<grid_for(npix * (C / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(src, src_ld, dst, dst_ld, npix, C, act, to_split);
     return ff::check_launch("ff_split_copy");
+}
+
+extern "C" int ff_range_probe(const float* x, int ld, long long npix, int C, unsigned int* word, void* stream) {
+    FF_REQUIRE(x && word && npix > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C && ff::aligned16(x), "ff_range_probe: bad argument");
+    const long long groups = npix * (C / 4);
+    range_probe_kernel<<<(unsigned)std::min<long long>((groups + 1023) / 1024, 512), 256, 0, static_cast<hipStream_t>(stream)>>>(x, ld, npix, C, word);
+    return ff::check_launch("ff_range_probe");
 }
 
 extern "C" int ff_coords_init(float* coords, const float* flow_init, int B, int H, int W, void* stream) {

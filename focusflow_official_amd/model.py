@@ -116,9 +116,17 @@ class FF_RAFT_FUSION(nn.Module):
                 self._table = tab.to(image1.device)
             m1 = ops.mask_prepare(MASK_MODES[modal], mask1, image1, self._table)
             m2 = i2 if modal == "context" else ops.prep_input(None, b, h, w, image1, fill=255.0)
+        ops.guard_begin(image1.device)       # (raises if an EARLIER forward left the split formats' range: ops.guard_check)
         out = self.flow_net(i1, i2, m1, m2, iters=raft_iters, flow_init=flow_init, test_mode=test_mode)
+        ops.guard_end("FF_RAFT_FUSION.forward")
         ops.check_range("FF_RAFT_FUSION.forward")      # debug mode FF_CHECK_RANGE=1 only (one host sync)
         return out
+
+    def check_range(self):
+        """The always-on range guard (ops.guard_*), now: waits for the forwards issued so far and raises FocusFlowHipError if
+        one of them pushed an encoder output beyond the fp16-split formats' range (|x| >= 16376).  Without this call the
+        same error is raised by the next forward."""
+        ops.guard_check(sync=True)
 
     def freeze_self(self):
         if self.use_fusion == "parallel":

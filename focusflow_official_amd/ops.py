@@ -546,6 +546,65 @@ def check_range(what: str = "forward pass"):
             "(ff_common.h).  Run this checkpoint / input with FF_CONV_PRECISION=fp32.")
 
 
+# ---- the always-on guard ---------------------------------------------------------------------------------------------------
+# Two tensors per forward decide whether a checkpoint / input stays inside the split formats' range: the context encoder's
+# output (no norm behind its last convolution: |x| ~ 700 on the synthetic test weights) and the feature maps the correlation
+# volume is built from.  Their max|x| is measured in every forward (two read-only passes,
+# ff_range_probe: ~15 us), copied to pinned host memory without a synchronisation, and looked at when the NEXT
+# forward starts - or on demand (FF_RAFT_FUSION.check_range(): one host sync): an overflow raises FocusFlowHipError instead
+# of travelling on as inf / NaN flow.  FF_RANGE_GUARD=0 switches it off.
+RANGE_GUARD = os.environ.get("FF_RANGE_GUARD", "1") != "0"
+_guard_word = None          # device word of the running forward
+_guard_pending = []         # [(pinned host word, event, what)] of finished forwards, not looked at yet
+
+
+def guard_begin(device):
+    global _guard_word
+    _guard_word = None
+    if torch.cuda.is_current_stream_capturing():      # (no event queries, host copies or fresh words inside a hipGraph capture)
+        return
+    guard_check()
+    if RANGE_GUARD:
+        _guard_word = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def guard_probe(x: Tensor):
+    """max|x| of an NHWC tensor into the running forward's guard word (no copy, no sync)."""
+    if _guard_word is None:
+        return
+    b, h, w, c = x.shape
+    _hip.call("ff_range_probe", _p(x), _ld(x), b * h * w, c, _p(_guard_word), _stream())
+
+
+def guard_end(what: str):
+    global _guard_word
+    if _guard_word is None:
+        return
+    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    host.copy_(_guard_word, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _guard_pending.append((host, ev, what))
+    _guard_word = None
+
+
+def guard_check(sync: bool = False):
+    """Look at the guard words of finished forwards (all of them if sync, else those whose copy has arrived)."""
+    while _guard_pending:
+        host, ev, what = _guard_pending[0]
+        if not ev.query():
+            if not sync:
+                return
+            ev.synchronize()
+        _guard_pending.pop(0)
+        m = float(host.view(torch.float32).item())
+        if not (m < X_LIMIT):
+            _guard_pending.clear()
+            raise _hip.FocusFlowHipError(
+                f"{what}: an encoder output reached |x| = {m:.6g}; the fp16-split conv formats need |x| < {X_LIMIT:g} "
+                "(csrc/ff_common.h) - the flow of that pass is not valid.  Run this checkpoint / input with FF_CONV_PRECISION=fp32.")
+
+
 def _zero_stats(s, c, device):
     global _stats_used
     n = s * c * 2

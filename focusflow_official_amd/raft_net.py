@@ -117,6 +117,8 @@ class RAFT(nn.Module):
             cnet.record_stream(main)
         else:
             cnet = self.cnet(image1, mask1)
+        ops.guard_probe(cnet)           # the always-on range guard: the two encoder outputs (ops.guard_begin)
+        ops.guard_probe(f12)
         taped = fn.recording(cnet)
         if taped:
             net = fn.ActFn.apply(cnet[..., :128], ACT_TANH)

@@ -309,6 +309,11 @@ int ff_act_copy(const float* src, int src_ld, float* dst, int dst_ld, long long 
  * way (the hidden state's tanh, raft.py:208).  C % 32 == 0, 16-byte aligned pointers, lds % 4 == 0.  to_split = 0 converts
  * back, v = (x0 + x1) / 4 (22 significant bits; act must be FF_ACT_NONE) - tests and debugging. */
 int ff_split_copy(const float* src, int src_ld, float* dst, int dst_ld, long long npix, int C, int act, int to_split, void* stream);
+/* The always-on range guard of the drop-in module: max|x| of an NHWC tensor (C % 4 == 0) as float bits into *word by
+ * atomicMax (the caller zeroes the word; several probes may share it); a NaN or an infinity leaves +inf.  The fp16-split
+ * conv formats need |x| < 16376 at every convolution input - the module probes its two encoder outputs once per forward
+ * and raises instead of returning inf / NaN flow. */
+int ff_range_probe(const float* x, int ld, long long npix, int C, unsigned int* word, void* stream);
 /* coords_grid (utils.py:74-77): coords[b][y][x] = (x, y) (+ flow_init NHWC2 if given) */
 int ff_coords_init(float* coords, const float* flow_init_nchw, int B, int H, int W, void* stream);
 /* coords1 += delta (if delta) ; flow = coords1 - coords0 written to

@@ -183,3 +183,21 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("test oracle", ""), f"{f} mentions the oracle"
+
+
+def test_the_product_library_carries_no_timing_only_ablations(lib_path):
+    """the ablation instances (results WRONG by design) and their getenv()s live behind -DFF_LAB in
+    the lab build (tools/build_lab.sh); libfocusflow_hip.so contains none of their switches, the loader refuses to come up
+    while one is set in the environment, and bench.py refuses every lab / tuning switch."""
+    import subprocess
+    import sys
+    blob = open(lib_path, "rb").read()
+    for name in (b"FF_PATCH_ABLATE", b"FF_LOOKUP_ABLATE", b"FF_CORR_BUILD_ABLATE", b"FF_WS_ABLATE", b"FF_DMA_ABL"):
+        assert name not in blob, f"{name.decode()} found in the product library"
+    env = dict(os.environ, FF_LOOKUP_ABLATE3="4")
+    env.pop("FF_LAB_LIB", None)
+    r = subprocess.run([sys.executable, "-c", "from focusflow_official_amd import _hip; _hip.load()"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "FF_LOOKUP_ABLATE3" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], cwd=ROOT, env=dict(os.environ, FF_DMA_TILE="4"),
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "FF_DMA_TILE" in (r.stderr + r.stdout)

@@ -557,8 +557,24 @@ def test_check_range_debug_mode_reports_activations_beyond_the_split_format(det_
                 m(*inp, raft_iters=2, test_mode=True)
     finally:
         hops.CHECK_RANGE = False
+    # The always-on guard (ops.guard_*: max|x| of the two encoder outputs, every forward, no synchronisation) saw the same
+    # pass: it raises on demand or when the next forward starts - never silently returns the inf / NaN flow.
+    with pytest.raises(_hip.FocusFlowHipError, match="16376"):
+        m.check_range()
     with torch.no_grad():
-        m(*inp, raft_iters=2, test_mode=True)                          # check off: nothing is measured, nothing raised
+        m(*inp, raft_iters=2, test_mode=True)                          # debug check off: this call itself returns ...
+        with pytest.raises(_hip.FocusFlowHipError, match="16376"):
+            torch.cuda.synchronize()
+            m(*inp, raft_iters=2, test_mode=True)                      # ... and the next one reports it
+    hops._guard_pending.clear()
+    monkey_guard = hops.RANGE_GUARD
+    hops.RANGE_GUARD = False
+    try:
+        with torch.no_grad():
+            m(*inp, raft_iters=2, test_mode=True)                      # guard off: nothing is measured, nothing raised
+        m.check_range()
+    finally:
+        hops.RANGE_GUARD = monkey_guard
 
 
 def test_gru_steps_in_the_conv_epilogues_are_bit_identical(det_sd, monkeypatch):
