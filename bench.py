@@ -99,12 +99,14 @@ def host_issue_time(step, n=5):
 
 
 def pmc_traffic(queries, pyramid):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r03_lookup_traffic[_fp16].json:
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r04_lookup_traffic.json, r03_lookup_traffic_fp16.json:
     TCC_EA0_RDREQ x 128 B + WRITE_SIZE), scaled per query, and where the number comes from; (None, reason) if the
     profile is absent.  PMC passes cannot run inside the timed process: the fp32 profile holds the lookup launches of this
     very command under rocprofv3 --pmc (tools/prof_pmc.sh ... bench.py), the fp16 one the same kernel on the same shape in
     tools/lookup_lab.cpp (tools/prof_pmc_bin.sh) - NOT a counter read in this run."""
-    name = "r03_lookup_traffic.json" if pyramid == "fp32" else "r03_lookup_traffic_fp16.json"
+    name = "r04_lookup_traffic.json" if pyramid == "fp32" else "r03_lookup_traffic_fp16.json"      # (the fp16 instance of the kernel is unchanged since round 3)
+    if not os.path.exists(os.path.join(ROOT, "profiles", name)):
+        name = name.replace("r04_", "r03_")
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)

@@ -101,12 +101,16 @@ class FF_RAFT_FUSION(nn.Module):
             raise ValueError("H and W must be multiples of 8 (pad with InputPadder as the reference's callers do)")
         # ff_raft.py:31-38 + :142-145 fused into one NCHW->NHWC4 pass per input;
         # 'point' mode ignores the caller's mask2 and uses a constant 255 plane.
-        i1 = ops.prep_input(image1, b, h, w, image1)
-        i2 = ops.prep_input(image2, b, h, w, image1)
+        # (both frames - and both masks - into the halves of one buffer: the feature encoder takes them as one batch of 2B
+        # without a torch.cat, ops.cat_batch)
+        i12 = ops.empty_nhwc(2 * b, h, w, 4, image1)
+        i1 = ops.prep_input(image1, b, h, w, image1, out=i12[:b])
+        i2 = ops.prep_input(image2, b, h, w, image1, out=i12[b:])
         modal = self.mask_modal
         if modal == "point":
-            m1 = ops.prep_input(mask1, b, h, w, image1)
-            m2 = ops.prep_input(None, b, h, w, image1, fill=255.0)
+            m12 = ops.empty_nhwc(2 * b, h, w, 4, image1)
+            m1 = ops.prep_input(mask1, b, h, w, image1, out=m12[:b])
+            m2 = ops.prep_input(None, b, h, w, image1, fill=255.0, out=m12[b:])
         elif modal == "frame":                      # ff_raft.py:68-70: the masks are the frames themselves
             m1, m2 = i1, i2
         else:                                       # ff_raft.py:24-30, 40-66

@@ -665,8 +665,9 @@ def bn_update_running(bn: torch.nn.BatchNorm2d, stats: Tensor, count: int):
 
 
 # ----------------------------------------------------------------------------
-def prep_input(src_nchw: Optional[Tensor], b, h, w, like: Tensor, fill: float = 0.0) -> Tensor:
-    dst = empty_nhwc(b, h, w, 4, like)
+def prep_input(src_nchw: Optional[Tensor], b, h, w, like: Tensor, fill: float = 0.0, out: Optional[Tensor] = None) -> Tensor:
+    dst = empty_nhwc(b, h, w, 4, like) if out is None else out
+    assert dst.shape == (b, h, w, 4) and dst.is_contiguous()
     if src_nchw is not None:
         _require_gpu(src_nchw)
         src_nchw = src_nchw.contiguous()
@@ -674,6 +675,15 @@ def prep_input(src_nchw: Optional[Tensor], b, h, w, like: Tensor, fill: float = 
     _hip.call("ff_prep_input", _p(src_nchw), src_nchw.shape[1] if src_nchw is not None else 0, fill, _p(dst), b, h, w,
               _stream())
     return dst
+
+
+def cat_batch(a: Tensor, b: Tensor) -> Tensor:
+    """torch.cat([a, b], 0) - without the copy when b lies right behind a in one buffer (the model prepares both frames of a
+    pair into the two halves of one tensor, so that the feature encoder sees them as ONE batch of 2B, raft.py:187-189)."""
+    if (a.is_contiguous() and b.is_contiguous() and a.shape[1:] == b.shape[1:] and a.dtype == b.dtype
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and b.storage_offset() == a.storage_offset() + a.numel()):
+        return torch.as_strided(a, (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+    return torch.cat([a, b], 0)
 
 
 def mask_prepare(mode: int, mask_nchw: Tensor, image: Tensor, table: Tensor, raw: bool = False, image_nhwc4: bool = False) -> Tensor:

@@ -108,7 +108,7 @@ class RAFT(nn.Module):
                 join.record(self._enc_stream)
             for t in (image1, mask1):
                 t.record_stream(self._enc_stream)
-        f12 = self.fnet(torch.cat([image1, image2], 0), torch.cat([mask1, mask2], 0))
+        f12 = self.fnet(ops.cat_batch(image1, image2), ops.cat_batch(mask1, mask2))
         fmap1, fmap2 = f12[:b], f12[b:]
         self.fmap = fmap1
         corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
