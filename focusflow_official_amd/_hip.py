@@ -94,6 +94,8 @@ _SIGS = {
     "ff_split_copy": [_fp, C.c_int, _fp, C.c_int, _ll, C.c_int, C.c_int, C.c_int, _fp],
     "ff_coords_init": [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
     "ff_coords_step": [_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_gru_pass": [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                    C.c_int, C.c_int, C.c_int, _fp],
     "ff_gru_rh": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
     "ff_gru_blend": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
     "ff_upsample_flow": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp],

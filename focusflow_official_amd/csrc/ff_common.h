@@ -116,8 +116,13 @@ __device__ __forceinline__ float fast_tanh(float v) {
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case FF_ACT_RELU: return v > 0.f ? v : 0.f;
+#ifdef FF_EXACT_ACT      // lab build: libm's expf / tanhf and an IEEE division (what the fast forms were measured against)
+        case FF_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case FF_ACT_TANH: return tanhf(v);
+#else
         case FF_ACT_SIGMOID: return fast_sigmoid(v);
         case FF_ACT_TANH: return fast_tanh(v);
+#endif
         case FF_ACT_LEAKY: return v > 0.f ? v : 0.1f * v;
         default: return v;
     }

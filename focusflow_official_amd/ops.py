@@ -815,6 +815,17 @@ def gru_blend(z: Tensor, q: Tensor, h: Tensor, out: Optional[Tensor] = None) -> 
     return out
 
 
+def gru_pass(direction: int, hs, motion, h: Tensor, zr_pre: Tensor, q_pre: Tensor, wzr_frag: Tensor, wq_frag: Tensor, bzr: Tensor, bq: Tensor,
+             w_fmt: int):
+    """One SepConvGRU pass as one launch (ff_gru_pass): hs / motion SplitT, h fp32 -> (h' fp32, h' SplitT)."""
+    b, hh, ww, c = h.shape
+    assert c == 128 and hs.shape == h.shape and motion.shape == h.shape and zr_pre.shape == (b, hh, ww, 256) and q_pre.shape == h.shape
+    y, y2 = empty_nhwc(b, hh, ww, c, h), empty_nhwc(b, hh, ww, c, h)
+    _hip.call("ff_gru_pass", direction, _p(hs.t), _ld(hs.t), _p(motion.t), _ld(motion.t), _p(h), _ld(h), _p(zr_pre), _ld(zr_pre), _p(q_pre), _ld(q_pre),
+              _p(wzr_frag), _p(wq_frag), _p(bzr), _p(bq), w_fmt, _p(y), _ld(y), _p(y2), _ld(y2), b, hh, ww, _stream())
+    return y, SplitT(y2)
+
+
 def mask_upsample_pack(w_split: Tensor) -> Tensor:
     """Split rows of the mask head's second convolution (576 x 256) -> ff_mask_upsample_fwd's stage-major weight image."""
     assert w_split.dtype == torch.uint8 and w_split.numel() == 576 * 1024 and w_split.is_contiguous()

@@ -23,6 +23,7 @@ _GRU_EPILOGUE = os.environ.get("FF_GRU_EPILOGUE", "1") != "0"    # r*h and the s
 # producers' epilogues write what the consumers' loaders would have made of fp32, the consumers take their patches by LDS-DMA
 # (csrc/conv_dma.hip).  Same bits as the fp32 route.  FF_SPLIT_ACT=0: A/B switch back to fp32 tensors and conv_patch.hip.
 _SPLIT_ACT = os.environ.get("FF_SPLIT_ACT", "1") != "0"
+_GRU_PASS = os.environ.get("FF_GRU_PASS", "1") != "0"       # A/B switch: a SepConvGRU pass as one launch (z|r conv, r * h, q conv, blend)
 
 
 def split_activations() -> bool:
@@ -80,6 +81,12 @@ class SepConvGRU(nn.Module):
         (the convolutions read it), motion SplitT, pre = prepare(inp).  -> (h, hs).  update.py:45-60; the same sequence
         of operations as run()'s fused branch - bit-identical states."""
         c = self.hidden_dim
+        if _GRU_PASS:
+            # each pass as ONE launch (csrc/gru_pass.hip): r * h and z never leave the CU
+            for d, (zr_conv, q_conv, (zr_pre, q_pre)) in enumerate(zip(self._zr_hm, self._q_hm, pre)):
+                (_, bzr), (_, bq) = zr_conv.get(), q_conv.get()
+                h, hs = ops.gru_pass(d, hs, motion, h, zr_pre, q_pre, zr_conv.frag(), q_conv.frag(), bzr, bq, zr_conv.fmt)
+            return h, hs
         for zr_conv, q_conv, (zr_pre, q_pre) in zip(self._zr_hm, self._q_hm, pre):
             # [z | r * h]: z stays fp32 (the blend reads it), r * h leaves in the split-pair format (only the q convolution reads it)
             zr = zr_conv([hs, motion], res=zr_pre, act_res=ACT_SIGMOID, ep_rh=h, ep_split=c, y_split=c)

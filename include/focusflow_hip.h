@@ -321,6 +321,18 @@ int ff_coords_init(float* coords, const float* flow_init_nchw, int B, int H, int
  * slot `slot` ([npix][slot_ld], 2 floats) if non-null.   raft.py:219,223 */
 int ff_coords_step(float* coords1, const float* delta, int delta_ld, float* flow4,
                    float* slot, int slot_ld, int B, int H, int W, void* stream);
+/* One pass of SepConvGRU (update.py:45-60) as one launch, inference on split-pair activations (FF_FMT_SPLIT):
+ *   z | r = sigmoid(conv_zr([h, motion]) + zr_pre) ; q = tanh(conv_q([r * h, motion]) + q_pre) ; h' = (1 - z) h + z q
+ * dir 0 = the (1,5) convolutions of pass 1, dir 1 = the (5,1) convolutions of pass 2.  hs / motion: split-pair, 128 channels;
+ * h: the same state in fp32; zr_pre [..][256] / q_pre [..][128]: the loop-invariant context share of the gates (fp32, no
+ * bias); wzr_frag / wq_frag: the packed [Cout][5 taps][256] weights of the two convolutions over [h, motion] in fragment
+ * order (ff_pack_frag16); bzr [256], bq [128]; w_format FF_W_F16X3 / FF_W_F16.  Writes the new state twice: y fp32, y2
+ * split-pair.  r * h and z never leave the CU.  Bit-identical to the two ff_conv2d_fwd launches with FF_EP_GRU_RH /
+ * FF_EP_GRU_BLEND that it replaces. */
+int ff_gru_pass(int dir, const float* hs, int hs_ld, const float* motion, int mo_ld, const float* h, int h_ld,
+                const float* zr_pre, int zr_pre_ld, const float* q_pre, int q_pre_ld, const void* wzr_frag, const void* wq_frag,
+                const float* bzr, const float* bq, int w_format, float* y, int y_ld, float* y2, int y2_ld, int B, int H, int W,
+                void* stream);
 /* GRU gates (update.py:47-49): rh = r*h ; h' = (1-z)*h + z*q */
 int ff_gru_rh(const float* r, int r_ld, const float* h, int h_ld, float* rh, int rh_ld,
               long long npix, int C, void* stream);

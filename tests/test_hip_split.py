@@ -173,6 +173,45 @@ def test_dma_conv_gru_epilogues_are_bit_identical_to_the_fp32_route(ops, shape):
         close(nchw(h_new), (1 - z) * hst.double() + z * q, rtol=2e-5, what="GRU pass vs fp64")
 
 
+@pytest.mark.parametrize("th", [0, 6, 4])
+@pytest.mark.parametrize("shape", [(2, 18, 32), (1, 21, 30), (1, 7, 50), (8, 48, 64)])
+def test_gru_pass_as_one_launch_is_bit_identical_to_the_two_convolutions(ops, shape, th, monkeypatch):
+    """csrc/gru_pass.hip: a SepConvGRU pass (z|r convolution, r * h, q convolution, blend) as ONE launch against the two
+    conv_dma.hip launches with the GRU epilogues - same arithmetic in the same order, so torch.equal on the new state (fp32
+    and split-pair), both tap directions, planes that are ragged against the 6 x 16 / 4 x 16 tiles, and fp64 of the definition."""
+    b, h, w = shape
+    if th:
+        monkeypatch.setenv("FF_GRU_PASS_TH", str(th))
+    else:
+        monkeypatch.delenv("FF_GRU_PASS_TH", raising=False)
+    g = torch.Generator().manual_seed(b * 11 + h + w)
+    c = 128
+    hst, mot = torch.randn(b, c, h, w, generator=g), torch.randn(b, c, h, w, generator=g)
+    pre_zr, pre_q = torch.randn(b, 2 * c, h, w, generator=g), torch.randn(b, c, h, w, generator=g)
+    hp, mp = _views([hst, mot])
+    hs, ms = ops.split_copy(hp), ops.split_copy(mp)
+    for d, (kh, kw) in enumerate(((1, 5), (5, 1))):
+        wzr = torch.randn(2 * c, 2 * c, kh, kw, generator=g) / (2 * c * 5) ** 0.5
+        wq = torch.randn(c, 2 * c, kh, kw, generator=g) / (2 * c * 5) ** 0.5
+        bzr, bq = torch.randn(2 * c, generator=g).to(DEV), torch.randn(c, generator=g).to(DEV)
+        pzr, pq = _pack(ops, wzr, 2 * c), _pack(ops, wq, 2 * c)
+        fzr, fq = ops.pack_frag16(pzr, 2 * c), ops.pack_frag16(pq, c)
+        pad = (kh // 2, kw // 2)
+        przr, prq = nhwc(pre_zr), nhwc(pre_q)
+        zr = ops.conv2d([hs, ms], pzr, bzr, 2 * c, kh, kw, 1, pad, res=przr, act_res=2, w_fmt=1, ep_rh=hp, ep_split=c, y_split=c, w_frag=fzr)
+        h2, h2s = ops.conv2d([ops.SplitT(zr[..., c:]), ms], pq, bq, c, kh, kw, 1, pad, res=prq, act_res=3, w_fmt=1, ep_blend=(zr[..., :c], hp),
+                             y2_split=True, w_frag=fq)
+        h1, h1s = ops.gru_pass(d, hs, ms, hp, przr, prq, fzr, fq, bzr, bq, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(h1, h2), f"new state, pass {d + 1}"
+        assert torch.equal(h1s.t.view(torch.int32), h2s.t.view(torch.int32)), f"new state as a split pair, pass {d + 1}"
+        x = torch.cat([hst, mot], 1).double()
+        zrd = torch.sigmoid(F.conv2d(x, wzr.double(), bzr.cpu().double(), padding=pad) + pre_zr.double())
+        z, r = zrd[:, :c], zrd[:, c:]
+        q = torch.tanh(F.conv2d(torch.cat([r * hst.double(), mot.double()], 1), wq.double(), bq.cpu().double(), padding=pad) + pre_q.double())
+        close(nchw(h1), (1 - z) * hst.double() + z * q, rtol=2e-5, what=f"GRU pass {d + 1} vs fp64")
+
+
 def test_motion_tail_and_split_outputs_of_the_fp32_input_kernels(ops):
     """FF_EP_MOTION_TAIL (the motion encoder's last convolution writes torch.cat([out, flow])'s flow channels itself) and
     the split-pair epilogue of the im2col kernel (convc1 1x1 over the lookup's fp32 output, convf1 7x7 over the flow)."""
