@@ -77,9 +77,13 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // UG: pixel rows whose epilogue operands are loaded together
 // (An fp32-input mode of this kernel - patch staged through registers - for the encoders' 3x3 layers was built and measured:
 // 2.5 % slower end to end than conv_patch.hip at four blocks per CU; tools/proto/conv_dma_f32_inputs.hip.)
-template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int UG, int NSET>
+// NW: waves per block = 16 NV NW output channels per block.  4 in the general instances; Cout / (16 NV) in the "all channels"
+// instances: ONE block per 6 x 16 pixel tile computes every output channel (a patch is DMA'd once per tile instead of once
+// per 64 channels; 8 x 8 x 4 = 256 blocks at the headline shape = one per CU, evenly - the 64-channel blocks of a 192- or
+// 126-channel layer are 576 / 384 blocks on 768 slots, and the CUs that hold three of them set the kernel's time).
+template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int UG, int NSET, int NW>
 __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
-    constexpr int PW = 16 + KW - 1, PH = TH + KH - 1, NPIX = PH * PW, NPIECE = (NPIX + 7) / 8, NPP = (NPIECE + 3) / 4;
+    constexpr int PW = 16 + KW - 1, PH = TH + KH - 1, NPIX = PH * PW, NPIECE = (NPIX + 7) / 8, NPP = (NPIECE + NW - 1) / NW;
     constexpr int PBYTES = NPIECE * 1024, NT = KH * KW, NWL = NV * (TERMS == 3 ? 2 : 1);
     static_assert(PW % 2 == 0, "the bank argument needs an even patch width");
     extern __shared__ __attribute__((aligned(16))) char smem[];          // two patch buffers
@@ -99,18 +103,18 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int bimg = bid / a.tiles_y;
-    const int y0 = ty * TH, x0 = tx * 16, n0 = nt * (64 * NV) + wave * (16 * NV);    // n0: this WAVE's first output channel
+    const int y0 = ty * TH, x0 = tx * 16, n0 = nt * (16 * NV * NW) + wave * (16 * NV);    // n0: this WAVE's first output channel
 
     const long long pix_total = (long long)p.B * H * W;
     const int c0 = p.x_c[0], c01 = p.x_c[0] + p.x_c[1];
 
-    // ---- DMA roles: piece pc = wave + 4 j covers LDS rows 8 pc .. 8 pc + 7; lane -> row (lane >> 3), slot (lane & 7)
+    // ---- DMA roles: piece pc = wave + NW j covers LDS rows 8 pc .. 8 pc + 7; lane -> row (lane >> 3), slot (lane & 7)
     // per piece one word: (image pixel << 7) | byte offset of the source slot inside the pixel's 128-byte chunk, or -1
     // (outside the image / past the patch: zeros)
     int ppix[NPP];
 #pragma unroll
     for (int j = 0; j < NPP; ++j) {
-        const int r = (wave + 4 * j) * 8 + (lane >> 3);
+        const int r = (wave + NW * j) * 8 + (lane >> 3);
         const int py = r / PW, px = r - py * PW;
         const int yy = y0 - p.pad_h + py, xx = x0 - p.pad_w + px;
         const bool in = r < NPIX && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
@@ -131,9 +135,9 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(xpu), 0, __builtin_amdgcn_readfirstlane((int)(pix_total * ldb)), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NPP; ++j) {
-            if ((wave + 4 * j) < NPIECE) {       // wave-uniform
+            if ((wave + NW * j) < NPIECE) {       // wave-uniform
                 const unsigned voff = ppix[j] >= 0 ? __umul24((unsigned)(ppix[j] >> 7), (unsigned)ldb) + (unsigned)(ppix[j] & 127) : OOB;
-                dma_piece(voff, rs, lds0 + buf * PBYTES + (wave + 4 * j) * 1024, soff);
+                dma_piece(voff, rs, lds0 + buf * PBYTES + (wave + NW * j) * 1024, soff);
             }
         }
     };
@@ -405,11 +409,11 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
 #endif
 }
 
-template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_dma_kernel(const DArgs a) {
-    // all TH rows at once where the registers allow: one channel tile per wave (32 accumulator registers) at three waves per SIMD
-    // three weight register sets where three waves per SIMD leave the registers for them
-    conv_dma_body<KH, KW, TH, NV, TERMS, EPI, (NV == 1 && OCC <= 3) ? TH : (TH < 4 ? TH : 4), (OCC <= 3 && NV == 1) ? FF_DMA_NSET : 2>(a);
+template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int OCC, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_dma_kernel(const DArgs a) {
+    // epilogue operands of all TH rows at once where the registers allow (one channel tile per wave at three waves per SIMD),
+    // else in groups of 4 (or 3: the 6-row tiles)
+    conv_dma_body<KH, KW, TH, NV, TERMS, EPI, (NV == 1 && OCC <= 3) ? TH : (TH < 4 ? TH : (TH % 4 == 0 ? 4 : 3)), (OCC <= 3 && NV == 1) ? FF_DMA_NSET : 2, NW>(a);
 }
 
 template <int KH, int KW, int TH, int NV, int TERMS, int OCC>
@@ -425,6 +429,19 @@ int launch_ep(const DArgs& a, hipStream_t s) {
         default: return ff::fail(FF_EINVAL, "ff_conv2d_fwd(dma): ep_mode %d", a.p.ep_mode);
     }
     return ff::check_launch("ff_conv2d_fwd(dma)");
+}
+
+// "all channels" instances (3x3, 6-row tiles): NW waves x NV channel tiles = every output channel in one block
+template <int NV, int NW, int TERMS, int OCC>
+int launch_allch(DArgs& a, hipStream_t s) {
+    constexpr size_t lds = 2 * ((8 * 18 + 7) / 8) * 1024;
+    a.tiles_y = (a.p.H + 5) / 6;
+    a.n_tiles = (a.p.Cout + (a.p.ep_mode == FF_EP_MOTION_TAIL ? 2 : 0) + 16 * NV * NW - 1) / (16 * NV * NW);
+    const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    if (a.p.ep_mode == FF_EP_NONE) conv_dma_kernel<3, 3, 6, NV, TERMS, FF_EP_NONE, OCC, NW><<<(unsigned)blocks, 64 * NW, lds, s>>>(a);
+    else if (a.p.ep_mode == FF_EP_MOTION_TAIL) conv_dma_kernel<3, 3, 6, NV, TERMS, FF_EP_MOTION_TAIL, OCC, NW><<<(unsigned)blocks, 64 * NW, lds, s>>>(a);
+    else return ff::fail(FF_EINVAL, "ff_conv2d_fwd(dma, all channels): ep_mode %d", a.p.ep_mode);
+    return ff::check_launch("ff_conv2d_fwd(dma, all channels)");
 }
 
 template <int KH, int KW, int TERMS>
@@ -516,6 +533,20 @@ int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s) {
         if (th != 4 && th != 8) return fail(FF_EINVAL, "FF_DMA_TILE: 4 or 8 (pixel rows per block)");
     }
     const bool t3 = p.w_format == FF_W_F16X3;
+    // "All channels" layout (launch_allch): where 6 x 16 tiles give about one block per CU - the update block's 3x3 layers at
+    // 8 pairs: 256 blocks.  More tiles than CUs would run as rounds of one block per CU with nothing to overlap the prologue and
+    // epilogue phases: the 64-channel blocks (three per CU, out of phase) are better there.  FF_DMA_ALLCH=0: A/B switch.
+    static const bool allch_on = !(getenv("FF_DMA_ALLCH") && atoi(getenv("FF_DMA_ALLCH")) == 0);
+    const long long tiles6 = (long long)p.B * ((p.H + 5) / 6) * a.tiles_x;
+    if (allch_on && k33 && !getenv("FF_DMA_TILE") && tiles6 >= 192 && tiles6 <= 272 && (p.ep_mode == FF_EP_NONE || p.ep_mode == FF_EP_MOTION_TAIL)) {
+        const int ct = (couts + 15) / 16;          // 16-channel tiles
+        if (ct > 8 && ct <= 12) return t3 ? launch_allch<1, 12, 3, 3>(a, s) : launch_allch<1, 12, 1, 3>(a, s);
+        if (ct > 4 && ct <= 8) return t3 ? launch_allch<1, 8, 3, 2>(a, s) : launch_allch<1, 8, 1, 2>(a, s);
+        // 512 channels (the flow / mask heads): two 16-wave blocks of 256 channels per tile, one block per CU at a time at four
+        // waves per SIMD (16 waves x TWO channel tiles each spills at the 128 registers that leaves)
+        static const bool heads16 = !(getenv("FF_DMA_HEADS16") && atoi(getenv("FF_DMA_HEADS16")) == 0);
+        if (heads16 && ct > 16 && ct <= 32) return t3 ? launch_allch<1, 16, 3, 4>(a, s) : launch_allch<1, 16, 1, 4>(a, s);
+    }
     if (k33) return t3 ? launch_tile<3, 3, 3>(a, th, s) : launch_tile<3, 3, 1>(a, th, s);
     if (k15) return t3 ? launch_tile<1, 5, 3>(a, th, s) : launch_tile<1, 5, 1>(a, th, s);
     return t3 ? launch_tile<5, 1, 3>(a, th, s) : launch_tile<5, 1, 1>(a, th, s);

@@ -84,6 +84,10 @@ DMA_CASES = [
     ([128], 512, 3, 3, 1, 16, 24, 1),           # heads
     ([32, 64, 32], 96, 3, 3, 1, 9, 17, 0),      # three segments, Cout off the 64 / 128 tiles, tiny plane
     ([128, 128], 256, 1, 5, 8, 48, 64, 0),      # the headline launch shape
+    ([256], 192, 3, 3, 8, 48, 64, 1),           # convc2 at the headline shape: the "all channels" layout (12 waves per block)
+    ([192, 64], 126, 3, 3, 8, 48, 64, 1),       # motion conv at the headline shape: "all channels", 8 waves
+    ([128], 512, 3, 3, 8, 48, 64, 1),           # heads at the headline shape: two 16-wave blocks of 256 channels per tile
+    ([64], 160, 3, 3, 3, 30, 170, 0),           # "all channels" on a ragged plane (30 = 5 x 6 rows, 170 = 10.6 x 16 columns), Cout 160
 ]
 
 
