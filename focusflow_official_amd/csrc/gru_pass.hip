@@ -252,61 +252,60 @@ __global__ __launch_bounds__(512) void gru_pass_kernel(const GArgs a) {
     issue_patch(true, 0, 0);
     const float xinv = ff::SPLIT_INV;
     const int cw = wave * 16 + g16 * 4;                         // this lane's first channel (of 128) in z, r, q
+    // ALL operand loads of the rest of the block in flight together, unconditionally (pixels outside the image read pixel 0
+    // and are zeroed by a select: a load under a branch is waited for before the next one is issued): the gates' context
+    // shares on the tile (z, q) and on the r region (r), the state on the r region - the tile's own pixels of it are the
+    // blend's h.  One memory round trip here, none in the epilogue.
+    f32x4 pq[TH], hout[TH];
     {
         const f32x4 bz = *reinterpret_cast<const f32x4*>(a.bzr + cw), br = *reinterpret_cast<const f32x4*>(a.bzr + C + cw);
-        // z on the tile's pixels
-        f32x4 pz[TH];
+        f32x4 pz[TH], pr[NR], hh[NR];
+        int rrow[NR], rcol[NR];
+        bool live[NR], rin[NR], oin[TH];
 #pragma unroll
         for (int u = 0; u < TH; ++u) {
             const int y = y0 + u, x = x0 + pcol;
-            const long long po = (y < H && x < W) ? ((long long)bimg * H + y) * W + x : -1;
-            pz[u] = po >= 0 ? *reinterpret_cast<const f32x4*>(a.zr_pre + po * a.zr_pre_ld + cw) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            oin[u] = y < H && x < W;
+            const long long po = oin[u] ? ((long long)bimg * H + y) * W + x : 0;
+            pz[u] = *reinterpret_cast<const f32x4*>(a.zr_pre + po * a.zr_pre_ld + cw);
+            pq[u] = *reinterpret_cast<const f32x4*>(a.q_pre + po * a.q_pre_ld + cw);
         }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            if (j < NREG) { rrow[j] = j; rcol[j] = rcol_reg; live[j] = true; }
+            else { rrow[j] = hrow[j < NREG ? 0 : j - NREG]; rcol[j] = hcol[j < NREG ? 0 : j - NREG]; live[j] = rrow[j] < RH; }      // (the last halo tile may be partly empty)
+            const int y = ry0 + rrow[j], x = rx0 + rcol[j];
+            rin[j] = live[j] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const long long po = rin[j] ? ((long long)bimg * H + y) * W + x : 0;
+            pr[j] = *reinterpret_cast<const f32x4*>(a.zr_pre + po * a.zr_pre_ld + C + cw);
+            hh[j] = *reinterpret_cast<const f32x4*>(a.h + po * a.h_ld + cw);
+        }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        // z on the tile's pixels
 #pragma unroll
         for (int u = 0; u < TH; ++u) {
             f32x4 t = az[u] * xinv + bz;
+            const f32x4 pv = oin[u] ? pz[u] : zero4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = ff::fast_sigmoid(t[r] + pz[u][r]);
+            for (int r = 0; r < 4; ++r) t[r] = ff::fast_sigmoid(t[r] + pv[r]);
             az[u] = t;
+            hout[u] = oin[u] ? hh[u + ZOFF] : zero4;
+            pq[u] = oin[u] ? pq[u] : zero4;
         }
-        // r * h on the r region, in groups of tiles (operand loads of a group together)
+        // r * h on the r region -> LDS; outside the image h = 0: r * h = 0 there, the q convolution's zero padding
         const int chunk = wave >> 1, slot = 2 * (wave & 1) + (g16 >> 1), half8 = (g16 & 1) * 8;
-        constexpr int GR = 4;
 #pragma unroll
-        for (int j0 = 0; j0 < NR; j0 += GR) {
-            f32x4 pr[GR], hh[GR];
-            int rrow[GR], rcol[GR];
-            bool live[GR];
+        for (int j = 0; j < NR; ++j) {
+            f32x4 t = ar[j] * xinv + br;
+            const f32x4 pv = rin[j] ? pr[j] : zero4, hv = rin[j] ? hh[j] : zero4;
 #pragma unroll
-            for (int k = 0; k < GR; ++k) {
-                const int j = j0 + k;
-                rrow[k] = 0; rcol[k] = 0; live[k] = false;
-                pr[k] = hh[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (j >= NR) continue;
-                if (j < NREG) { rrow[k] = j; rcol[k] = rcol_reg; live[k] = true; }
-                else { rrow[k] = hrow[j < NREG ? 0 : j - NREG]; rcol[k] = hcol[j < NREG ? 0 : j - NREG]; live[k] = rrow[k] < RH; }      // (the last halo tile may be partly empty)
-                const int y = ry0 + rrow[k], x = rx0 + rcol[k];
-                const bool in = live[k] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                const long long po = in ? ((long long)bimg * H + y) * W + x : -1;
-                if (po >= 0) {
-                    pr[k] = *reinterpret_cast<const f32x4*>(a.zr_pre + po * a.zr_pre_ld + C + cw);
-                    hh[k] = *reinterpret_cast<const f32x4*>(a.h + po * a.h_ld + cw);      // outside the image h = 0: r * h = 0 there, the q convolution's zero padding
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < GR; ++k) {
-                const int j = j0 + k;
-                if (j >= NR) continue;
-                f32x4 t = ar[j] * xinv + br;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] = __fmul_rn(ff::fast_sigmoid(t[r] + pr[k][r]), hh[k][r]);
-                if (!live[k]) continue;
-                ff::ff_f16x4 h0, h1;
-                ff::split_pair4(t, h0, h1);
-                const unsigned adr = rh0 + chunk * RPLANE + (unsigned)((rrow[k] * RW + rcol[k]) * 128) + (((unsigned)slot ^ (unsigned)((rcol[k] >> 1) & 7)) << 4) + half8;
-                *(__attribute__((address_space(3))) ff::ff_f16x4*)(unsigned long)adr = h0;
-                if (TERMS == 3) *(__attribute__((address_space(3))) ff::ff_f16x4*)(unsigned long)(adr ^ 64) = h1;
-            }
+            for (int r = 0; r < 4; ++r) t[r] = __fmul_rn(ff::fast_sigmoid(t[r] + pv[r]), hv[r]);
+            if (!live[j]) continue;
+            ff::ff_f16x4 h0, h1;
+            ff::split_pair4(t, h0, h1);
+            const unsigned adr = rh0 + chunk * RPLANE + (unsigned)((rrow[j] * RW + rcol[j]) * 128) + (((unsigned)slot ^ (unsigned)((rcol[j] >> 1) & 7)) << 4) + half8;
+            *(__attribute__((address_space(3))) ff::ff_f16x4*)(unsigned long)adr = h0;
+            if (TERMS == 3) *(__attribute__((address_space(3))) ff::ff_f16x4*)(unsigned long)(adr ^ 64) = h1;
         }
     }
     __syncthreads();            // r * h complete for every wave (lgkmcnt + barrier; the vmcnt(0) also lands the motion patch and q's first weights)
@@ -376,26 +375,19 @@ __global__ __launch_bounds__(512) void gru_pass_kernel(const GArgs a) {
     // =================== epilogue: q = tanh(.), h' = (1 - z) h + z q (update.py:49-50) ===================
     {
         const f32x4 bq = *reinterpret_cast<const f32x4*>(a.bq + cw);
-        f32x4 pq[TH], hh[TH];
-        long long po[TH];
 #pragma unroll
         for (int u = 0; u < TH; ++u) {
             const int y = y0 + u, x = x0 + pcol;
-            po[u] = (y < H && x < W) ? ((long long)bimg * H + y) * W + x : -1;
-            pq[u] = po[u] >= 0 ? *reinterpret_cast<const f32x4*>(a.q_pre + po[u] * a.q_pre_ld + cw) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            hh[u] = po[u] >= 0 ? *reinterpret_cast<const f32x4*>(a.h + po[u] * a.h_ld + cw) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < TH; ++u) {
-            if (po[u] < 0) continue;
+            if (!(y < H && x < W)) continue;
+            const long long po = ((long long)bimg * H + y) * W + x;
             f32x4 t = aq[u] * xinv + bq;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float q = ff::fast_tanh(t[r] + pq[u][r]);
-                t[r] = __fadd_rn(__fmul_rn(__fsub_rn(1.f, az[u][r]), hh[u][r]), __fmul_rn(az[u][r], q));
+                t[r] = __fadd_rn(__fmul_rn(__fsub_rn(1.f, az[u][r]), hout[u][r]), __fmul_rn(az[u][r], q));
             }
-            *reinterpret_cast<f32x4*>(a.y + po[u] * a.y_ld + cw) = t;
-            ff::store_split4(a.y2 + po[u] * a.y2_ld, cw, t);
+            *reinterpret_cast<f32x4*>(a.y + po * a.y_ld + cw) = t;
+            ff::store_split4(a.y2 + po * a.y2_ld, cw, t);
         }
     }
 #ifdef FF_LAB
