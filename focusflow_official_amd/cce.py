@@ -299,6 +299,7 @@ def _branch_stream(device):
     return _branch_streams[key]
 
 
+_ENC_SPLIT = os.environ.get("FF_ENC_SPLIT", "1") != "0"     # split-pair activations inside the eval-BatchNorm encoder's residual blocks (A/B switch)
 _PAIR_FUSION = os.environ.get("FF_PAIR_FUSION", "1") != "0"   # both 1x1 convs of a fusion unit in one launch (inference)
 
 
@@ -572,7 +573,34 @@ class BasicParallelFusionLayer(nn.Module):
             x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
         return self._conv_norm(y, blk._p2, blk.norm2, ACT_RELU, res=x)
 
+    def _split_ok(self, blk: ResidualBlock):
+        """Eval-mode BatchNorm (the context encoder at inference): scale / shift ride in the conv epilogues, so every
+        activation between the block's 3x3 convolutions is final when it is stored - it can leave in the split-pair format
+        (ops.SplitT) and the consumer runs on conv_dma.hip, as in the update block.  Not with InstanceNorm: its
+        coefficients exist only after the whole plane, the consumer normalises raw fp32 values while it loads them."""
+        p2 = blk._p2
+        return (_ENC_SPLIT and self.norm_fn == "batch" and not blk.norm1.training and not blk.norm2.training and not torch.is_grad_enabled()
+                and ops.w_format() in (_hip.W_F16X3, _hip.W_F16) and (p2.kh, p2.kw, p2.stride) == (3, 3, 1) and p2.cin % 32 == 0 and p2.cout % 32 == 0
+                and blk._p1.cout % 32 == 0)
+
+    def _block_split(self, blk: ResidualBlock, x, xs, want_split):
+        """One residual block with split-pair activations inside: x fp32 (the residual), xs its split-pair copy or None ->
+        (y fp32, y split-pair or None).  Same arithmetic as _block: the two formats give a convolution the same bits."""
+        p1, p2 = blk._p1, blk._p2
+        sc1, sh1 = ops.bn_fold(blk.norm1)
+        sc2, sh2 = ops.bn_fold(blk.norm2)
+        dma1 = xs is not None and (p1.kh, p1.kw, p1.stride) == (3, 3, 1) and p1.cin % 32 == 0
+        t = p1(xs if dma1 else x, act=ACT_RELU, ch_scale=sc1, ch_shift=sh1, y_split=True)
+        if blk.downsample is not None:
+            x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
+        if want_split:
+            return p2(t, act=ACT_RELU, ch_scale=sc2, ch_shift=sh2, res=x, act_res=ACT_RELU, y2_split=True)
+        return p2(t, act=ACT_RELU, ch_scale=sc2, ch_shift=sh2, res=x, act_res=ACT_RELU), None
+
     def _run_stage(self, stage, x):
+        if self._split_ok(stage[0]) and self._split_ok(stage[1]):
+            y, ys = self._block_split(stage[0], x, None, True)
+            return self._block_split(stage[1], y, ys, False)[0]
         return self._block(stage[1], self._block(stage[0], x))
 
     def _branches(self, fm, fx, m, x):

@@ -465,6 +465,7 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
         const float bias = p.bias ? p.bias[n] : 0.f;
         const float cs = p.ch_scale ? p.ch_scale[n] : 1.f;
         const float ct = p.ch_scale ? p.ch_shift[n] : 0.f;
+        const bool split_out = p.y_fmt == FF_FMT_SPLIT && n >= p.y_fmt_from;
         float st_p = 0.f, st_s1 = 0.f, st_s2 = 0.f, st_n = 0.f;      // STATS: this lane's channel over its TM x 16 pixels
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
@@ -495,7 +496,9 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
                 const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;        // 0..31: row = pi>>4, col = pi&15 rotated as the loads
                 const int y = y0 + (wm * TM + t) * 2 + (pi >> 4), x = x0 + ((pi - (pi >> 4) * rot) & 15);
                 if (y >= H || x >= W) continue;
-                p.y[(((long long)bimg * H + y) * W + x) * p.y_ld + n] = vv[r];
+                const long long pix = ((long long)bimg * H + y) * W + x;
+                if (split_out) ff::store_split1(p.y + pix * p.y_ld, n, vv[r]);      // FF_FMT_SPLIT output (the consumer is conv_dma.hip)
+                else p.y[pix * p.y_ld + n] = vv[r];
             }
             if constexpr (STATS) {
                 if (y0 + TH <= H && x0 + TW <= W) {      // block-uniform: every pixel of the tile is inside the image
@@ -722,6 +725,12 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
         return launch<3, 6, 2, 1, 3>(a, lds, s);
     }
 #endif
+    // split-pair output (y_fmt; y2 belongs to split-pair inputs = conv_dma.hip): the 32x32x16 epilogue of the high-occupancy
+    // variants writes it; everything else declines (the im2col kernel takes the convolution)
+    if (p.y_fmt != FF_FMT_F32) {
+        static const bool mf16 = getenv("FF_MFMA16") && atoi(getenv("FF_MFMA16")) == 1;
+        if (!occ || p.ep_mode || p.splitk > 1 || mf16) return 1;
+    }
     // split-K (FFConvParams.splitk, see conv2d_splitk_hint): the 4-row high-occupancy variant only
     if (!(occ && th == 4 && p.splitk > 1 && p.splitk_ws && !p.in_scale && !p.res2)) a.p.splitk = 0;
     a.nci_split = a.p.splitk > 1 ? (a.nci + a.p.splitk - 1) / a.p.splitk : a.nci;

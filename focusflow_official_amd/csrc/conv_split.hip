@@ -458,10 +458,10 @@ namespace ff {
 int conv2d_fwd_split(const FFConvParams& p, int M, int cin, hipStream_t s) {
     int rc = conv2d_fwd_dma(p, cin, s);               // split-pair inputs: patch by LDS-DMA, weights straight into registers (conv_dma.hip)
     if (rc != 1) return rc;
-    const bool split_out = p.y_fmt != FF_FMT_F32 || p.y2;      // fp32 in, split-pair out: the im2col kernel's epilogue writes it
+    const bool split_out = p.y_fmt != FF_FMT_F32 || p.y2;      // fp32 in, split-pair out: the patch kernel's or the im2col kernel's epilogue writes it
     rc = split_out ? 1 : conv2d_fwd_stem(p, cin, s);  // the encoders' 7x7 stride-2 stems over NHWC4 (conv_stem.hip)
     if (rc != 1) return rc;
-    rc = split_out ? 1 : conv2d_fwd_patch(p, cin, s); // stride-1 "same" convolutions: patch-stationary kernel
+    rc = conv2d_fwd_patch(p, cin, s);                 // stride-1 "same" convolutions: patch-stationary kernel (declines split outputs it cannot write)
     if (rc != 1) return rc;
     if (p.in_scale) return fail(FF_EINVAL, "ff_conv2d_fwd: in_scale/in_shift: the patch kernel declined this shape");
     if (p.ep_mode) return fail(FF_EINVAL, "ff_conv2d_fwd: ep_mode: the patch kernel declined this shape");

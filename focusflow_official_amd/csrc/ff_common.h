@@ -88,6 +88,14 @@ __device__ __forceinline__ void store_split4(float* pixel_row, int n4, const ff_
             }
     }
 }
+// one channel n of one pixel (kernels whose lanes own single channels: two 2-byte stores)
+__device__ __forceinline__ void store_split1(float* pixel_row, int n, float v) {
+    const float sv = v * XSPLIT;
+    const _Float16 h0 = (_Float16)sv, h1 = (_Float16)(sv - (float)h0);
+    char* c = reinterpret_cast<char*>(pixel_row + (n & ~31)) + (n & 31) * 2;
+    *reinterpret_cast<_Float16*>(c) = h0;
+    *reinterpret_cast<_Float16*>(c + 64) = h1;
+}
 int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s);           // conv_dma.hip (split-pair inputs by LDS-DMA); 1 = not eligible
 int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int cin, hipStream_t s);   // conv_wgrad_split.hip
 int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hipStream_t s);          // conv_wgrad_patch.hip; 1 = not eligible

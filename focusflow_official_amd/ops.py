@@ -821,8 +821,10 @@ def gru_pass(direction: int, hs, motion, h: Tensor, zr_pre: Tensor, q_pre: Tenso
     b, hh, ww, c = h.shape
     assert c == 128 and hs.shape == h.shape and motion.shape == h.shape and zr_pre.shape == (b, hh, ww, 256) and q_pre.shape == h.shape
     y, y2 = empty_nhwc(b, hh, ww, c, h), empty_nhwc(b, hh, ww, c, h)
-    _hip.call("ff_gru_pass", direction, _p(hs.t), _ld(hs.t), _p(motion.t), _ld(motion.t), _p(h), _ld(h), _p(zr_pre), _ld(zr_pre), _p(q_pre), _ld(q_pre),
-              _p(wzr_frag), _p(wq_frag), _p(bzr), _p(bq), w_fmt, _p(y), _ld(y), _p(y2), _ld(y2), b, hh, ww, _stream())
+    # (timed with the convolutions in bench.py's roofline_conv: it IS two of them - 384 -> 256 and 384 -> 128, five taps)
+    _timed_call("conv", "ff_gru_pass", direction, _p(hs.t), _ld(hs.t), _p(motion.t), _ld(motion.t), _p(h), _ld(h), _p(zr_pre), _ld(zr_pre), _p(q_pre), _ld(q_pre),
+                _p(wzr_frag), _p(wq_frag), _p(bzr), _p(bq), w_fmt, _p(y), _ld(y), _p(y2), _ld(y2), b, hh, ww, _stream(),
+                note=(2.0 * b * hh * ww * 384 * 384 * 5, w_fmt))
     return y, SplitT(y2)
 
 

@@ -293,3 +293,56 @@ def test_forward_with_and_without_split_activations(det_sd, size, monkeypatch):
     close(up_s.cpu(), ref_up, rtol=0, atol=1e-3, what="split-pair route vs oracle")
     close(up_p.cpu(), ref_up, rtol=0, atol=1e-3, what="fp32 route vs oracle")
     close(lo_s.cpu(), ref_lo, rtol=0, atol=1e-3, what="flow_low vs oracle")
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 40, 64, 64), (1, 21, 19, 96, 96), (3, 6, 16, 128, 128)])
+def test_patch_kernel_writes_split_pair_outputs(ops, shape):
+    """conv_patch.hip (fp32 in, 3x3 stride 1) writes FF_FMT_SPLIT from its 32x32x16 epilogue - the first convolution of a
+    residual block of the eval-BatchNorm encoder: the bytes are the split pair of what the fp32 output holds, with folded
+    BatchNorm scale / shift, activation and residual in the epilogue."""
+    b, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    bias, sc, sh = (torch.randn(cout, generator=g).to(DEV) for _ in range(3))
+    res = nhwc(torch.randn(b, cout, h, w, generator=g))
+    wp = _pack(ops, wt, cin)
+    kw = dict(act=1, ch_scale=sc, ch_shift=sh, res=res, act_res=1, w_fmt=1)
+    plain = ops.conv2d([nhwc(x)], wp, bias, cout, 3, 3, 1, (1, 1), **kw)
+    sp = ops.conv2d([nhwc(x)], wp, bias, cout, 3, 3, 1, (1, 1), y_split=True, **kw)
+    assert torch.equal(sp.t.view(torch.int32), ops.split_copy(plain).t.view(torch.int32))
+    ref = torch.relu(torch.relu(F.conv2d(x, wt, bias.cpu(), padding=1) * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None]) + nchw(res))
+    close(nchw(plain), ref, rtol=2e-5, what="conv + folded BatchNorm + residual")
+
+
+@pytest.mark.parametrize("size", [(2, 128, 144), (1, 200, 136)])
+def test_context_encoder_with_and_without_split_activations(det_sd, size, monkeypatch):
+    """The eval-BatchNorm encoder (cnet): residual blocks with split-pair activations between their convolutions (conv_dma.hip
+    for 9 of its 12 stride-1 3x3 layers per branch) against the fp32 route - same values up to the summation order inside a
+    32-channel chunk - and the whole forward against the oracle."""
+    from focusflow_official_amd import cce
+    b, h, w = size
+    inp = [t.to(DEV) for t in orc.shifted_pair(b, h, w, seed=5)]
+    m = _model(det_sd)
+    from focusflow_official_amd import ops as _ops
+    seen = []
+    orig = _ops.conv2d
+
+    def spy(xs, *a, **kw):
+        seen.append(any(isinstance(x, _ops.SplitT) for x in xs))
+        return orig(xs, *a, **kw)
+
+    assert cce._ENC_SPLIT
+    with torch.no_grad():
+        monkeypatch.setattr(_ops, "conv2d", spy)
+        lo_s, up_s = m(*inp, raft_iters=2, test_mode=True)
+        n_split_on = sum(seen)
+        seen.clear()
+        monkeypatch.setattr(cce, "_ENC_SPLIT", False)
+        lo_p, up_p = m(*inp, raft_iters=2, test_mode=True)
+        n_split_off = sum(seen)
+        ref_lo, ref_up = orc.ffraft_forward(det_sd, *[t.cpu() for t in inp], raft_iters=2, test_mode=True)
+    assert n_split_on - n_split_off == 18, (n_split_on, n_split_off)        # 2 branches x 3 stages x (b0.conv2, b1.conv1, b1.conv2)
+    close(up_s.cpu(), up_p.cpu(), rtol=0, atol=1e-4, what="context encoder: split-pair activations on vs off")
+    close(up_s.cpu(), ref_up, rtol=0, atol=1e-3, what="split-pair encoder vs oracle")
+    close(lo_s.cpu(), ref_lo, rtol=0, atol=1e-3, what="flow_low vs oracle")

@@ -12,7 +12,7 @@ from focusflow_official_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-H, W = 48, 64
+H, W = (int(v) for v in os.environ.get("HW", "48x64").split("x"))
 # (name, segments, cout, kh, kw, epilogue)
 LAYERS = [
     ("convc2 256->192 3x3", [256], 192, 3, 3, None),
@@ -26,6 +26,9 @@ LAYERS = [
 ]
 
 
+if os.environ.get("ENC"):       # the eval-BatchNorm encoder's residual-block layers (HW=192x256 / 96x128 / 48x64 with B = 8)
+    c = int(os.environ["ENC"])
+    LAYERS = [(f"enc {c}->{c} 3x3", [c], c, 3, 3, None)]
 if os.environ.get("EXP"):       # fixed cost vs slope: the z|r layer over 1, 2, 3 input segments (K = 640, 1280, 1920)
     LAYERS = [("zr K640 1x5", [128], 256, 1, 5, "rh"), ("zr K1280 1x5", [128, 128], 256, 1, 5, "rh"), ("zr K1920 1x5", [128, 128, 128], 256, 1, 5, "rh"),
               ("plain K640 1x5", [128], 256, 1, 5, None), ("plain K1280 1x5", [128, 128], 256, 1, 5, None), ("plain K1920 1x5", [128, 128, 128], 256, 1, 5, None)]

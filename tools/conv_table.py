@@ -1,6 +1,6 @@
-"""Per-layer table of the forward convolutions: record every ops.conv2d call of one FF-RAFT step (B=8, 384x512, 12
-iterations), replay each distinct shape in isolation and print time, useful TFLOP/s and minimum-traffic GB/s, sorted by
-their share of the step."""
+"""Per-layer table of the forward convolutions: record every ops.conv2d call - and every ops.gru_pass call, two
+convolutions in one launch - of one FF-RAFT step (B=8, 384x512, 12 iterations), replay each distinct shape in isolation and
+print time, useful TFLOP/s and minimum-traffic GB/s, sorted by their share of the step."""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from argparse import Namespace
@@ -28,10 +28,28 @@ g = torch.Generator().manual_seed(0)
 im = [torch.randint(0, 256, (b, 3, 384, 512), generator=g).float().cuda() for _ in range(2)]
 mk = [((torch.rand(b, 1, 384, 512, generator=g) < 0.0025).float() * 255).cuda() for _ in range(2)]
 import focusflow_official_amd.cce as cce, focusflow_official_amd.fn as fn, focusflow_official_amd.update_block as ub
+orig_gp = ops.gru_pass
+gp_calls = collections.OrderedDict()
+
+
+def rec_gp(direction, *a):
+    out = orig_gp(direction, *a)
+    gp_calls.setdefault(direction, dict(n=0, args=(direction,) + a))["n"] += 1
+    return out
+
+
 ops.conv2d = rec
+ops.gru_pass = rec_gp
 with torch.no_grad():
     m(im[0], im[1], mk[0], mk[1], raft_iters=12, test_mode=True)
 ops.conv2d = orig
+ops.gru_pass = orig_gp
+
+
+def numel(x):
+    return x.t.numel() if isinstance(x, ops.SplitT) else x.numel()
+
+
 rows = []
 for key, c in calls.items():
     xs, wpack, bias, cout, kh, kw, stride, pad, kw_ = c["args"]
@@ -51,10 +69,29 @@ for key, c in calls.items():
     cin = sum(x.shape[3] for x in xs)
     npx = out.shape[0] * out.shape[1] * out.shape[2]
     fl = 2.0 * npx * cout * cin * kh * kw
-    by = (sum(x.numel() for x in xs) + out.numel() * (2 if key[-1] else 1)) * 4
+    by = (sum(numel(x) for x in xs) + numel(out) * (2 if key[-1] else 1)) * 4
     rows.append((us * c["n"], us, c["n"], key, fl / us / 1e6, by / us / 1e3))
+for direction, c in gp_calls.items():       # z|r (384 -> 256) and q (384 -> 128) of one pass, 1x5 or 5x1, one launch
+    for _ in range(2):
+        orig_gp(*c["args"])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        orig_gp(*c["args"])
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    h = c["args"][3]
+    npx = h.shape[0] * h.shape[1] * h.shape[2]
+    fl = 2.0 * npx * 384 * 384 * 5
+    by = npx * (128 * 3 + 384 + 128 * 2) * 4        # h, its split copy, the motion features, the context shares of the gates; new state twice
+    kh, kw = ((1, 5), (5, 1))[direction]
+    rows.append((us * c["n"], us, c["n"], (((h.shape[0], h.shape[1], h.shape[2], 384),), 384, kh, kw, 1, (kh // 2, kw // 2), 1, False), fl / us / 1e6, by / us / 1e3))
 tot = sum(r[0] for r in rows)
 print(f"total conv time (isolated replay) {tot / 1e3:.2f} ms per step")
 for t, us, n, key, tf, gb in sorted(rows, reverse=True)[:40]:
     shp = "+".join(str(s[3]) for s in key[0])
+    if key[1] == 384 and key[0][0][3] == 384:
+        shp = "gru pass"
     print(f"{t / 1e3:6.2f} ms {100 * t / tot:5.1f}%  n={n:3d} {us:7.1f} us  {tf:6.1f} TF/s {gb:6.0f} GB/s  {key[0][0][1]}x{key[0][0][2]} cin {shp:>11} -> {key[1]:3d} k{key[2]}x{key[3]} s{key[4]} res={int(key[7])}")

@@ -9,7 +9,7 @@ mkdir -p "$out"
 export PYTHONUNBUFFERED=1
 part=${PART:-12}
 if [[ $part == *1* ]]; then
-echo "== default bench line"; python bench.py > "$out/bench_line.json" 2> "$out/bench_line.err"; tail -c 300 "$out/bench_line.json"; echo
+echo "== bench line (the command of the driver's BENCH record)"; python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_line.json" 2> "$out/bench_line.err"; tail -c 300 "$out/bench_line.json"; echo
 echo "== A/B: split-pair activations in the update block (same box, 20 steps each)"
 for v in 0 1 0 1; do FF_SPLIT_ACT=$v python bench.py --steps 20 --warmup 3 --no-secondary --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FF_SPLIT_ACT=$v', d['value'], 'pairs/s', d['ms_per_step'], 'ms; conv launches summed', d['roofline_conv']['sum_launch_ms'], 'ms; lookup frac', d['roofline']['frac'])"; done | tee "$out/ab_split_act.txt"
 echo "== kernel trace of the bench command"
