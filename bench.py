@@ -668,7 +668,9 @@ def main():
                                    f"iters={args.iters}, {args.pyramid} correlation pyramid, random-init weights, ORB-like masks "
                                    f"({'BASELINE configs[1]' if c2 else 'BASELINE configs[4]' if args.pyramid == 'fp16' else 'non-headline shape'})",
                        "pairs_per_gpu": args.batch, "corr_pyramid": args.pyramid, "conv_precision": ops.conv_precision(), "hipgraph": bool(args.graph), "skip_unused_upsample": bool(args.skip_unused_upsample),
-                       "parallelism": f"dp{world} (independent shards, no collective)"},
+                       "parallelism": f"dp{world} (independent shards, no collective)",
+                       # feature switches (A/B runs: FF_SPLIT_ACT=0, FF_GRU_PASS=0 ...) present in the environment; [] for the default line
+                       "env_switches": sorted(f"{k}={v}" for k, v in os.environ.items() if k.startswith("FF_"))},
             "roofline": {"kernel": f"lookup_dma_kernel<{'fp16' if args.pyramid == 'fp16' else 'fp32'}> (ff_corr_lookup_tiled_fwd)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(q, args.pyramid)[0],

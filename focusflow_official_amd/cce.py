@@ -299,7 +299,12 @@ def _branch_stream(device):
     return _branch_streams[key]
 
 
-_ENC_SPLIT = os.environ.get("FF_ENC_SPLIT", "1") != "0"     # split-pair activations inside the eval-BatchNorm encoder's residual blocks (A/B switch)
+# Split-pair activations inside the eval-BatchNorm (context) encoder's residual blocks: OPT-IN (FF_ENC_SPLIT=1).  Built, tested and
+# measured in round 4: 601.7 -> 604-606 pairs/s end to end (inside the noise), and per layer a wash at 8 x 192 x 256 x 64 - conv_dma.hip
+# saves the second convolution of a block 10 us of 109, the first one pays 13 us for writing the format as 2-byte stores from
+# conv_patch.hip's one-channel-per-lane epilogue (tools/conv_table.py: 11.7 ms of convolutions per step without, 12.4 with).
+_ENC_SPLIT = os.environ.get("FF_ENC_SPLIT", "0") == "1"
+_ENC_DUAL = os.environ.get("FF_ENC_DUAL", "0") == "1"
 _PAIR_FUSION = os.environ.get("FF_PAIR_FUSION", "1") != "0"   # both 1x1 convs of a fusion unit in one launch (inference)
 
 
@@ -599,7 +604,10 @@ class BasicParallelFusionLayer(nn.Module):
 
     def _run_stage(self, stage, x):
         if self._split_ok(stage[0]) and self._split_ok(stage[1]):
-            y, ys = self._block_split(stage[0], x, None, True)
+            # (_ENC_DUAL: block 0 also writes its output as a split pair so that block 1's first convolution runs conv_dma.hip
+            # too.  Measured per layer at 8 x 192 x 256 x 64: the second output costs conv2 47 us (152 against 105), the DMA
+            # route saves conv1 10 (99 against 109) - off.)
+            y, ys = self._block_split(stage[0], x, None, _ENC_DUAL)
             return self._block_split(stage[1], y, ys, False)[0]
         return self._block(stage[1], self._block(stage[0], x))
 
