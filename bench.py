@@ -449,16 +449,21 @@ def batch16_measurement(args, device):
                 o = m(*batch, raft_iters=args.iters, test_mode=True)
             torch.cuda.synchronize()
             n = 5
-            ops.launch_timing_begin(ops.TIME_LOOKUP)
-            t0 = time.perf_counter()
-            for _ in range(n):
-                o = m(*batch, raft_iters=args.iters, test_mode=True)
-            torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        lk = ops.launch_timing_end(ops.TIME_LOOKUP)
+            dt, lk = None, None
+            for _ in range(2):       # two batches of n steps, the faster one is reported (a secondary figure measured once, seconds
+                                     # after other models' buffers were released: a single allocator stall would halve it)
+                ops.launch_timing_begin(ops.TIME_LOOKUP)
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    o = m(*batch, raft_iters=args.iters, test_mode=True)
+                torch.cuda.synchronize()
+                d = (time.perf_counter() - t0) / n
+                l = ops.launch_timing_end(ops.TIME_LOOKUP)
+                if dt is None or d < dt:
+                    dt, lk = d, l
         q = 16 * (args.height // 8) * (args.width // 8)
         us = lk[1] / max(1, lk[0])
-        res = {"value": round(16 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n, "warmup": 2,
+        res = {"value": round(16 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n, "warmup": 2, "batches": "faster of 2",
                "finite": bool(torch.isfinite(o[1]).all()),
                "lookup": {"queries_per_launch": q, "launches": lk[0], "avg_launch_us": round(us, 2),
                           "frac_of_hbm_peak": round(q * LOOKUP_BYTES_PER_QUERY["fp32"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None},
