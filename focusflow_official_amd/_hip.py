@@ -21,6 +21,15 @@ _fp = C.c_void_p
 _ll = C.c_longlong
 
 
+class FFFusionPair(C.Structure):
+    """include/focusflow_hip.h: FFFusionPair (ff_fusion_pair_fwd)."""
+    _fields_ = [
+        ("x", _fp * 2), ("x_ld", C.c_int * 2), ("xres", _fp * 2), ("xres_ld", C.c_int * 2), ("scale", _fp * 2), ("shift", _fp * 2),
+        ("in_act", C.c_int), ("w_frag", _fp * 2), ("bias", _fp * 2), ("w_format", C.c_int), ("y", _fp * 2), ("y_ld", C.c_int * 2),
+        ("B", C.c_int), ("HW", C.c_int), ("C", C.c_int),
+    ]
+
+
 class FFConvParams(C.Structure):
     _fields_ = [
         ("x", _fp * MAX_SEG), ("x_ld", C.c_int * MAX_SEG), ("x_c", C.c_int * MAX_SEG),
@@ -96,6 +105,7 @@ _SIGS = {
     "ff_coords_step": [_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_gru_pass": [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
                     C.c_int, C.c_int, C.c_int, _fp],
+    "ff_fusion_pair_fwd": [C.POINTER(FFFusionPair), _fp],
     "ff_gru_rh": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
     "ff_gru_blend": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
     "ff_upsample_flow": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _fp],
@@ -146,9 +156,9 @@ _SIGS = {
     "ff_scale_add_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int,
                          C.c_int, _fp],
 }
-EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint", "ff_conv2d_stats_parts"])
+EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint", "ff_conv2d_stats_parts", "ff_fusion_pair_tile"])
 
-ABI_VERSION = 5      # include/focusflow_hip.h: FF_ABI_VERSION
+ABI_VERSION = 6      # include/focusflow_hip.h: FF_ABI_VERSION
 _lib = None
 
 
@@ -196,6 +206,8 @@ def load():
     lib.ff_corr_plane_elems.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.ff_conv2d_splitk_hint.restype = C.c_int
     lib.ff_conv2d_splitk_hint.argtypes = [C.POINTER(FFConvParams)]
+    lib.ff_fusion_pair_tile.restype = C.c_int
+    lib.ff_fusion_pair_tile.argtypes = [C.c_int]
     lib.ff_conv2d_stats_parts.restype = C.c_int
     lib.ff_conv2d_stats_parts.argtypes = [C.POINTER(FFConvParams)]
     got = lib.ff_abi_version()

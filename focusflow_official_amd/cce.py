@@ -305,6 +305,7 @@ def _branch_stream(device):
 # conv_patch.hip's one-channel-per-lane epilogue (tools/conv_table.py: 11.7 ms of convolutions per step without, 12.4 with).
 _ENC_SPLIT = os.environ.get("FF_ENC_SPLIT", "0") == "1"
 _ENC_DUAL = os.environ.get("FF_ENC_DUAL", "0") == "1"
+_FUSION_PAIR = os.environ.get("FF_FUSION_PAIR", "1") != "0"   # fusion units 1-3 as ff_fusion_pair_fwd launches with lazy normalised inputs (inference; A/B switch)
 _PAIR_FUSION = os.environ.get("FF_PAIR_FUSION", "1") != "0"   # both 1x1 convs of a fusion unit in one launch (inference)
 
 
@@ -453,7 +454,28 @@ class FusionUnit(nn.Module):
             self._pair_key = key
         return self._pair_w, self._pair_b
 
+    def _pair_kernel_ok(self, img):
+        """ff_fusion_pair_fwd takes this unit: both directions, inference, a split weight format, 64 or 96 channels per
+        branch, whole tiles per image."""
+        if not (_FUSION_PAIR and self.fusion_type == "1x1conv" and self.img2mask is not None and not torch.is_grad_enabled()
+                and ops.w_format() in (_hip.W_F16X3, _hip.W_F16)):
+            return False
+        b, h, w, c = img.shape
+        tp = ops.fusion_pair_tile(c)
+        return tp > 0 and (h * w) % tp == 0
+
     def run(self, mask, img):
+        if self._pair_kernel_ok(img) and mask.shape == img.shape and ops.fusion_pair_inputs_ok(img, mask):
+            # inference: the unit as ONE bandwidth-shaped launch (csrc/fusion_pair.hip); lazy inputs (ops.LazyAct: the
+            # normalisation pass in front of the unit) are evaluated inside its loader
+            pa, pb = self.mask2img._p, self.img2mask._p
+            (_, ba), (_, bb) = pa.get(), pb.get()
+            img_out, mask_out = ops.fusion_pair(img, mask, (pa.frag(), pb.frag()), (ba, bb), ops.w_format())
+            return mask_out, img_out
+        if isinstance(img, ops.LazyAct):
+            img = img.materialise()
+        if isinstance(mask, ops.LazyAct):
+            mask = mask.materialise()
         if (_PAIR_FUSION and self.fusion_type == "1x1conv" and self.img2mask is not None and not torch.is_grad_enabled()
                 and ops.w_format() != 0 and img.shape[3] % 32 == 0 and img.shape == mask.shape):
             # inference: ONE launch for img' = img + conv(mask) and mask' = mask + conv(img).  The two separate launches
@@ -522,8 +544,9 @@ class BasicParallelFusionLayer(nn.Module):
         return nn.Sequential(ResidualBlock(cin, cout, self.norm_fn, stride), ResidualBlock(cout, cout, self.norm_fn, 1))
 
     # -- execution ---------------------------------------------------------
-    def _conv_norm(self, x, pc: PackedConv, norm, act, res=None):
-        """act(norm(conv(x))) and, with `res`, relu(res + that)."""
+    def _conv_norm(self, x, pc: PackedConv, norm, act, res=None, lazy=False):
+        """act(norm(conv(x))) and, with `res`, relu(res + that).  lazy (InstanceNorm inference only): -> ops.LazyAct, the
+        normalisation left to the fusion unit that reads it."""
         relu = act == ACT_RELU
         params = [pc.convs[0].weight, pc.convs[0].bias]
         if self.norm_fn == "batch":
@@ -532,6 +555,8 @@ class BasicParallelFusionLayer(nn.Module):
         if self.norm_fn == "instance":
             if not taped:
                 y, st = pc(x, want_stats=True)       # the statistics come out of the conv's epilogue where it can
+                if lazy:
+                    return ops.LazyAct(y, st, y.shape[1] * y.shape[2], EPS, act, res)
                 return ops.norm_apply(y, st, True, EPS, act=act, res=res, out=y)
             if ops.CONV_STATS_TRAIN:
                 y, st = fn.conv(pc, x, want_stats=True)
@@ -561,7 +586,7 @@ class BasicParallelFusionLayer(nn.Module):
             raise NotImplementedError("norm_fn='none' has no autograd path (unused by the reference configs)")
         return pc(x, act=act, res=res, act_res=ACT_RELU)  # 'none'
 
-    def _block(self, blk: ResidualBlock, x):
+    def _block(self, blk: ResidualBlock, x, lazy_out=False):
         p2 = blk._p2
         if (_NORM_ON_LOAD and self.norm_fn == "instance" and not torch.is_grad_enabled() and ops.w_format() in (_hip.W_F16X3, _hip.W_F16)
                 and p2.cin % 32 == 0 and (p2.kh, p2.kw, p2.stride) == (3, 3, 1)):
@@ -572,11 +597,13 @@ class BasicParallelFusionLayer(nn.Module):
             if blk.downsample is not None:
                 x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
             t2, st2 = p2(t1, in_scale=sc, in_shift=sh, in_act=ACT_RELU, want_stats=True)
+            if lazy_out:     # the stage's last block: relu(x + relu(norm2(t2))) is evaluated by the fusion unit's loader
+                return ops.LazyAct(t2, st2, t2.shape[1] * t2.shape[2], EPS, ACT_RELU, x)
             return ops.norm_apply(t2, st2, True, EPS, act=ACT_RELU, res=x, out=t2)
         y = self._conv_norm(x, blk._p1, blk.norm1, ACT_RELU)
         if blk.downsample is not None:
             x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
-        return self._conv_norm(y, blk._p2, blk.norm2, ACT_RELU, res=x)
+        return self._conv_norm(y, blk._p2, blk.norm2, ACT_RELU, res=x, lazy=lazy_out and self.norm_fn == "instance" and not torch.is_grad_enabled())
 
     def _split_ok(self, blk: ResidualBlock):
         """Eval-mode BatchNorm (the context encoder at inference): scale / shift ride in the conv epilogues, so every
@@ -602,7 +629,9 @@ class BasicParallelFusionLayer(nn.Module):
             return p2(t, act=ACT_RELU, ch_scale=sc2, ch_shift=sh2, res=x, act_res=ACT_RELU, y2_split=True)
         return p2(t, act=ACT_RELU, ch_scale=sc2, ch_shift=sh2, res=x, act_res=ACT_RELU), None
 
-    def _run_stage(self, stage, x):
+    def _run_stage(self, stage, x, lazy_out=False):
+        if lazy_out:
+            return self._block(stage[1], self._block(stage[0], x), True)
         if self._split_ok(stage[0]) and self._split_ok(stage[1]):
             # (_ENC_DUAL: block 0 also writes its output as a split pair so that block 1's first convolution runs conv_dma.hip
             # too.  Measured per layer at 8 x 192 x 256 x 64: the second output costs conv2 47 us (152 against 105), the DMA
@@ -633,13 +662,25 @@ class BasicParallelFusionLayer(nn.Module):
         mo.record_stream(main)             # allocated on the side stream, read on the main stream
         return mo, xo
 
+    def _lazy_for(self, unit: "FusionUnit", c, h, w):
+        """Leave the normalisation pass in front of `unit` to the unit's own loader (ops.LazyAct)?  InstanceNorm inference
+        only - an eval BatchNorm is already folded into the producing convolution's epilogue."""
+        if self.norm_fn != "instance" or torch.is_grad_enabled():
+            return False
+        probe = torch.empty((1, h, w, c), device="meta")
+        return unit._pair_kernel_ok(probe)
+
     def forward(self, x, mask):
-        m, x = self._branches(lambda t: self._conv_norm(t, self._mstem, self.mask_norm1, ACT_RELU),
-                              lambda t: self._conv_norm(t, self._stem, self.norm1, ACT_RELU), mask, x)
+        b, hh, ww = x.shape[0], x.shape[1], x.shape[2]
+        lz1 = self._lazy_for(self.fusion1, 64, hh // 2, ww // 2)
+        lz2 = self._lazy_for(self.fusion2, 64, hh // 2, ww // 2)
+        lz3 = self._lazy_for(self.fusion3, 96, hh // 4, ww // 4)
+        m, x = self._branches(lambda t: self._conv_norm(t, self._mstem, self.mask_norm1, ACT_RELU, lazy=lz1),
+                              lambda t: self._conv_norm(t, self._stem, self.norm1, ACT_RELU, lazy=lz1), mask, x)
         m, x = self.fusion1.run(m, x)
-        m, x = self._branches(lambda t: self._run_stage(self.mask_layer1, t), lambda t: self._run_stage(self.layer1, t), m, x)
+        m, x = self._branches(lambda t: self._run_stage(self.mask_layer1, t, lz2), lambda t: self._run_stage(self.layer1, t, lz2), m, x)
         m, x = self.fusion2.run(m, x)
-        m, x = self._branches(lambda t: self._run_stage(self.mask_layer2, t), lambda t: self._run_stage(self.layer2, t), m, x)
+        m, x = self._branches(lambda t: self._run_stage(self.mask_layer2, t, lz3), lambda t: self._run_stage(self.layer2, t, lz3), m, x)
         m, x = self.fusion3.run(m, x)
         m, x = self._branches(lambda t: self._run_stage(self.mask_layer3, t), lambda t: self._run_stage(self.layer3, t), m, x)
         m, x = self.fusion4.run(m, x)

@@ -159,7 +159,7 @@ __device__ __forceinline__ void conv_patch_body(const PArgs& a) {
                     v = __builtin_elementwise_fma(v, nmul, nadd);      // (one fused operation, as norm_apply_kernel's: the two give the same bits)
                     if (p.in_act == FF_ACT_RELU) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];      // (not fmaxf: a NaN must stay one - ff::apply_act)
                     }
                     if (ppix[i] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }

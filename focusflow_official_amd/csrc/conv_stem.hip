@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const SArgs a) {
                 }
                 if (p.act == FF_ACT_RELU) {         // the activation is a launch constant: one branch per tile, not per value
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) vv[r] = vv[r] > 0.f ? vv[r] : 0.f;
+                    for (int r = 0; r < 16; ++r) vv[r] = vv[r] < 0.f ? 0.f : vv[r];      // (NaN-propagating, as ff::apply_act)
                 }
                 if (full) {
 #pragma unroll

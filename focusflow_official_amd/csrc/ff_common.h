@@ -123,7 +123,7 @@ __device__ __forceinline__ float fast_tanh(float v) {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
-        case FF_ACT_RELU: return v > 0.f ? v : 0.f;
+        case FF_ACT_RELU: return v < 0.f ? 0.f : v;      // torch.relu: a NaN stays a NaN (v > 0 ? v : 0 would turn it into 0 and hide an overflow of the split formats from the range guard)
 #ifdef FF_EXACT_ACT      // lab build: libm's expf / tanhf and an IEEE division (what the fast forms were measured against)
         case FF_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case FF_ACT_TANH: return tanhf(v);

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         for (int j = 0; j < 4; ++j) {
             float o = fmaf(v[j], s_mul[g * 4 + j], s_add[g * 4 + j]);       // (one fused operation: the normalise-on-load loaders of conv_patch.hip / conv_dma.hip do the same)
             o = ff::apply_act(o, act);
-            if (rb) { o += r[j]; o = o > 0.f ? o : 0.f; }
+            if (rb) { o += r[j]; o = o < 0.f ? 0.f : o; }
             v[j] = o;
         }
         *reinterpret_cast<f32x4*>(yb + p * y_ld + g * 4) = v;

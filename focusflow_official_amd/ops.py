@@ -828,6 +828,83 @@ def gru_pass(direction: int, hs, motion, h: Tensor, zr_pre: Tensor, q_pre: Tenso
     return y, SplitT(y2)
 
 
+class LazyAct:
+    """An activation that exists only as its ingredients: relu(InstanceNorm(t)) after a stem, relu(x + relu(InstanceNorm(t)))
+    at the end of a residual stage - `t` raw convolution output, `scale` / `shift` the [B][C] tables of norm_coeffs, `res` the
+    block's input or None.  The one consumer that can read it like this is fusion_pair (csrc/fusion_pair.hip: the
+    normalisation pass, its write and its re-read disappear); anything else calls materialise() = ff_norm_apply's result,
+    bit for bit."""
+    __slots__ = ("t", "stats", "count", "eps", "act", "res", "_coef")
+
+    def __init__(self, t: Tensor, stats: Tensor, count: int, eps: float, act: int, res: Optional[Tensor]):
+        self.t, self.stats, self.count, self.eps, self.act, self.res, self._coef = t, stats, count, eps, act, res, None
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def coeffs(self):
+        if self._coef is None:
+            self._coef = norm_coeffs(self.stats, self.count, self.eps)
+        return self._coef
+
+    def materialise(self) -> Tensor:
+        return norm_apply(self.t, self.stats, True, self.eps, act=self.act, res=self.res, out=self.t)
+
+    def record_stream(self, stream):
+        for x in (self.t, self.stats, self.res) + (tuple(self._coef) if self._coef is not None else ()):
+            if x is not None:
+                x.record_stream(stream)
+
+
+def fusion_pair_tile(c: int) -> int:
+    """Pixels per tile of ff_fusion_pair_fwd for c channels per branch (0: no instance)."""
+    return _hip.load().ff_fusion_pair_tile(c)
+
+
+def fusion_pair_inputs_ok(*ins) -> bool:
+    """ff_fusion_pair_fwd reads contiguous NHWC tensors (leading dimension == C) of less than 2 GiB."""
+    for v in ins:
+        for t in ((v.t, v.res) if isinstance(v, LazyAct) else (v,)):
+            if t is not None and (not t.is_cuda or _ld(t) != t.shape[3] or t.numel() * 4 >= (1 << 31)):
+                return False
+    return True
+
+
+def fusion_pair(img, mask, w_frag, bias, w_fmt: int):
+    """FusionUnit '1x1conv', both directions, one launch (ff_fusion_pair_fwd): img / mask fp32 NHWC tensors or LazyAct;
+    w_frag = (mask2img, img2mask) weights in fragment order, bias likewise -> (img', mask')."""
+    ins = (img, mask)
+    b, h, w, c = ins[0].shape
+    assert ins[1].shape == ins[0].shape
+    p = _hip.FFFusionPair()
+    outs = []
+    for i, v in enumerate(ins):
+        t = v.t if isinstance(v, LazyAct) else v
+        _require_gpu(t)
+        p.x[i], p.x_ld[i] = t.data_ptr(), _ld(t)
+        if isinstance(v, LazyAct):
+            sc, sh = v.coeffs()
+            p.scale[i], p.shift[i] = sc.data_ptr(), sh.data_ptr()
+            p.in_act = v.act
+            if v.res is not None:
+                p.xres[i], p.xres_ld[i] = v.res.data_ptr(), _ld(v.res)
+        y = t if isinstance(v, LazyAct) else empty_nhwc(b, h, w, c, t)       # a lazy input's raw tensor has no other reader: write over it
+        outs.append(y)
+        p.y[i], p.y_ld[i] = y.data_ptr(), _ld(y)
+        p.w_frag[i] = w_frag[i].data_ptr()
+        p.bias[i] = bias[i].data_ptr() if bias[i] is not None else None
+    if _range_word is not None:      # CHECK_RANGE: what the unit reads goes through the split format like any convolution input
+        for v in ins:
+            # (a lazy value is relu(res + relu(InstanceNorm(t))): bounded by the residual, which is probed; t itself never meets the format)
+            _range_probe(v.res if isinstance(v, LazyAct) else v) if not (isinstance(v, LazyAct) and v.res is None) else None
+    acts = {v.act for v in ins if isinstance(v, LazyAct)}
+    assert len(acts) <= 1, "lazy inputs of one fusion unit share the activation"
+    p.w_format, p.B, p.HW, p.C = w_fmt, b, h * w, c
+    _hip.call("ff_fusion_pair_fwd", C.byref(p), _stream())
+    return outs[0], outs[1]
+
+
 def mask_upsample_pack(w_split: Tensor) -> Tensor:
     """Split rows of the mask head's second convolution (576 x 256) -> ff_mask_upsample_fwd's stage-major weight image."""
     assert w_split.dtype == torch.uint8 and w_split.numel() == 576 * 1024 and w_split.is_contiguous()

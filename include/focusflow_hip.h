@@ -54,8 +54,9 @@ const char* ff_last_error(void);
  *                ff_norm_stats_finish, ff_launch_timing_begin / _end, ff_mask_upsample_pack / _fwd,
  *                ff_corr_lookup_tiled_bwd_all
  *   5 (round 4): FFConvParams + x_fmt[], y_fmt, y_fmt_from, y2, y2_ld (the split-pair activation format between the
- *                layers of the update block); + ff_split_copy; FF_EP_MOTION_TAIL */
-#define FF_ABI_VERSION 5
+ *                layers of the update block); + ff_split_copy; FF_EP_MOTION_TAIL
+ *   6 (round 4): entry points only: ff_fusion_pair_fwd / ff_fusion_pair_tile (FFFusionPair) */
+#define FF_ABI_VERSION 6
 int ff_abi_version(void);
 
 /* Kernel-timestamp timing of one class of the library's launches (measurement only; bench.py's roofline uses it).
@@ -333,6 +334,34 @@ int ff_gru_pass(int dir, const float* hs, int hs_ld, const float* motion, int mo
                 const float* zr_pre, int zr_pre_ld, const float* q_pre, int q_pre_ld, const void* wzr_frag, const void* wq_frag,
                 const float* bzr, const float* bq, int w_format, float* y, int y_ld, float* y2, int y2_ld, int B, int H, int W,
                 void* stream);
+/* ------------------------------------------------------------------------
+ * One fusion unit of the Condition Control Encoder, type '1x1conv', both directions (parallel_fusion.py:98-150):
+ *     y[0] = v0 + conv1x1(v1; w_frag[0]) + bias[0]        (img'  = img  + mask2img(mask))
+ *     y[1] = v1 + conv1x1(v0; w_frag[1]) + bias[1]        (mask' = mask + img2mask(img))
+ * in one launch that reads every input once and keeps the residual in registers (csrc/fusion_pair.hip).  Branch i's
+ * value v_i is x[i] itself, or - LAZY inputs, scale[i] != NULL - what the normalisation pass in front of the unit would
+ * have written (extractor.py:44-56, parallel_fusion.py:211-217):
+ *     t = in_act(fma(x[i], scale[i][b][c], shift[i][b][c]))  ;  v_i = xres[i] ? relu(xres[i] + t) : t
+ * with the [B][C] coefficient tables of ff_norm_coeffs - the operations of ff_norm_apply, bit for bit.
+ * C = 64 or 96 channels per branch (ff_fusion_pair_tile(C) = pixels per tile, 0 = no instance: use ff_conv2d_fwd);
+ * HW = pixels per image, a multiple of the tile; w_frag[i]: the C x C weights as split rows (ff_pack_conv_weight +
+ * ff_pack_split_f16) re-ordered by ff_pack_frag16; bias[i]: [C] or NULL; w_format FF_W_F16X3 / FF_W_F16; all tensors
+ * NHWC fp32, 16-byte aligned, leading dimensions multiples of 4.  An output may alias its OWN branch's x / xres
+ * (every pixel is read before it is written), never the other branch's.
+ * ---------------------------------------------------------------------- */
+typedef struct FFFusionPair {
+    const float* x[2];     int x_ld[2];
+    const float* xres[2];  int xres_ld[2];
+    const float* scale[2]; const float* shift[2];
+    int in_act;                      /* FF_ACT_* applied to fma(x, scale, shift) */
+    const void* w_frag[2];
+    const float* bias[2];
+    int w_format;
+    float* y[2];           int y_ld[2];
+    int B, HW, C;
+} FFFusionPair;
+int ff_fusion_pair_tile(int C);
+int ff_fusion_pair_fwd(const FFFusionPair* p, void* stream);
 /* GRU gates (update.py:47-49): rh = r*h ; h' = (1-z)*h + z*q */
 int ff_gru_rh(const float* r, int r_ld, const float* h, int h_ld, float* rh, int rh_ld,
               long long npix, int C, void* stream);

@@ -347,3 +347,87 @@ def test_context_encoder_with_and_without_split_activations(det_sd, size, monkey
     close(up_s.cpu(), up_p.cpu(), rtol=0, atol=1e-4, what="context encoder: split-pair activations on vs off")
     close(up_s.cpu(), ref_up, rtol=0, atol=1e-3, what="split-pair encoder vs oracle")
     close(lo_s.cpu(), ref_lo, rtol=0, atol=1e-3, what="flow_low vs oracle")
+
+
+def _fusion_ref(v_img, v_mask, wa, ba, wb, bb):
+    """parallel_fusion.py:98-150, '1x1conv': img' = img + conv(mask), mask' = mask + conv(img), in fp64 (NCHW in / out)."""
+    img, mask = v_img.double(), v_mask.double()
+    return (img + F.conv2d(mask, wa.double(), ba.double()), mask + F.conv2d(img, wb.double(), bb.double()))
+
+
+@pytest.mark.parametrize("lazy", ["plain", "stem", "stage"])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 64), (1, 8, 16, 64), (3, 32, 12, 64), (2, 8, 12, 96), (1, 24, 20, 96)])
+def test_fusion_unit_as_one_launch(ops, shape, lazy):
+    """ff_fusion_pair_fwd (csrc/fusion_pair.hip): a bidirectional '1x1conv' fusion unit in one launch - against fp64, and
+    against the generic route (ops.conv2d over [img, mask] with the anti-diagonal weight) it replaces; with LAZY inputs the
+    loader evaluates the normalisation pass in front of the unit itself: the values it uses are ff_norm_apply's, bit for
+    bit (the residual part of the output proves it: conv weights zero -> output == norm_apply's output exactly)."""
+    b, h, w, c = shape
+    g = torch.Generator().manual_seed(h * 7 + b)
+    t = [torch.randn(b, c, h, w, generator=g) * 2 + 0.3 for _ in range(2)]
+    xr = [torch.randn(b, c, h, w, generator=g) for _ in range(2)]
+    wa, wb = (torch.randn(c, c, 1, 1, generator=g) / 8 for _ in range(2))
+    ba, bb = (torch.randn(c, generator=g) for _ in range(2))
+    td = [nhwc(v) for v in t]
+    xd = [nhwc(v) for v in xr]
+    if lazy == "plain":
+        ins = [td[0].clone(), td[1].clone()]
+        vals = [t[0], t[1]]
+    else:
+        res = xd if lazy == "stage" else [None, None]
+        stats = [ops.norm_stats(v, per_sample=True) for v in td]
+        vals = [nchw(ops.norm_apply(td[i].clone(), stats[i], True, 1e-5, act=1, res=res[i])).cpu() for i in range(2)]
+        ins = [ops.LazyAct(td[i].clone(), stats[i], h * w, 1e-5, 1, res[i]) for i in range(2)]
+    packs = []
+    for wt, bias in ((wa, ba), (wb, bb)):
+        rows = _pack(ops, wt, c)
+        packs.append((ops.pack_frag16(rows, c), bias.to(DEV), rows))
+    img_o, mask_o = ops.fusion_pair(ins[0], ins[1], (packs[0][0], packs[1][0]), (packs[0][1], packs[1][1]), 1)
+    ref_i, ref_m = _fusion_ref(vals[0], vals[1], wa, ba, wb, bb)
+    close(nchw(img_o), ref_i, rtol=2e-5, what=f"img' ({lazy})")
+    close(nchw(mask_o), ref_m, rtol=2e-5, what=f"mask' ({lazy})")
+    # zero weights and biases: the output is the value the unit read - norm_apply's result, exactly
+    zf = torch.zeros_like(packs[0][0])
+    zb = torch.zeros(c, device=DEV)
+    if lazy != "plain":
+        ins = [ops.LazyAct(td[i].clone(), stats[i], h * w, 1e-5, 1, res[i]) for i in range(2)]
+    else:
+        ins = [td[0].clone(), td[1].clone()]
+    i0, m0 = ops.fusion_pair(ins[0], ins[1], (zf, zf), (zb, zb), 1)
+    assert torch.equal(nchw(i0).cpu(), vals[0]) and torch.equal(nchw(m0).cpu(), vals[1])
+
+
+def test_fusion_unit_kernel_refuses_what_it_cannot_read(ops):
+    from focusflow_official_amd._hip import FocusFlowHipError
+    g = torch.Generator().manual_seed(1)
+    x = nhwc(torch.randn(1, 64, 8, 16, generator=g))
+    rows = _pack(ops, torch.randn(64, 64, 1, 1, generator=g), 64)
+    fr = ops.pack_frag16(rows, 64)
+    bias = torch.zeros(64, device=DEV)
+    with pytest.raises(FocusFlowHipError, match="multiple of"):
+        ops.fusion_pair(x[:, :3].contiguous(), x[:, :3].contiguous(), (fr, fr), (bias, bias), 1)       # 48 pixels per image
+    wide = torch.zeros(1, 8, 16, 128, device=DEV)
+    with pytest.raises(FocusFlowHipError, match="contiguous"):
+        ops.fusion_pair(wide[..., :64], wide[..., 64:], (fr, fr), (bias, bias), 1)                      # channel slices
+    x128 = torch.zeros(1, 8, 16, 128, device=DEV)
+    with pytest.raises(FocusFlowHipError, match="C = 128"):
+        ops.fusion_pair(x128, x128.clone(), (fr, fr), (bias, bias), 1)
+
+
+@pytest.mark.parametrize("size", [(2, 128, 144, 3), (1, 384, 512, 12)])
+def test_forward_with_and_without_the_fusion_unit_kernel(det_sd, size, monkeypatch):
+    """The whole forward with fusion units 1 - 3 of both encoders as ff_fusion_pair_fwd launches (lazy normalised inputs in
+    the feature encoder) against the generic route, and against the oracle."""
+    from focusflow_official_amd import cce
+    b, h, w, iters = size
+    inp = [t.to(DEV) for t in orc.shifted_pair(b, h, w, seed=17)]
+    m = _model(det_sd)
+    assert cce._FUSION_PAIR
+    with torch.no_grad():
+        lo_n, up_n = m(*inp, raft_iters=iters, test_mode=True)
+        monkeypatch.setattr(cce, "_FUSION_PAIR", False)
+        lo_o, up_o = m(*inp, raft_iters=iters, test_mode=True)
+        ref_lo, ref_up = orc.ffraft_forward(det_sd, *[t.cpu() for t in inp], raft_iters=iters, test_mode=True)
+    close(up_n.cpu(), up_o.cpu(), rtol=0, atol=1e-4 if iters < 12 else 5e-4, what="fusion-unit kernel on vs off")
+    close(up_n.cpu(), ref_up, rtol=0, atol=1e-3, what="fusion-unit kernel vs oracle")
+    close(lo_n.cpu(), ref_lo, rtol=0, atol=1e-3, what="flow_low vs oracle")
