@@ -739,7 +739,7 @@ def main():
         mfma_ms = sum(t for t, n in zip(conv_ms, notes) if n[1] != 0)
         tot_ms = sum(conv_ms)
         line["roofline_conv"] = {
-            "kernel": "every ff_conv2d_fwd and ff_gru_pass launch of one step (conv_patch / conv_split / conv_small / conv_dma / gru_pass kernels)", "bound": "mfma",
+            "kernel": "every ff_conv2d_fwd, ff_gru_pass and ff_fusion_pair_fwd launch of one step (conv_patch / conv_split / conv_small / conv_dma / gru_pass / fusion_pair kernels)", "bound": "mfma",
             "achieved": round(issued_fl / (mfma_ms * 1e-3) / 1e12, 1) if mfma_ms > 0 else 0.0, "peak": MFMA_PEAK_TFLOPS["f16"],
             "unit": "TFLOP/s", "frac": round(issued_fl / (mfma_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f16"], 4) if mfma_ms > 0 else 0.0,
             "note": f"f16 MFMA FLOP issued (3 per fp32-accurate product) over the summed launch durations; useful "

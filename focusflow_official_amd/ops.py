@@ -901,7 +901,8 @@ def fusion_pair(img, mask, w_frag, bias, w_fmt: int):
     acts = {v.act for v in ins if isinstance(v, LazyAct)}
     assert len(acts) <= 1, "lazy inputs of one fusion unit share the activation"
     p.w_format, p.B, p.HW, p.C = w_fmt, b, h * w, c
-    _hip.call("ff_fusion_pair_fwd", C.byref(p), _stream())
+    # (timed with the convolutions in bench.py's roofline_conv: two C x C 1x1 convolutions)
+    _timed_call("conv", "ff_fusion_pair_fwd", C.byref(p), _stream(), note=(2.0 * b * h * w * 2 * c * c, w_fmt))
     return outs[0], outs[1]
 
 

@@ -18,11 +18,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/tr" -- python3 "$G
 cd "$GRAFT_REPO_ROOT"
 f=$(find "$out/tr" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/bench_b8_kernel_stats.csv"
 f=$(find "$out/tr" -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_iter.py "$f" > "$out/iter_trace.txt" 2>&1
+[ -n "$f" ] && FULL=1 FWD=4 python tools/trace_encoder.py "$f" > "$out/encoder_trace.txt" 2>&1
 rm -rf "$out/tr"; tail -4 "$out/iter_trace.txt"
 echo "== counter passes of the bench command (conv_dma kernels, lookup)"
 PASSES="1 2 3 4 6 8" bash tools/prof_pmc.sh r04/bench_pmc bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline > "$out/bench_pmc.log" 2>&1
 python tools/pmc_summary.py "$out/bench_pmc" conv_dma > "$out/conv_dma_pmc_summary.txt" 2>&1
 python tools/pmc_summary.py "$out/bench_pmc" gru_pass > "$out/gru_pass_pmc_summary.txt" 2>&1
+python tools/pmc_summary.py "$out/bench_pmc" fusion_pair > "$out/fusion_pair_pmc_summary.txt" 2>&1
 python tools/pmc_summary.py "$out/bench_pmc" lookup_dma > "$out/lookup_pmc_summary.txt" 2>&1
 python tools/make_traffic_json.py "$out/bench_pmc" lookup_dma_kernel 24576 2904 "$out/lookup_traffic.json" "the lookup launches of bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline itself (8 pairs 384x512, 12 iterations), tools/prof_pmc.sh passes 1 2 3 4 6 8 + a kernel-trace pass"
 fi
@@ -33,6 +35,7 @@ TILES=8,8,4 python tools/bench_dma_conv.py 8 > "$out/dma_layers_b8.txt" 2>&1; ca
 TILES=8,8 python tools/bench_dma_conv.py 32 > "$out/dma_layers_b32.txt" 2>&1; tail -3 "$out/dma_layers_b32.txt"
 echo "== A/B: the fused GRU pass, the all-channels blocks (same box, 20 steps each)"
 for v in 0 1 0 1; do FF_GRU_PASS=$v python bench.py --steps 20 --warmup 3 --no-secondary --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FF_GRU_PASS=$v', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"; done | tee "$out/ab_gru_pass.txt"
+for v in 0 1 0 1; do FF_FUSION_PAIR=$v python bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FF_FUSION_PAIR=$v', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"; done | tee "$out/ab_fusion_pair.txt"
 for v in 0 1 0 1; do FF_DMA_ALLCH=$v python bench.py --steps 20 --warmup 3 --no-secondary --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FF_DMA_ALLCH=$v', d['value'], 'pairs/s', d['ms_per_step'], 'ms')"; done | tee "$out/ab_allch.txt"
 python tools/loop_time.py 8 > "$out/loop_time.txt" 2>&1; cat "$out/loop_time.txt"
 echo "== in-kernel stamps (lab build)"
