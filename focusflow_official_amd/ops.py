@@ -897,7 +897,9 @@ def fusion_pair(img, mask, w_frag, bias, w_fmt: int):
     if _range_word is not None:      # CHECK_RANGE: what the unit reads goes through the split format like any convolution input
         for v in ins:
             # (a lazy value is relu(res + relu(InstanceNorm(t))): bounded by the residual, which is probed; t itself never meets the format)
-            _range_probe(v.res if isinstance(v, LazyAct) else v) if not (isinstance(v, LazyAct) and v.res is None) else None
+            probe = v.res if isinstance(v, LazyAct) else v
+            if probe is not None:
+                _range_probe(probe)
     acts = {v.act for v in ins if isinstance(v, LazyAct)}
     assert len(acts) <= 1, "lazy inputs of one fusion unit share the activation"
     p.w_format, p.B, p.HW, p.C = w_fmt, b, h * w, c
