@@ -431,3 +431,23 @@ def test_forward_with_and_without_the_fusion_unit_kernel(det_sd, size, monkeypat
     close(up_n.cpu(), up_o.cpu(), rtol=0, atol=1e-4 if iters < 12 else 5e-4, what="fusion-unit kernel on vs off")
     close(up_n.cpu(), ref_up, rtol=0, atol=1e-3, what="fusion-unit kernel vs oracle")
     close(lo_n.cpu(), ref_lo, rtol=0, atol=1e-3, what="flow_low vs oracle")
+
+
+def test_fusion_unit_falls_back_when_the_kernel_cannot_take_the_shape(ops):
+    """FusionUnit.run with lazy inputs on a plane that is not whole tiles (120 pixels per image): the inputs are materialised
+    (ff_norm_apply) and the generic 1x1 route runs - same result as materialising by hand."""
+    from focusflow_official_amd import cce
+    from argparse import Namespace
+    g = torch.Generator().manual_seed(9)
+    b, h, w, c = 2, 10, 12, 64
+    unit = cce.FusionUnit(c, "1x1conv", True).to(DEV)
+    t = [nhwc(torch.randn(b, c, h, w, generator=g)) for _ in range(2)]
+    xr = [nhwc(torch.randn(b, c, h, w, generator=g)) for _ in range(2)]
+    st = [ops.norm_stats(v, per_sample=True) for v in t]
+    with torch.no_grad():
+        assert not unit._pair_kernel_ok(t[0])
+        lazy = [ops.LazyAct(t[i].clone(), st[i], h * w, 1e-5, 1, xr[i]) for i in range(2)]
+        m1, i1 = unit.run(lazy[1], lazy[0])
+        plain = [ops.norm_apply(t[i].clone(), st[i], True, 1e-5, act=1, res=xr[i]) for i in range(2)]
+        m2, i2 = unit.run(plain[1], plain[0])
+    assert torch.equal(i1, i2) and torch.equal(m1, m2)
