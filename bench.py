@@ -312,22 +312,43 @@ def memory_only_companion(launch_bytes, achieved_gbs, device, forward=None):
     # ... and the same kernel INSIDE the pipeline: one extra (untimed) forward in which every lookup is followed by a
     # probe launch on the same stream - behind the same convolutions, at the clocks and with the cache contents the
     # lookup itself meets there
-    piped = None
+    piped, placed = None, {}
     if forward is not None:
-        orig, salt = ops.corr_lookup_tiled, [100]
+        salt = [100]
 
-        def lookup_then_probe(*a, **k):
-            r = orig(*a, **k)
+        def probe():
             salt[0] += 1
             ops.probe_memory_kernel(src, dst, 128, blocks, trips, salt[0])
-            return r
-        ops.corr_lookup_tiled = lookup_then_probe
-        try:
-            ops.launch_timing_begin(ops.TIME_PROBE)
-            forward()
-            piped = ops.launch_timing_end(ops.TIME_PROBE)
-        finally:
-            ops.corr_lookup_tiled = orig
+
+        def run_with(name, before):
+            """One extra forward with a probe launch before (or after) every call of ops.<name>."""
+            orig = getattr(ops, name)
+
+            def hooked(*a, **k):
+                if before:
+                    probe()
+                r = orig(*a, **k)
+                if not before:
+                    probe()
+                return r
+            setattr(ops, name, hooked)
+            try:
+                ops.launch_timing_begin(ops.TIME_PROBE)
+                forward()
+                return ops.launch_timing_end(ops.TIME_PROBE)
+            finally:
+                setattr(ops, name, orig)
+        piped = run_with("corr_lookup_tiled", False)
+        # Two more placements (VERDICT round 3): where the lookup itself stands - its predecessor is the up-sampling kernel,
+        # which has just written 25 MB - and behind the flow head, a predecessor that leaves 0.2 MB dirty
+        for key, name, note in (("in_pipeline_before_lookup", "corr_lookup_tiled", "issued right before every lookup: behind the up-sampling kernel (25 MB of flow_up just written) - the lookup's own place"),
+                                ("in_pipeline_behind_flow_head", "mask_upsample", "issued right behind the flow head's last convolution (0.2 MB written), before the up-sampling kernel")):
+            try:
+                t = run_with(name, True)
+                if t and t[0]:
+                    placed[key] = {"launches": t[0], "avg_launch_us": round(t[1] / t[0], 2), "min_launch_us": round(t[2], 2), "max_launch_us": round(t[3], 2), "note": note}
+            except Exception as e:          # noqa: BLE001
+                placed[key] = {"error": f"{type(e).__name__}: {e}"}
     del src, dst
     torch.cuda.empty_cache()
     avg = tot / max(1, n)
@@ -339,7 +360,8 @@ def memory_only_companion(launch_bytes, achieved_gbs, device, forward=None):
             "note": "back-to-back launches on an otherwise idle chip; the lookup is timed inside the pipeline",
             "in_pipeline": None if not piped or not piped[0] else {
                 "launches": piped[0], "avg_launch_us": round(piped[1] / piped[0], 2), "min_launch_us": round(piped[2], 2), "max_launch_us": round(piped[3], 2),
-                "note": "the same launch issued right behind every lookup of one extra untimed forward"}}
+                "note": "the same launch issued right behind every lookup of one extra untimed forward"},
+            **placed}
 
 
 def _epe(a, b):
@@ -698,13 +720,14 @@ def main():
                     # around 64-80-byte window rows: 1.245 x the algorithmic bytes) - a derived figure, not a measurement
                     mo["scaled_to_counted_traffic_us"] = round(mo["avg_launch_us"] * traffic / mo["bytes_per_launch"], 2)
                     mo["lookup_over_scaled"] = round(mo["scaled_to_counted_traffic_us"] / (per_launch_ms * 1e3), 4) if per_launch_ms > 0 else None
-                ip = mo.get("in_pipeline")
-                if ip and ip["avg_launch_us"] > 0:
-                    gbs = mo["bytes_per_launch"] / (ip["avg_launch_us"] * 1e-6) / 1e9
-                    ip.update(achieved=round(gbs, 1), unit="GB/s", frac_of_peak=round(gbs / HBM_PEAK_GBS, 4), lookup_over_this=round(achieved / gbs, 4))
-                    if traffic:
-                        ip["scaled_to_counted_traffic_us"] = round(ip["avg_launch_us"] * traffic / mo["bytes_per_launch"], 2)
-                        ip["lookup_over_scaled"] = round(ip["scaled_to_counted_traffic_us"] / (per_launch_ms * 1e3), 4) if per_launch_ms > 0 else None
+                for key in ("in_pipeline", "in_pipeline_before_lookup", "in_pipeline_behind_flow_head"):
+                    ip = mo.get(key)
+                    if ip and ip.get("avg_launch_us", 0) > 0:
+                        gbs = mo["bytes_per_launch"] / (ip["avg_launch_us"] * 1e-6) / 1e9
+                        ip.update(achieved=round(gbs, 1), unit="GB/s", frac_of_peak=round(gbs / HBM_PEAK_GBS, 4), lookup_over_this=round(achieved / gbs, 4))
+                        if traffic:
+                            ip["scaled_to_counted_traffic_us"] = round(ip["avg_launch_us"] * traffic / mo["bytes_per_launch"], 2)
+                            ip["lookup_over_scaled"] = round(ip["scaled_to_counted_traffic_us"] / (per_launch_ms * 1e3), 4) if per_launch_ms > 0 else None
                 line["roofline"]["memory_only_kernel"] = mo
             except Exception as e:          # noqa: BLE001 - a measurement aid must not cost the bench line
                 line["roofline"]["memory_only_kernel"] = {"error": f"{type(e).__name__}: {e}"}
