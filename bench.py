@@ -458,6 +458,40 @@ def config4_measurements(device):
     return out
 
 
+def graph_replay_measurement(args, device):
+    """The headline step replayed from a captured hipGraph (focusflow_official_amd.graph.GraphedForward: the context encoder
+    forked beside the feature encoder inside the capture) - the same work, all twelve up-samplings, no host in the loop.
+    Not the headline: bench.py's roofline needs the library's own launches (dispatch-bound events), which a replay does not make."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    from focusflow_official_amd.graph import GraphedForward
+    try:
+        torch.manual_seed(1234)
+        m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
+        batch = synthetic_batch(args.batch, args.height, args.width, 7, device)
+        g = GraphedForward(m, batch, raft_iters=args.iters)
+        for _ in range(3):
+            o = g(*batch)
+        torch.cuda.synchronize()
+        n, dt = 10, None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                o = g(*batch)
+            torch.cuda.synchronize()
+            d = (time.perf_counter() - t0) / n
+            dt = d if dt is None or d < dt else dt
+        with torch.no_grad():
+            ref = m(*batch, raft_iters=args.iters, test_mode=True)
+        res = {"value": round(args.batch / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n, "batches": "faster of 2",
+               "finite": bool(torch.isfinite(o[1]).all()), "max_abs_vs_eager_px": float((o[1] - ref[1]).abs().max()),
+               "workload": f"the headline step ({args.batch} pairs {args.height}x{args.width}, iters={args.iters}) replayed from a hipGraph"}
+        del g
+    except Exception as e:          # noqa: BLE001
+        res = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    return res
+
+
 def batch16_measurement(args, device):
     """The headline workload at 16 pairs per GPU instead of the 8 that BASELINE configs[1] names: what the per-launch ramps of
     the update loop cost at batch 8 (every kernel of the loop is a 5-100 us launch at 1/8 resolution)."""
@@ -556,6 +590,7 @@ def secondary_measurements(args, device):
     torch.cuda.empty_cache()
     out["config4_544x960_it32_fp16_pyramid"] = config4_measurements(device)
     out["headline_shape_16_pairs"] = batch16_measurement(args, device)
+    out["hipgraph_replay"] = graph_replay_measurement(args, device)
     return out
 
 

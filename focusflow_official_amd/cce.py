@@ -644,7 +644,9 @@ class BasicParallelFusionLayer(nn.Module):
         """(fm(m), fx(x)): the mask branch and the image branch between two fusion units are independent.  Inference runs
         the mask branch on a side stream (forked and joined with events: capturable): one branch's memory-bound norm passes
         overlap the other's convolutions."""
-        # (not while a hipGraph is being captured: a fork inside a forked stream - cnet runs beside fnet - kills the capture)
+        # (not while a hipGraph is being captured: the capture takes ONE level of forks - the context encoder beside the feature
+        # encoder, raft_net.py, replay 665 against 650 pairs/s without it - but a fork inside a forked stream dumps core in the HIP
+        # runtime of ROCm 7.2: measured, round 4)
         if not (_BRANCH_STREAMS and ops.policy.encoder_streams_ok and not ops.policy.single_stream and (not torch.is_grad_enabled() or train_streams()) and x.is_cuda) or torch.cuda.is_current_stream_capturing():
             return fm(m), fx(x)
         main = torch.cuda.current_stream()

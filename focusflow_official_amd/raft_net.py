@@ -94,7 +94,7 @@ class RAFT(nn.Module):
         # encoder, whose InstanceNorm statistics / apply passes are memory-bound - the two use different parts of the chip.
         ops.policy.encoder_streams_ok = b * hh * ww >= _STREAMS_MIN_PIXELS
         two_streams = (_ENC_STREAMS and ops.policy.encoder_streams_ok and not ops.policy.single_stream and (not torch.is_grad_enabled() or train_streams())
-                       and not torch.cuda.is_current_stream_capturing())
+                       )      # (also while a hipGraph is being captured: one level of forks is capturable; the branch forks inside each encoder are not - cce._branches)
         if two_streams:
             main = torch.cuda.current_stream()
             if getattr(self, "_enc_stream", None) is None:
