@@ -123,6 +123,12 @@ _SIGS = {
     "ff_gru_blend_bwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
                          _fp, C.c_int, _ll, C.c_int, _fp],
     "ff_upsample_flow_bwd": [_fp, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_upsample_flow_bwd_ex": [_fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_float, _fp, C.c_int, C.c_int, C.c_int, _fp],
+    "ff_gru_bwd_blend": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                         _fp, _fp, _ll, C.c_int, _fp],
+    "ff_gru_bwd_rh": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _ll, C.c_int, _fp],
+    "ff_gru_bwd_out": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _ll, C.c_int, _fp],
+    "ff_sum_stack": [_fp, C.c_int, _ll, _fp, _fp],
     # FF-PWC native component
     "ff_pwc_costvolume_fwd": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_pwc_costvolume_fwd_ex": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp],
@@ -158,7 +164,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["ff_last_error", "ff_abi_version", "ff_corr_plane_elems", "ff_conv2d_splitk_hint", "ff_conv2d_stats_parts", "ff_fusion_pair_tile"])
 
-ABI_VERSION = 6      # include/focusflow_hip.h: FF_ABI_VERSION
+ABI_VERSION = 7      # include/focusflow_hip.h: FF_ABI_VERSION
 _lib = None
 
 

@@ -302,7 +302,8 @@ __global__ void gru_blend_bwd_kernel(const float* __restrict__ dhn, int dhn_ld, 
 // kernel ran at 0.25 TB/s); rows h-1..h+1 go to dflow with global atomics at the end.
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ flow,
                                                            int flow_ld, const float* __restrict__ mask, int mask_ld,
-                                                           float* __restrict__ dflow, float* __restrict__ dmask, int H,
+                                                           float* __restrict__ dflow, int dflow_ld, float* __restrict__ dmask,
+                                                           float mask_scale, unsigned int* __restrict__ dmask_amax, int H,
                                                            int W) {
     extern __shared__ float acc[];   // [3][W][2]
     const int b = blockIdx.y, h = blockIdx.x;
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     const long long rowpix = ((long long)b * H + h) * W;
     const int HW8 = 64 * H * W;
     const int ij = threadIdx.x & 63, i = ij >> 3, j = ij & 7;
+    float amx = 0.f;
     for (int w = wbeg + (threadIdx.x >> 6); w < wend; w += 4) {
         const float* m = mask + (rowpix + w) * mask_ld + ij;
         float pk[9], mx = -INFINITY;
@@ -355,14 +357,30 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
         }
         float* dm = dmask + (rowpix + w) * 576 + ij;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dm[k * 64] = pk[k] * (s[k] - dot);
+        for (int k = 0; k < 9; ++k) {
+            const float gm = pk[k] * (s[k] - dot) * mask_scale;       // mask_scale: the ".25 *" of update.py:133 on the way
+            dm[k * 64] = gm;
+            amx = fmaxf(amx, fabsf(gm));
+        }
     }
     __syncthreads();
     for (int i2 = threadIdx.x; i2 < 3 * W * 2; i2 += 256) {
         const int rr = i2 / (W * 2), rem = i2 - rr * W * 2;
         const int yy = h + rr - 1;
         if ((unsigned)yy < (unsigned)H && acc[i2] != 0.f)
-            atomicAdd(dflow + (((long long)b * H + yy) * W) * 2 + rem, acc[i2]);
+            atomicAdd(dflow + (((long long)b * H + yy) * W + (rem >> 1)) * dflow_ld + (rem & 1), acc[i2]);
+    }
+    if (dmask_amax) {                  // bits of max|d mask| for the convolution gradients that read it (FFConvParams.x_amax)
+        __shared__ float wmax[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            amx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (amx > 0.f && amx < INFINITY && __float_as_uint(amx) > *reinterpret_cast<volatile unsigned int*>(dmask_amax))
+                atomicMax(dmask_amax, __float_as_uint(amx));
+        }
     }
 }
 
@@ -449,6 +467,16 @@ extern "C" int ff_upsample_flow_bwd(const float* dout_nchw, const float* flow, i
     FF_REQUIRE(dout_nchw && flow && mask && dflow && dmask && B > 0 && H > 0 && W > 0 && flow_ld >= 2 && mask_ld >= 576,
                "ff_upsample_flow_bwd: bad argument");
     const size_t lds = (size_t)3 * W * 2 * sizeof(float);
-    upsample_bwd_kernel<<<dim3(H, B, W >= 16 ? 2 : 1), 256, lds, static_cast<hipStream_t>(stream)>>>(dout_nchw, flow, flow_ld, mask, mask_ld, dflow, dmask, H, W);
+    upsample_bwd_kernel<<<dim3(H, B, W >= 16 ? 2 : 1), 256, lds, static_cast<hipStream_t>(stream)>>>(dout_nchw, flow, flow_ld, mask, mask_ld, dflow, 2, dmask, 1.f, nullptr, H, W);
     return ff::check_launch("ff_upsample_flow_bwd");
+}
+
+extern "C" int ff_upsample_flow_bwd_ex(const float* dout_nchw, const float* flow, int flow_ld, const float* mask, int mask_ld,
+                                       float* dflow, int dflow_ld, float* dmask, float mask_scale, unsigned int* dmask_amax,
+                                       int B, int H, int W, void* stream) {
+    FF_REQUIRE(dout_nchw && flow && mask && dflow && dmask && B > 0 && H > 0 && W > 0 && flow_ld >= 2 && mask_ld >= 576 && dflow_ld >= 2,
+               "ff_upsample_flow_bwd_ex: bad argument");
+    const size_t lds = (size_t)3 * W * 2 * sizeof(float);
+    upsample_bwd_kernel<<<dim3(H, B, W >= 16 ? 2 : 1), 256, lds, static_cast<hipStream_t>(stream)>>>(dout_nchw, flow, flow_ld, mask, mask_ld, dflow, dflow_ld, dmask, mask_scale, dmask_amax, H, W);
+    return ff::check_launch("ff_upsample_flow_bwd_ex");
 }

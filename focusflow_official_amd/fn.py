@@ -130,23 +130,8 @@ class ParamGate(torch.autograd.Function):
         pc = ctx.pc
         acc = ctx.scope.acc.pop(pc, None)
         grads: List[Optional[Tensor]] = [None, None]
-        if acc is not None and _UNPACK_GROUP and type(pc).__name__ == "PackedConv" and len(pc.convs) <= 4 \
-                and len(pc.cin_slices or ()) <= 4 and all(ctx.needs_input_grad[2:]):
-            # every member's OIHW gradient and bias gradient in one launch, as views of one buffer
-            has_b = [cv.bias is not None and pc.use_bias for cv in pc.convs]
-            couts = [cv.out_channels for cv in pc.convs]
-            offs = [sum(couts[:j]) for j in range(len(couts))]
-            cin_src = pc.convs[0].in_channels
-            flat = ops.unpack_wgrad_group(acc[0], acc[1], couts, offs, has_b, cin_src, pc.cin_slices, pc.kh, pc.kw, pc.cin_pad)
-            at = 0
-            for cv, co, hb in zip(pc.convs, couts, has_b):
-                n = co * cin_src * pc.kh * pc.kw
-                grads.append(flat[at:at + n].view(co, cin_src, pc.kh, pc.kw))
-                at += n
-                if hb:
-                    grads.append(flat[at:at + co])
-                    at += co
-            return tuple(grads)
+        if acc is not None and _group_unpackable(pc) and all(ctx.needs_input_grad[2:]):
+            return tuple(grads + [g for g in unpack_group(pc, acc[0], acc[1]) if g is not None])
         off, k = 0, 2                     # k: position among this node's inputs (None parameters were not passed)
         for j, cv in enumerate(pc.convs):
             co = cv.out_channels
@@ -157,6 +142,39 @@ class ParamGate(torch.autograd.Function):
                 k += 1
             off += co
         return tuple(grads)
+
+
+def _group_unpackable(pc) -> bool:
+    return _UNPACK_GROUP and type(pc).__name__ == "PackedConv" and len(pc.convs) <= 4 and len(pc.cin_slices or ()) <= 4
+
+
+def unpack_group(pc, dw: Tensor, db: Tensor) -> List[Optional[Tensor]]:
+    """Packed weight-gradient rows dw [Cout][K] + bias gradient db [Cout] of a PackedConv -> the gradients of its members'
+    parameters in the order of pc.params() (None where a member has no bias of its own): every member's OIHW gradient and
+    bias gradient from ONE launch, as views of one buffer (ff_unpack_wgrad_group)."""
+    if not _group_unpackable(pc):
+        out, off = [], 0
+        for j, cv in enumerate(pc.convs):
+            out.append(pc.unpack_wgrad(dw, j, off))
+            out.append(db[off:off + cv.out_channels].clone() if (cv.bias is not None and pc.use_bias) else None)
+            off += cv.out_channels
+        return out
+    has_b = [cv.bias is not None and pc.use_bias for cv in pc.convs]
+    couts = [cv.out_channels for cv in pc.convs]
+    offs = [sum(couts[:j]) for j in range(len(couts))]
+    cin_src = pc.convs[0].in_channels
+    flat = ops.unpack_wgrad_group(dw, db, couts, offs, has_b, cin_src, pc.cin_slices, pc.kh, pc.kw, pc.cin_pad)
+    out, at = [], 0
+    for cv, co, hb in zip(pc.convs, couts, has_b):
+        n = co * cin_src * pc.kh * pc.kw
+        out.append(flat[at:at + n].view(co, cin_src, pc.kh, pc.kw))
+        at += n
+        if hb:
+            out.append(flat[at:at + co])
+            at += co
+        else:
+            out.append(None)
+    return out
 
 
 _scope: Optional[GraphScope] = None

@@ -1041,6 +1041,15 @@ def act_bwd(dy: Tensor, y: Optional[Tensor], act: int, scale: float, c: int, wan
     return (g, amax) if want_amax else g
 
 
+def act_bwd_into(dy: Tensor, y: Optional[Tensor], act: int, g: Tensor, amax: Tensor, scale: float = 1.0):
+    """ff_act_bwd into an existing gradient tensor g (same channel count as dy, a multiple of 4), max|g| into the zeroed
+    word `amax` (the recorded update loop: train_loop.py)."""
+    b, h, w, c = dy.shape
+    assert g.shape == dy.shape and c % 4 == 0
+    _hip.call("ff_act_bwd", _p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, _p(g), _ld(g), b * h * w, c, c, act, scale, _p(amax), _stream())
+    return g
+
+
 def deconv4x4s2_small(x: Tensor, w_rows: Tensor, bias: Optional[Tensor], cout: int, out: Tensor) -> Tensor:
     """ConvTranspose2d(Cin, cout <= 2, 4, 2, 1) of NHWC x (B,H,W,Cin) into `out` (B,2H,2W,>=cout) - ff_deconv4x4s2_small.
     w_rows: fp32 rows [cout][16*Cin] of the equivalent forward conv (transposed + flipped parameter, pack_conv_weight)."""

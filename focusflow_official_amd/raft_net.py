@@ -4,7 +4,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _hip, cce, fn, ops
+from . import _hip, cce, fn, ops, train_loop
 from .cce import BasicParallelFusionLayer, train_streams
 from .corr_block import CorrBlock
 from .ops import ACT_RELU, ACT_TANH
@@ -111,7 +111,14 @@ class RAFT(nn.Module):
         f12 = self.fnet(ops.cat_batch(image1, image2), ops.cat_batch(mask1, mask2))
         fmap1, fmap2 = f12[:b], f12[b:]
         self.fmap = fmap1
-        corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
+        # recorded passes: the whole update loop is one autograd node (train_loop.UpdateLoopFn) that takes the feature maps
+        # themselves - the pyramid is then built outside the tape
+        fused_train = (torch.is_grad_enabled() and train_loop.ENABLED and _GRU_CTX_ONCE and ops.w_format() in (_hip.W_F16X3, _hip.W_F16)
+                       and not test_mode)
+        if fused_train:
+            corr_fn = CorrBlock(fmap1.detach(), fmap2.detach(), radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
+        else:
+            corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
         if two_streams:
             main.wait_event(join)
             cnet.record_stream(main)
@@ -130,7 +137,14 @@ class RAFT(nn.Module):
             ops.act_copy(cnet[..., 128:], inp, ACT_RELU)
         coords1 = ops.coords_init(b, h8, w8, cnet, flow_init)      # never differentiated (raft.py:216)
         # the context features' share of the GRU gate convolutions does not change over the iterations
-        gru_pre = self.update_block.gru.prepare(inp) if _GRU_CTX_ONCE and (taped or not torch.is_grad_enabled()) else None
+        gru_pre = self.update_block.gru.prepare(inp) if _GRU_CTX_ONCE and (taped or fused_train or not torch.is_grad_enabled()) else None
+        if fused_train:
+            lp = train_loop.loop_params(self.update_block)
+            pre = [t for zq in gru_pre for t in zq]
+            if fn.recording(net, *pre, fmap1, fmap2, *lp) and train_loop.eligible(self.update_block, corr_fn, net, gru_pre):
+                return list(train_loop.UpdateLoopFn.apply(self.update_block, corr_fn, coords1, iters, net, *pre, fmap1.contiguous(), fmap2.contiguous(), *lp))
+            if fn.recording(fmap1, fmap2):      # (not eligible after all: the per-operation tape needs the pyramid on the tape)
+                corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
         if (_UPDATE_SPLIT > 1 and test_mode and not taped and not torch.is_grad_enabled() and b % _UPDATE_SPLIT == 0
                 and not ops.policy.single_stream and not torch.cuda.is_current_stream_capturing()):
             # Opt-in (FF_UPDATE_SPLIT=2): the update loop of n batch slices on n streams, the iterations issued alternately.

@@ -55,8 +55,10 @@ const char* ff_last_error(void);
  *                ff_corr_lookup_tiled_bwd_all
  *   5 (round 4): FFConvParams + x_fmt[], y_fmt, y_fmt_from, y2, y2_ld (the split-pair activation format between the
  *                layers of the update block); + ff_split_copy; FF_EP_MOTION_TAIL
- *   6 (round 4): entry points only: ff_fusion_pair_fwd / ff_fusion_pair_tile (FFFusionPair) */
-#define FF_ABI_VERSION 6
+ *   6 (round 4): entry points only: ff_fusion_pair_fwd / ff_fusion_pair_tile (FFFusionPair)
+ *   7 (round 5): entry points only: ff_gru_bwd_blend / _rh / _out, ff_sum_stack, ff_upsample_flow_bwd_ex (the recorded
+ *                update loop's backward) */
+#define FF_ABI_VERSION 7
 int ff_abi_version(void);
 
 /* Kernel-timestamp timing of one class of the library's launches (measurement only; bench.py's roofline uses it).
@@ -472,6 +474,40 @@ int ff_gru_blend_bwd(const float* dhn, int dhn_ld, const float* z, int z_ld, con
 /* convex upsampling backward: dflow NHWC [B*H*W][2] (CALLER ZEROES), dmask NHWC [B*H*W][576] */
 int ff_upsample_flow_bwd(const float* dout_nchw, const float* flow, int flow_ld, const float* mask,
                          int mask_ld, float* dflow, float* dmask, int B, int H, int W, void* stream);
+/* The same for the recorded update loop (below): dflow with its own leading dimension (the 4-channel gradient tensor the flow
+ * head's convolution gradients read; CALLER ZEROES), dmask multiplied by mask_scale on the way out (the ".25 *" of
+ * update.py:133) and max|dmask| left in *dmask_amax (nullable; a zeroed word - FFConvParams.x_amax of the mask head's
+ * gradient convolutions). */
+int ff_upsample_flow_bwd_ex(const float* dout_nchw, const float* flow, int flow_ld, const float* mask, int mask_ld,
+                            float* dflow, int dflow_ld, float* dmask, float mask_scale, unsigned int* dmask_amax,
+                            int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Backward of SepConvGRU (update.py:45-60) between its input-gradient convolutions, as the recorded update loop issues it
+ * (one autograd node for all iterations of raft.py:218-231; focusflow_official_amd/train_loop.py).  Per pass, in backward order:
+ *   ff_gru_bwd_blend   d h' (+ the h half of a [d h | d motion] tensor from the LATER pass's z|r input gradient, whose motion
+ *                      half is added to the motion accumulator dm) -> g_z = d h' (q - h) z (1 - z), g_q = d h' z (1 - q^2),
+ *                      dh_out = d h' (1 - z)         [h' = (1 - z) h + z q]
+ *   (input gradient of the q convolution over [r h, motion]  ->  dqc = [d rh | d motion])
+ *   ff_gru_bwd_rh      g_r = d rh h r (1 - r) ; dh += d rh r ; dm = (dm_init ? 0 : dm) + d motion
+ *   (input gradient of the z|r convolution over [h, motion]  ->  dzc = [d h | d motion])
+ * and once per iteration, behind pass 1:
+ *   ff_gru_bwd_out     dh_out = dh + dzc[:, :C] ; g_motion = (dm + dzc[:, C:]) * [motion > 0] in channels < Cm, 0 from Cm on
+ *                      (the motion encoder's last convolution has Cm = 126 outputs + relu; channels 126, 127 are the flow,
+ *                      which carries no gradient: raft.py:220)
+ * Every g leaves max|g| in a zeroed device word (atomicMax of the float bits): FFConvParams.x_amax of the gradient convolutions
+ * that read it.  g_z and g_r are the two halves of ONE tensor (the z|r convolution's output gradient) and share amax_zr.
+ * All tensors NHWC fp32, 16-byte aligned, leading dimensions multiples of 4; in-place where the names coincide.
+ *   ff_sum_stack       dst[i] = sum_t src[t * n + i], t < T (n % 4 == 0): gradient of a tensor every iteration reads
+ * ---------------------------------------------------------------------- */
+int ff_gru_bwd_blend(const float* dh_in, int dh_in_ld, const float* dzc, int dzc_ld, float* dm, int dm_ld, const float* z, int z_ld,
+                     const float* q, int q_ld, const float* h, int h_ld, float* gz, int gz_ld, float* gq, int gq_ld, float* dh_out,
+                     int dh_out_ld, unsigned int* amax_zr, unsigned int* amax_q, long long npix, int C, void* stream);
+int ff_gru_bwd_rh(const float* dqc, int dqc_ld, const float* r, int r_ld, const float* h, int h_ld, float* gr, int gr_ld,
+                  float* dh, int dh_ld, float* dm, int dm_ld, int dm_init, unsigned int* amax_zr, long long npix, int C, void* stream);
+int ff_gru_bwd_out(const float* dh, int dh_ld, const float* dzc, int dzc_ld, const float* dm, int dm_ld, const float* motion, int mo_ld,
+                   float* dh_out, int dh_out_ld, float* gm, int gm_ld, int Cm, unsigned int* amax_m, long long npix, int C, void* stream);
+int ff_sum_stack(const float* src, int T, long long n, float* dst, void* stream);
 
 /* ========================================================================
  * FF-PWC native component (core/models/ff-pwcnet/PWCNet_Core/): the 81-channel cost volume

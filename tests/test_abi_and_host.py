@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert set(_hip.EXPORTS) == declared, "ctypes table and header disagree"
     lib.ff_abi_version.restype = ctypes.c_int
     ver = int(re.search(r"#define FF_ABI_VERSION (\d+)", hdr).group(1))
-    assert lib.ff_abi_version() == ver == _hip.ABI_VERSION == 6
+    assert lib.ff_abi_version() == ver == _hip.ABI_VERSION == 7
 
 
 def test_conv_params_struct_layout(lib_path):
