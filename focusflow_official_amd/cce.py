@@ -43,6 +43,7 @@ class PackedConv:
     _used_f = _used_d = False      # get() / get_dgrad() have been asked for: prepack() keeps these layouts fresh
     _gen = 0
     _frag = _frag_of = None
+    _dfrag = _dfrag_of = None
 
     def __init__(self, convs: Sequence[nn.Conv2d], cin_pad: Optional[int] = None,
                  cin_slices: Optional[Sequence[Tuple[int, int]]] = None, use_bias: bool = True):
@@ -150,16 +151,35 @@ class PackedConv:
     def frag(self):
         """The forward rows in MFMA-fragment order (ops.pack_frag16) for the split-pair kernel; re-made per repack."""
         w, _ = self.get()
-        key = (self._gen, w.data_ptr())
+        key = (self._gen, self._key, w.data_ptr())      # (_key carries the parameters' versions: subclasses that repack into a fresh buffer never bump _gen)
         if self._frag_of != key:
             self._frag, self._frag_of = ops.pack_frag16(w, self.cout), key
         return self._frag
+
+    def dma_f32_ok(self, xs) -> bool:
+        """conv_dma.hip's fp32-input route takes this convolution (stride-1 'same' 3x3 / 1x5 / 5x1, f16x3, segments of
+        multiples of 32 channels): it then wants the rows in fragment order too."""
+        return (_DMA_FRAG and self.fmt == _hip.W_F16X3 and (self.kh, self.kw) in ((3, 3), (1, 5), (5, 1)) and self.stride == 1 and self.dil == 1
+                and self.pad == (self.kh // 2, self.kw // 2) and all(x.shape[3] % 32 == 0 for x in xs))
+
+    def frag_dgrad(self):
+        """get_dgrad()'s rows in fragment order, or None where the input-gradient convolution does not take conv_dma.hip's
+        fp32-input route (its 'input' channels are this convolution's padded output channels)."""
+        wd, dfmt = self.get_dgrad()
+        cout_pad = (self.cout + 3) // 4 * 4
+        if not (_DMA_FRAG and dfmt == _hip.W_F16X3 and (self.kh, self.kw) in ((3, 3), (1, 5), (5, 1)) and self.stride == 1 and self.dil == 1
+                and self.pad == (self.kh // 2, self.kw // 2) and cout_pad % 32 == 0):
+            return None
+        key = (self._dkey, wd.data_ptr())
+        if self._dfrag_of != key:
+            self._dfrag, self._dfrag_of = ops.pack_frag16(wd, self.cin_pad), key
+        return self._dfrag
 
     def __call__(self, xs, act=ACT_NONE, **kw):
         w, b = self.get()
         if not isinstance(xs, (list, tuple)):
             xs = [xs]
-        if _DMA_FRAG and self.fmt != 0 and any(isinstance(x, ops.SplitT) for x in xs):     # conv_dma.hip loads its weights in fragment order
+        if _DMA_FRAG and self.fmt != 0 and (any(isinstance(x, ops.SplitT) for x in xs) or self.dma_f32_ok(xs)):     # conv_dma.hip loads its weights in fragment order
             kw["w_frag"] = self.frag()
         return ops.conv2d(xs, w, b, self.cout, self.kh, self.kw, self.stride, self.pad, act=act, w_fmt=self.fmt,
                           dilation=self.dil, **kw)

@@ -81,8 +81,18 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // instances: ONE block per 6 x 16 pixel tile computes every output channel (a patch is DMA'd once per tile instead of once
 // per 64 channels; 8 x 8 x 4 = 256 blocks at the headline shape = one per CU, evenly - the 64-channel blocks of a 192- or
 // 126-channel layer are 576 / 384 blocks on 768 slots, and the CUs that hold three of them set the kernel's time).
-template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int UG, int NSET, int NW>
+// XMODE (round 5): 0 = split-pair inputs.  1 = FP32 inputs: the raw patch travels L2 -> LDS by the same LDS-DMA (no registers
+// hold the next chunk's patch during the tap loop - what cost the register-staged prototype its fourth wave per SIMD), and at the
+// top of a chunk the block converts it IN PLACE: a pixel's 32 fp32 channels and its split-pair chunk are the same 128 bytes,
+// the four lanes that own a pixel sit in one wave and read all of it before they write any of it.  2 = 1 + the producer's
+// normalisation applied on the way (FFConvParams in_scale / in_shift / in_act: InstanceNorm + ReLU of the encoders' residual
+// blocks; zero padding AFTER it).  Everything else - no weights in LDS, one weight set per tap straight into registers, 0.33 LDS
+// reads per MFMA - is the split-pair kernel's: this is what takes the stride-1 3x3 / 1x5 / 5x1 layers with fp32 inputs (the
+// encoders, every recorded forward convolution and input gradient) from conv_patch.hip.
+// STATS: FFConvParams.stats_part (partial InstanceNorm statistics of the output from the epilogue, as conv_patch.hip's)
+template <int KH, int KW, int TH, int NV, int TERMS, int EPI, int UG, int NSET, int NW, int XMODE = 0, bool STATS = false>
 __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
+    constexpr bool XF32 = XMODE != 0, INORM = XMODE == 2;
     constexpr int PW = 16 + KW - 1, PH = TH + KH - 1, NPIX = PH * PW, NPIECE = (NPIX + 7) / 8, NPP = (NPIECE + NW - 1) / NW;
     constexpr int PBYTES = NPIECE * 1024, NT = KH * KW, NWL = NV * (TERMS == 3 ? 2 : 1);
     static_assert(PW % 2 == 0, "the bank argument needs an even patch width");
@@ -118,7 +128,8 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
         const int py = r / PW, px = r - py * PW;
         const int yy = y0 - p.pad_h + py, xx = x0 - p.pad_w + px;
         const bool in = r < NPIX && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        ppix[j] = in ? ((((bimg * H + yy) * W + xx) << 7) | (((lane & 7) ^ ((px >> 1) & 7)) * 16)) : -1;
+        // (fp32 inputs land unswizzled - the in-place conversion applies the key when it writes the split-pair chunk)
+        ppix[j] = in ? ((((bimg * H + yy) * W + xx) << 7) | ((XF32 ? (lane & 7) : ((lane & 7) ^ ((px >> 1) & 7))) * 16)) : -1;
     }
     // (segment bookkeeping by mask arithmetic on scalars: `?:` chains over kernel-argument arrays or over buffer resources
     // become a scratch-resident table whose loads - and their vmcnt(0) - would sit inside the pipelined loop)
@@ -139,6 +150,67 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
                 const unsigned voff = ppix[j] >= 0 ? __umul24((unsigned)(ppix[j] >> 7), (unsigned)ldb) + (unsigned)(ppix[j] & 127) : OOB;
                 dma_piece(voff, rs, lds0 + buf * PBYTES + (wave + NW * j) * 1024, soff);
             }
+        }
+    };
+    // ---- fp32 inputs: in-place conversion of a landed patch.  item = tid + NTHR i -> patch row r = item >> 2, k-group s4 = item & 3
+    // (= tid & 3): the lane reads the row's fp32 slots 2 s4, 2 s4 + 1 (channels 8 s4 .. 8 s4 + 7) and writes the x0 halfs to slot
+    // s4 ^ key(px), the x1 halfs to slot (4 + s4) ^ key(px) of the same row.
+    constexpr int NTHR = 64 * NW, NCV = XF32 ? (NPIX * 4 + NTHR - 1) / NTHR : 1;
+    float xs = 1.f, xinv_in = 1.f;
+    if constexpr (XF32) ff::input_scale(p.x_amax, xs, xinv_in);     // gradients (dgrad on the f16 pipe): the input times 2^k, undone in the epilogue
+    const int s4 = tid & 3;
+    unsigned cv_key[NCV];       // swizzle key of the item's pixel column | 8 if the pixel lies inside the image | 16 if the item exists
+    if constexpr (XF32) {
+#pragma unroll
+        for (int i = 0; i < NCV; ++i) {
+            const int r = (tid >> 2) + (NTHR / 4) * i;
+            const int py = r / PW, px = r - py * PW;
+            const int yy = y0 - p.pad_h + py, xx = x0 - p.pad_w + px;
+            cv_key[i] = (unsigned)((px >> 1) & 7) | (((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? 8u : 0u) | (r < NPIX ? 16u : 0u);
+        }
+    }
+    auto convert = [&](int c, int buf) {
+        const unsigned base = lds0 + buf * PBYTES + (unsigned)(tid >> 2) * 128;
+        f32x4 va[NCV], vb[NCV];
+#pragma unroll
+        for (int i = 0; i < NCV; ++i) {
+            va[i] = vb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (cv_key[i] & 16u) {
+                va[i] = *(__attribute__((address_space(3))) const f32x4*)(unsigned long)(base + s4 * 32 + i * (NTHR * 32));
+                vb[i] = *(__attribute__((address_space(3))) const f32x4*)(unsigned long)(base + s4 * 32 + 16 + i * (NTHR * 32));
+            }
+        }
+        f32x4 m0 = {1.f, 1.f, 1.f, 1.f}, m1 = m0, a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        if constexpr (INORM) {              // FFConvParams.in_scale / in_shift: one segment, tables [B][Cin]
+            const long long t = (long long)bimg * a.Cin + c * 32 + s4 * 8;
+            m0 = *reinterpret_cast<const f32x4*>(p.in_scale + t);
+            m1 = *reinterpret_cast<const f32x4*>(p.in_scale + t + 4);
+            a0 = *reinterpret_cast<const f32x4*>(p.in_shift + t);
+            a1 = *reinterpret_cast<const f32x4*>(p.in_shift + t + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NCV; ++i) {
+            if (!(cv_key[i] & 16u)) continue;
+            f32x4 v0 = va[i], v1 = vb[i];
+            if constexpr (INORM) {          // the producer's normalisation (+ ReLU) on the way in; padding is zero AFTER it
+                v0 = __builtin_elementwise_fma(v0, m0, a0);      // (one fused operation, as norm_apply_kernel's: the two give the same bits)
+                v1 = __builtin_elementwise_fma(v1, m1, a1);
+                if (p.in_act == FF_ACT_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v0[j] = v0[j] < 0.f ? 0.f : v0[j]; v1[j] = v1[j] < 0.f ? 0.f : v1[j]; }      // (a NaN stays one: ff::apply_act)
+                }
+                if (!(cv_key[i] & 8u)) v0 = v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            ff::ff_f16x4 h00, h01, h10, h11;
+            ff::split_pair4(v0 * xs, h00, h10);
+            ff::split_pair4(v1 * xs, h01, h11);
+            f16x8 x0, x1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x0[j] = h00[j]; x0[4 + j] = h01[j]; x1[j] = h10[j]; x1[4 + j] = h11[j]; }
+            const unsigned key = cv_key[i] & 7u;
+            const unsigned row = base + i * (NTHR * 32);
+            *(__attribute__((address_space(3))) f16x8*)(unsigned long)(row + (((unsigned)s4 ^ key) << 4)) = x0;
+            if (TERMS == 3) *(__attribute__((address_space(3))) f16x8*)(unsigned long)(row + (((unsigned)(4 + s4) ^ key) << 4)) = x1;
         }
     };
     // ---- weights: lane (i, g) holds k-group g of channel n0 + 16 v + i; term 1 = + 64 bytes
@@ -213,6 +285,10 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
 #endif
             wait_vm<NWL>();
             __builtin_amdgcn_s_barrier();      // every wave's pieces of patch c have landed; everybody is done with the other buffer
+            if constexpr (XF32) {              // fp32 patch -> split pairs, in place; nobody reads a fragment before everybody has converted
+                convert(c, c & 1);
+                __syncthreads();
+            }
 #ifdef FF_DMA_STAMPS
             if (s == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -301,7 +377,7 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
     // flight), then the arithmetic, then the stores.  In-kernel stamps (tools/dma_stamps.py) had shown the z|r and q blocks
     // spending 12 us of their 48 behind the main loop - every block of the launch in that phase at the same time, each
     // running load -> use -> load -> use chains of four memory round trips.
-    const float xinv = ff::SPLIT_INV;
+    const float xinv = ff::SPLIT_INV * xinv_in;
     const int x = x0 + pcol;
     const bool vec_y = (p.y_ld & 3) == 0 && ff::aligned16(p.y);
     const bool vec_r = !p.res || ((p.res_ld & 3) == 0 && ff::aligned16(p.res));
@@ -323,6 +399,8 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
         const bool out_full = nv == 4;
         const bool split_out = p.y_fmt == FF_FMT_SPLIT && n4 >= p.y_fmt_from;
         const bool rh = EPI == FF_EP_GRU_RH && n4 >= p.ep_split;
+        f32x4 st_p = {0.f, 0.f, 0.f, 0.f}, st_s1 = st_p, st_s2 = st_p;      // STATS: this lane's four channels over its pixels
+        float st_n = 0.f;
 #pragma unroll
         for (int ug = 0; ug < TH; ug += UG) {
             f32x4 rr[UG], aa[UG], bb[UG];
@@ -381,6 +459,17 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
                 }
                 vv[k] = t;
             }
+            if constexpr (STATS) {       // around a pivot (the lane's first value): fp32 sums without cancellation on nearly constant planes
+#pragma unroll
+                for (int k = 0; k < UG; ++k) {
+                    if (po[k] < 0) continue;
+                    if (st_n == 0.f) st_p = vv[k];
+                    const f32x4 d = vv[k] - st_p;
+                    st_s1 += d;
+                    st_s2 = __builtin_elementwise_fma(d, d, st_s2);
+                    st_n += 1.f;
+                }
+            }
             // -- stores
 #pragma unroll
             for (int k = 0; k < UG; ++k) {
@@ -396,6 +485,32 @@ __device__ __forceinline__ void conv_dma_body(const DArgs& a) {
                     }
                 }
                 if (p.y2) ff::store_split4(p.y2 + po[k] * p.y2_ld, n4, vv[k], nv);
+            }
+        }
+        if constexpr (STATS) {
+            // the sixteen lanes i16 of a k-group hold the same four channels over other pixel columns: butterfly merge, every
+            // partial re-centred on the receiving lane's pivot (sum(v - p) = s + n d, sum((v - p)^2) = q + 2 d s + n d^2 for
+            // entries around p + d); lane i16 == 0 writes the entry [image][part = tile][channel] = {pivot, s1, s2, n}
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                f32x4 p2, t1, t2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p2[r] = __shfl_xor(st_p[r], off); t1[r] = __shfl_xor(st_s1[r], off); t2[r] = __shfl_xor(st_s2[r], off); }
+                const float n2 = __shfl_xor(st_n, off);
+                if (st_n == 0.f) { st_p = p2; st_s1 = t1; st_s2 = t2; st_n = n2; }
+                else if (n2 > 0.f) {
+                    const f32x4 d = p2 - st_p;
+                    st_s2 += t2 + 2.f * d * t1 + n2 * d * d;
+                    st_s1 += t1 + n2 * d;
+                    st_n += n2;
+                }
+            }
+            if (i16 == 0) {
+                const int nparts = a.tiles_y * a.tiles_x, part = ty * a.tiles_x + tx;
+                float* e = p.stats_part + (((long long)bimg * nparts + part) * p.Cout + n4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n4 + r < p.Cout) *reinterpret_cast<f32x4*>(e + 4 * r) = (f32x4){st_p[r], st_s1[r], st_s2[r], st_n};
             }
         }
     }
@@ -459,6 +574,83 @@ int launch_tile(DArgs& a, int th, hipStream_t s) {
     return launch_ep<KH, KW, 4, 1, TERMS, 4>(a, s);      // (five waves per SIMD would cap the registers at 96: the 5x1 instances spill)
 }
 
+// ---- fp32 inputs (XMODE 1 / 2): one 16-channel tile per wave, NW waves = 16 NW output channels per block
+template <int KH, int KW, int TH, int OCC, int NW, int XMODE, bool STATS>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_dma_f32_kernel(const DArgs a) {
+    conv_dma_body<KH, KW, TH, 1, 3, FF_EP_NONE, (TH % 4 == 0 ? 4 : (TH % 3 == 0 ? 3 : TH)), 2, NW, XMODE, STATS>(a);
+}
+
+template <int KH, int KW, int TH, int OCC, int NW>
+int launch_f32(DArgs& a, hipStream_t s) {
+    constexpr int PW = 16 + KW - 1, PH = TH + KH - 1, NPIECE = (PH * PW + 7) / 8;
+    constexpr size_t lds = 2 * NPIECE * 1024;
+    a.tiles_y = (a.p.H + TH - 1) / TH;
+    a.n_tiles = (a.p.Cout + 16 * NW - 1) / (16 * NW);
+    const long long blocks = (long long)a.p.B * a.tiles_y * a.tiles_x * a.n_tiles;
+    const bool inorm = a.p.in_scale != nullptr, stats = a.p.stats_part != nullptr;
+    if constexpr (KH == 3 && KW == 3) {
+        if (inorm && stats) conv_dma_f32_kernel<KH, KW, TH, OCC, NW, 2, true><<<(unsigned)blocks, 64 * NW, lds, s>>>(a);
+        else if (inorm) conv_dma_f32_kernel<KH, KW, TH, OCC, NW, 2, false><<<(unsigned)blocks, 64 * NW, lds, s>>>(a);
+        else if (stats) conv_dma_f32_kernel<KH, KW, TH, OCC, NW, 1, true><<<(unsigned)blocks, 64 * NW, lds, s>>>(a);
+        else conv_dma_f32_kernel<KH, KW, TH, OCC, NW, 1, false><<<(unsigned)blocks, 64 * NW, lds, s>>>(a);
+    } else {
+        if (inorm || stats) return ff::fail(FF_EINVAL, "ff_conv2d_fwd(dma, fp32 inputs): in_scale / stats_part belong to the 3x3 layers");
+        conv_dma_f32_kernel<KH, KW, TH, OCC, NW, 1, false><<<(unsigned)blocks, 64 * NW, lds, s>>>(a);
+    }
+    return ff::check_launch("ff_conv2d_fwd(dma, fp32 inputs)");
+}
+
+// Which fp32-input convolutions this kernel takes from conv_patch.hip: stride-1 "same" 3x3 / 1x5 / 5x1 layers in the f16x3
+// format with every segment a multiple of 32 channels.  -> tile height (0 = not this kernel) and waves per block.
+struct F32Route { int th, nw; };
+F32Route f32_route(const FFConvParams& p, int cin) {
+    static const bool enabled = !(getenv("FF_DMA_F32") && atoi(getenv("FF_DMA_F32")) == 0);      // A/B switch: 0 = conv_patch.hip
+    F32Route no{0, 0};
+    if (!enabled) return no;
+    const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
+    const bool k33 = p.KH == 3 && p.KW == 3, k15 = p.KH == 1 && p.KW == 5, k51 = p.KH == 5 && p.KW == 1;
+    if (!(k33 || k15 || k51) || p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1 || p.pad_h != p.KH / 2 || p.pad_w != p.KW / 2) return no;
+    if (p.w_format != FF_W_F16X3 || cin % 32 || p.res2 || p.splitk > 1 || p.ep_mode) return no;
+    if ((p.y_fmt == FF_FMT_SPLIT && (p.y_fmt_from % 32 || p.y_ld % 4 || !ff::aligned16(p.y))) || (p.y2 && (p.y2_ld % 4 || !ff::aligned16(p.y2)))) return no;
+    if ((p.in_scale || p.stats_part) && !k33) return no;
+    // Measured per layer (round 5, same box): with 128 input channels and more this route beats conv_patch.hip (128 -> 128 at
+    // 16 x 48 x 64: 54.8 against 59.4 us; the recorded update block and its input gradients: training step 56.0 -> 55.1 ms with
+    // every layer routed, the encoders' included), with two or three chunks per tile it loses (64 -> 64 at 16 x 192 x 256: 215
+    // against 203 us, 96 -> 96: 144 against 136): a tile of two chunks is over before the first patch's round trip and the
+    // epilogue's stores are paid off, and conv_patch.hip hides them with four blocks per CU.  FF_DMA_F32_MINCH overrides (A/B).
+    static const int min_chunks = getenv("FF_DMA_F32_MINCH") ? atoi(getenv("FF_DMA_F32_MINCH")) : 4;
+    if (cin / 32 < min_chunks) return no;
+    long long max_bytes = (long long)(p.Cout + 15) * ((p.KH * p.KW * cin + 31) / 32) * 128;
+    for (int i = 0; i < FF_MAX_SEG && p.x_c[i]; ++i) {
+        if (p.x_c[i] % 32 || p.x_fmt[i] != FF_FMT_F32) return no;
+        max_bytes = std::max(max_bytes, (long long)p.B * p.H * p.W * p.x_ld[i] * 4);
+    }
+    if (max_bytes >= (1ll << 31) || (long long)p.B * p.H * p.W >= (1ll << 24)) return no;
+    if (p.in_scale && (p.x_amax || p.x_c[1] || !ff::aligned16(p.in_scale) || !ff::aligned16(p.in_shift))) return no;
+    if (p.stats_part && (p.x_amax || p.Cout % 4 || !ff::aligned16(p.stats_part))) return no;
+    const int tiles_x = (p.W + 15) / 16;
+    // all output channels in one block where they fit eight waves (the encoders' 64 / 96 / 128-channel layers: the patch is
+    // fetched and converted once per pixel tile), else 64 channels per block
+    // (eight waves x 16 channels for the 128-channel layers spill at the 128 registers two such blocks per CU leave: 64 channels per block there)
+    const int nw = k33 && p.Cout > 64 && p.Cout <= 96 ? 6 : 4;
+    const long long blocks8 = (long long)p.B * ((p.H + 7) / 8) * tiles_x * ((p.Cout + 16 * nw - 1) / (16 * nw));
+    // small planes with long reductions keep conv_patch.hip's K splits (FF-PWC's decoders; one-pair forwards under a hipGraph)
+    if (blocks8 < 256 && p.splitk_ws) return no;
+    if (blocks8 >= (nw == 4 ? 384 : 256)) return F32Route{8, nw};
+    return F32Route{4, 4};
+}
+
+int launch_f32_route(DArgs& a, F32Route r, hipStream_t s) {
+    const bool k33 = a.p.KH == 3, k15 = a.p.KH == 1;
+    if (k33) {
+        if (r.th == 8 && r.nw == 6) return launch_f32<3, 3, 8, 3, 6>(a, s);
+        if (r.th == 8) return launch_f32<3, 3, 8, 3, 4>(a, s);
+        return launch_f32<3, 3, 4, 4, 4>(a, s);
+    }
+    if (k15) return r.th == 8 ? launch_f32<1, 5, 8, 3, 4>(a, s) : launch_f32<1, 5, 4, 4, 4>(a, s);
+    return r.th == 8 ? launch_f32<5, 1, 8, 3, 4>(a, s) : launch_f32<5, 1, 4, 4, 4>(a, s);
+}
+
 // rows -> fragment order: one thread per 16-byte piece of the destination
 __global__ void pack_frag16_kernel(const char* __restrict__ src, char* __restrict__ dst, int rows, int nkc, long long pieces) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < pieces; i += (long long)gridDim.x * 256) {
@@ -486,13 +678,37 @@ extern "C" int ff_pack_frag16(const void* split_rows, void* dst, int rows, int n
 namespace ff {
 // returns FF_OK if launched, 1 if this kernel does not take the convolution (the caller goes on to the other kernels); a
 // split-pair input that it cannot take is an error - nothing else can read it
+// entries per (image, channel) of FFConvParams.stats_part if THIS kernel runs the convolution (0: it does not)
+int conv2d_dma_stats_parts(const FFConvParams& p, int cin) {
+    static const bool stats_on = !(getenv("FF_CONV_STATS") && atoi(getenv("FF_CONV_STATS")) == 0);
+    for (int i = 0; i < FF_MAX_SEG && p.x_c[i]; ++i)
+        if (p.x_fmt[i] != FF_FMT_F32) return 0;
+    if (!stats_on || p.KH != 3 || p.KW != 3 || p.x_amax || p.Cout % 4) return 0;
+    FFConvParams q = p;
+    q.stats_part = nullptr;         // (the route is asked before the buffer exists)
+    const F32Route r = f32_route(q, cin);
+    return r.th ? ((p.H + r.th - 1) / r.th) * ((p.W + 15) / 16) : 0;
+}
+
 int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s) {
     bool any = false, all = true;
     for (int i = 0; i < FF_MAX_SEG && p.x_c[i]; ++i) {
         any |= p.x_fmt[i] == FF_FMT_SPLIT;
         all &= p.x_fmt[i] == FF_FMT_SPLIT;
     }
-    if (!any) return 1;
+    if (!any) {
+        const F32Route r = f32_route(p, cin);
+        if (!r.th) return 1;
+        DArgs a;
+        a.p = p;
+        a.Cin = cin;
+        a.nci = cin / 32;
+        a.nkc = p.KH * p.KW * a.nci;
+        a.tiles_x = (p.W + 15) / 16;
+        a.w_row_bytes = (long long)a.nkc * 128;
+        if (p.w_frag && !aligned16(p.w_frag)) return fail(FF_EINVAL, "ff_conv2d_fwd: w_frag not 16-byte aligned");
+        return launch_f32_route(a, r, s);
+    }
     const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
     const bool k33 = p.KH == 3 && p.KW == 3, k15 = p.KH == 1 && p.KW == 5, k51 = p.KH == 5 && p.KW == 1;
     if (!all || p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1 || !(k33 || k15 || k51) || p.pad_h != p.KH / 2 || p.pad_w != p.KW / 2 ||

@@ -260,7 +260,9 @@ extern "C" int ff_conv2d_stats_parts(const FFConvParams* pp) {
     for (int s = 0; s < FF_MAX_SEG && pp->x_c[s]; ++s) cin += pp->x_c[s];
     if (cin <= 0) return 0;
     const int stem = ff::conv2d_stem_stats_parts(*pp, cin);
-    return stem ? stem : ff::conv2d_stats_parts(*pp, cin);
+    if (stem) return stem;
+    const int dma = ff::conv2d_dma_stats_parts(*pp, cin);       // the fp32-input route of conv_dma.hip takes the layer before conv_patch.hip
+    return dma ? dma : ff::conv2d_stats_parts(*pp, cin);
 }
 
 extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
@@ -315,7 +317,8 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     FF_REQUIRE(p.y_fmt == FF_FMT_F32 || p.y_fmt == FF_FMT_SPLIT, "ff_conv2d_fwd: bad y_fmt %d", p.y_fmt);
     FF_REQUIRE(!(split_in || p.y_fmt || p.y2) || (p.w_format != FF_W_F32 && p.groups == 1 && !p.splitk && !p.stats_part),
                "ff_conv2d_fwd: the split-pair activation format needs a split weight format, groups == 1, no splitk / stats_part");
-    FF_REQUIRE(!p.y2 || split_in, "ff_conv2d_fwd: y2 (second output) belongs to convolutions over split-pair inputs");
+    FF_REQUIRE(!p.y2 || split_in || (p.stride == 1 && cin % 32 == 0 && p.w_format == FF_W_F16X3),
+               "ff_conv2d_fwd: y2 (second output) belongs to conv_dma.hip: split-pair inputs, or fp32 inputs of a stride-1 3x3 / 1x5 / 5x1 f16x3 layer");
     FF_REQUIRE(p.ep_mode != FF_EP_MOTION_TAIL || split_in, "ff_conv2d_fwd: FF_EP_MOTION_TAIL belongs to convolutions over split-pair inputs");
     FF_REQUIRE(p.y_fmt != FF_FMT_SPLIT || (p.y_fmt_from >= 0 && p.y_fmt_from % 32 == 0 && p.y_ld % 4 == 0 && ff::aligned16(p.y) && !p.res2),
                "ff_conv2d_fwd: split-pair output: y_fmt_from %% 32 == 0, y_ld %% 4 == 0, 16-byte aligned y, no res2");

@@ -96,6 +96,7 @@ __device__ __forceinline__ void store_split1(float* pixel_row, int n, float v) {
     *reinterpret_cast<_Float16*>(c) = h0;
     *reinterpret_cast<_Float16*>(c + 64) = h1;
 }
+int conv2d_dma_stats_parts(const FFConvParams& p, int cin);                   // conv_dma.hip (fp32-input route); entries per (image, channel), 0 = not this route
 int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s);           // conv_dma.hip (split-pair inputs by LDS-DMA); 1 = not eligible
 int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int cin, hipStream_t s);   // conv_wgrad_split.hip
 int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hipStream_t s);          // conv_wgrad_patch.hip; 1 = not eligible

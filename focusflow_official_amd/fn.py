@@ -218,7 +218,7 @@ class ConvFn(torch.autograd.Function):
             out = full[..., :pc.cout]
         y = ops.conv2d(xs, w, b, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, act=ACT_NONE if has_res else act, out=out, res=res,
                        act_res=act if has_res else ACT_NONE, out_scale=out_scale, w_fmt=pc.fmt, dilation=pc.dil,
-                       want_stats=stats_out is not None)
+                       want_stats=stats_out is not None, w_frag=pc.frag() if pc.dma_f32_ok(xs) else None)
         if stats_out is not None:      # per-sample {sum, sum of squares} of y for the InstanceNorm that follows (a constant
             y, st = y                  # of the graph: NormFn's backward differentiates through the statistics itself)
             stats_out.append(st)
@@ -261,7 +261,7 @@ class ConvFn(torch.autograd.Function):
                 raise NotImplementedError("stride > 2")
             d = pc.dil
             dx = ops.conv2d([gi], wd, None, cin_tot, pc.kh, pc.kw, 1, (d * (pc.kh - 1) - pc.pad[0], d * (pc.kw - 1) - pc.pad[1]),
-                            w_fmt=dfmt, x_amax=amax if dfmt else None, dilation=d)
+                            w_fmt=dfmt, x_amax=amax if dfmt else None, dilation=d, w_frag=pc.frag_dgrad() if pc.stride == 1 else None)
             off = 0
             for i, x in enumerate(xs):
                 if ctx.needs_input_grad[NFIX + i]:

@@ -52,7 +52,8 @@ def _fwd(pc, xs, out, act=ACT_NONE, res=None, out_scale=1.0):
     if not isinstance(xs, (list, tuple)):
         xs = [xs]
     return ops.conv2d(xs, w, b, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, act=ACT_NONE if res is not None else act, out=out, res=res,
-                      act_res=act if res is not None else ACT_NONE, out_scale=out_scale, w_fmt=pc.fmt, dilation=pc.dil)
+                      act_res=act if res is not None else ACT_NONE, out_scale=out_scale, w_fmt=pc.fmt, dilation=pc.dil,
+                      w_frag=pc.frag() if pc.dma_f32_ok(xs) else None)
 
 
 def _dgrad(pc, g, amax, cin_tot, out, res=None):
@@ -60,7 +61,7 @@ def _dgrad(pc, g, amax, cin_tot, out, res=None):
     wd, dfmt = pc.get_dgrad()
     d = pc.dil
     return ops.conv2d([g], wd, None, cin_tot, pc.kh, pc.kw, 1, (d * (pc.kh - 1) - pc.pad[0], d * (pc.kw - 1) - pc.pad[1]),
-                      w_fmt=dfmt, x_amax=amax if dfmt else None, dilation=d, out=out, res=res)
+                      w_fmt=dfmt, x_amax=amax if dfmt else None, dilation=d, out=out, res=res, w_frag=pc.frag_dgrad())
 
 
 class UpdateLoopFn(torch.autograd.Function):
