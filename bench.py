@@ -228,7 +228,9 @@ def harness_selftest(args):
     if rank == 0:
         pairs = args.batch * world * args.steps
         print(json.dumps({"metric": "harness-selftest", "value": pairs / elapsed, "n_gpus": world, "steps": args.steps,
-                          "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak", "shard": [lo, hi]}), flush=True)
+                          "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak", "shard": [lo, hi],
+                          # what the real forward bench would do with these flags (N > 1: hipGraph replay unless --eager)
+                          "hipgraph": bool(args.graph or (world > 1 and not args.eager))}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -423,20 +425,20 @@ def parity_and_reduced_precision(args, device, checker):
 
 
 def config4_measurements(device):
-    """BASELINE configs[4]: FF-RAFT 540x960 (padded to 544x960), 32 iterations, fp16 correlation pyramid; 1 and 4 pairs."""
+    """BASELINE configs[4]: FF-RAFT 540x960 (padded to 544x960), 32 iterations, fp16 correlation pyramid; 1, 4, 16 and 32 pairs per step."""
     from focusflow_official_amd import FF_RAFT_FUSION, ops
     out = {}
     try:
         torch.manual_seed(1234)
         m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=cfg()).to(device).eval()
         m.flow_net.corr_pyramid_dtype = "fp16"
-        for b in (1, 4):
+        for b in (1, 4, 16, 32):      # (177 MB of fp16 pyramid per pair: 5.7 GB at 32 pairs - the batch at which this config is a bandwidth stress)
             batch = synthetic_batch(b, 544, 960, 77 + b, device)
             with torch.no_grad():
                 for _ in range(2):
                     o = m(*batch, raft_iters=32, test_mode=True)
                 torch.cuda.synchronize()
-                n = 5
+                n = 5 if b <= 4 else 3
                 ops.launch_timing_begin(ops.TIME_LOOKUP)
                 t0 = time.perf_counter()
                 for _ in range(n):
@@ -530,6 +532,84 @@ def batch16_measurement(args, device):
     return res
 
 
+def pwc_measurements(device):
+    """BASELINE configs[3]: FF-PWC forward on 448x1024 pairs - one pair eager and replayed from a hipGraph (a one-pair forward is
+    a chain of small launches: host-bound when issued eagerly), eight pairs eager, and the cost-volume kernel (correlation.py:34-102)
+    against the HBM roofline: algorithmic bytes of a launch (both feature maps read once, 81 channels written once) / its time."""
+    from argparse import Namespace
+    from focusflow_official_amd import ops
+    from focusflow_official_amd.pwcnet import FF_PWCNET
+    out = {"workload": "BASELINE configs[3]: FF_PWCNET test_mode, 448x1024 pairs, SIFT-like mask (2000 points), random-init weights"}
+    try:
+        pcfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"), MODEL=Namespace(FUSION="parallel", FUSION_TYPE="1x1conv"))
+        torch.manual_seed(0)
+        m = FF_PWCNET(pcfg).to(device).eval()
+        with torch.no_grad():       # unnormalised 0..255 inputs: keep the first layer's activations in fp16 range
+            m.netExtractor.netOne[0].weight.mul_(1 / 255.0)
+            m.netExtractor.mask_netOne[0].weight.mul_(1 / 255.0)
+
+        def inputs(b):
+            g = torch.Generator().manual_seed(0)
+            i1 = torch.randint(0, 256, (b, 3, 448, 1024), generator=g).float().to(device)
+            i2 = torch.roll(i1, (3, -5), (2, 3))
+            m1 = ((torch.rand(b, 1, 448, 1024, generator=g) < 2000 / (448 * 1024)).float() * 255).to(device)
+            return i1, i2, m1, m1
+
+        def timeit(f, n):
+            for _ in range(3):
+                o = f()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                o = f()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n, o
+
+        with torch.no_grad():
+            inp1 = inputs(1)
+            dt, ref = timeit(lambda: m(*inp1, test_mode=True), 10)
+            out["pairs_1_eager"] = {"value": round(1 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": 10, "warmup": 3,
+                                    "finite": bool(torch.isfinite(ref).all())}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    m(*inp1, test_mode=True)
+            torch.cuda.current_stream().wait_stream(side)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                gout = m(*inp1, test_mode=True)
+
+            def rep():
+                gr.replay()
+                return gout
+            dt, o = timeit(rep, 20)
+            out["pairs_1_hipgraph_replay"] = {"value": round(1 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": 20, "warmup": 3,
+                                              "max_abs_vs_eager_px": float((o - ref).abs().max())}
+            del gr, gout
+            inp8 = inputs(8)
+            dt, o = timeit(lambda: m(*inp8, test_mode=True), 5)
+            out["pairs_8_eager"] = {"value": round(8 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": 5, "warmup": 3,
+                                    "finite": bool(torch.isfinite(o).all())}
+            # the cost-volume launches of one more 8-pair forward, each bracketed by an event pair on its stream
+            ops.profile_begin("pwc_costvolume")
+            m(*inp8, test_mode=True)
+            notes = ops.profile_notes("pwc_costvolume")
+            times = ops.profile_end()["pwc_costvolume"]
+            levels = []
+            for ms, (nbytes, shape, splits) in zip(times, notes):
+                levels.append({"B_H_W_C": list(shape), "us": round(ms * 1e3, 2), "algorithmic_bytes": nbytes, "k_splits": splits,
+                               "achieved_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            big = max(levels, key=lambda l: l["algorithmic_bytes"]) if levels else None
+            out["costvolume_roofline"] = {"kernel": "costvolume_fwd_kernel (ff_pwc_costvolume_fwd_ex), 8 pairs", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "dominant_level": big, "levels": levels,
+                                          "timing": "event pair recorded around each launch on its stream (includes the dispatch gap; the launches are 5-60 us)"}
+    except Exception as e:          # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary_measurements(args, device):
     """The secondary BASELINE configs on the same GPU, after the headline measurement (N = 1 only, a few seconds each):
     the training step (configs[2] shape, one GPU), the FF-PWC forward (configs[3]) and configs[4] (544x960, 32 iterations,
@@ -558,36 +638,7 @@ def secondary_measurements(args, device):
     except Exception as e:          # noqa: BLE001 - reported, never fatal for the headline line
         out["train_step"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
-    try:
-        from argparse import Namespace
-        from focusflow_official_amd.pwcnet import FF_PWCNET
-        pcfg = Namespace(TRAIN=Namespace(MASK_CHANNEL=3, MASK_MODAL="point"), MODEL=Namespace(FUSION="parallel", FUSION_TYPE="1x1conv"))
-        torch.manual_seed(0)
-        m = FF_PWCNET(pcfg).to(device).eval()
-        with torch.no_grad():       # unnormalised 0..255 inputs: keep the first layer's activations in fp16 range
-            m.netExtractor.netOne[0].weight.mul_(1 / 255.0)
-            m.netExtractor.mask_netOne[0].weight.mul_(1 / 255.0)
-        g = torch.Generator().manual_seed(0)
-        i1 = torch.randint(0, 256, (1, 3, 448, 1024), generator=g).float().to(device)
-        i2 = torch.roll(i1, (3, -5), (2, 3))
-        m1 = ((torch.rand(1, 1, 448, 1024, generator=g) < 2000 / (448 * 1024)).float() * 255).to(device)
-        with torch.no_grad():
-            for _ in range(3):
-                o = m(i1, i2, m1, m1, test_mode=True)
-            torch.cuda.synchronize()
-            n = 10
-            t0 = time.perf_counter()
-            for _ in range(n):
-                o = m(i1, i2, m1, m1, test_mode=True)
-            torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        out["ff_pwc_forward"] = {"metric": "frame-pairs/sec FF-PWC forward 448x1024", "value": round(1 / dt, 2), "unit": "frame-pairs/s",
-                                 "ms_per_step": round(dt * 1e3, 3), "steps": n, "warmup": 3,
-                                 "workload": "BASELINE configs[3]: FF_PWCNET test_mode, 1 pair 448x1024, SIFT-like mask (2000 points)",
-                                 "finite": bool(torch.isfinite(o).all())}
-    except Exception as e:          # noqa: BLE001
-        out["ff_pwc_forward"] = {"error": f"{type(e).__name__}: {e}"}
-    torch.cuda.empty_cache()
+    out["ff_pwc_forward"] = pwc_measurements(device)
     out["config4_544x960_it32_fp16_pyramid"] = config4_measurements(device)
     out["headline_shape_16_pairs"] = batch16_measurement(args, device)
     out["hipgraph_replay"] = graph_replay_measurement(args, device)
@@ -620,7 +671,8 @@ def main():
     ap.add_argument("--pyramid", choices=["fp32", "fp16"], default="fp32",
                     help="storage type of the correlation pyramid: fp32 = the reference's arithmetic (headline); fp16 = "
                          "BASELINE configs[4] (540x960 padded to 544x960, iters 32: --height 544 --width 960 --iters 32 --batch 1)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (the default when --gpus > 1)")
+    ap.add_argument("--eager", action="store_true", help="--gpus > 1: issue the steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--skip-unused-upsample", action="store_true",
                     help="NOT the default / not the headline number: compute the mask head + convex up-sampling only for "
                          "the last iteration (the reference discards the other 11 in test_mode); outputs are bit-identical")
@@ -675,6 +727,11 @@ def main():
         with torch.no_grad():
             return model(*batch, raft_iters=args.iters, test_mode=True)
 
+    # N > 1 ranks on one host: the step is replayed from a captured hipGraph by default - an eager step costs the host 6 ms of a
+    # 12 ms step, and N ranks' launch threads share the host (--eager switches back; N = 1 stays eager so that the roofline's
+    # dispatch-bound events see the timed region itself)
+    if world > 1 and not args.eager:
+        args.graph = True
     if args.graph:
         from focusflow_official_amd.graph import GraphedForward
         graphed = GraphedForward(model, batch, raft_iters=args.iters)
@@ -692,6 +749,7 @@ def main():
     log(f"{args.steps} timed steps in {elapsed:.3f} s")
     lk, vb = ops.launch_timing_end(ops.TIME_LOOKUP), ops.launch_timing_end(ops.TIME_CORR_BUILD)
     assert torch.isfinite(out[1]).all()
+    ops.guard_check(sync=True)          # the always-on range guard looks at a forward when the next one starts: the last one here
     # host time to issue one step, MAX over ranks like the step time itself (outside the timed region)
     issue_ms, issue_total_ms = host_issue_time(step)
     if world > 1:

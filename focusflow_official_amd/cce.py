@@ -45,8 +45,10 @@ class PackedConv:
     _frag = _frag_of = None
     _dfrag = _dfrag_of = None
 
+    force_f32 = False
+
     def __init__(self, convs: Sequence[nn.Conv2d], cin_pad: Optional[int] = None,
-                 cin_slices: Optional[Sequence[Tuple[int, int]]] = None, use_bias: bool = True):
+                 cin_slices: Optional[Sequence[Tuple[int, int]]] = None, use_bias: bool = True, force_f32: bool = False):
         """cin_slices: take only these input-channel ranges of the weights, in this order (a convolution is linear
         in its input channels: the GRU splits off the part that meets the loop-invariant context features);
         use_bias=False leaves the bias to the other part (and its gradient: params() then
@@ -59,6 +61,7 @@ class PackedConv:
         self.dil = c0.dilation[0]
         self.cin_slices = list(cin_slices) if cin_slices is not None else None
         self.use_bias = use_bias
+        self.force_f32 = force_f32      # exact-fp32 rows whatever the global conv precision (the range guard's repair route)
         self.cin = c0.in_channels if cin_slices is None else sum(hi - lo for lo, hi in cin_slices)
         self.cin_pad = cin_pad if cin_pad is not None else (self.cin + 3) // 4 * 4
         self.cout = sum(c.out_channels for c in self.convs)
@@ -116,7 +119,7 @@ class PackedConv:
                 if c.bias is not None and self.use_bias:
                     self.b[off:off + c.out_channels].copy_(c.bias.detach())  # device memcpy
                 off += c.out_channels
-            self.fmt = 0 if self._small() else ops.w_format()
+            self.fmt = 0 if (self._small() or self.force_f32) else ops.w_format()
             if self.fmt != 0:
                 self.w = ops.pack_split(self.w)
             self._key = key
@@ -218,7 +221,7 @@ def _pack_job(pc, need_f, need_d, dev):
     for i, (lo, hi) in enumerate(sl):
         J.slice_lo[i], J.slice_hi[i] = lo, hi
     J.cin, J.cin_pad, J.KH, J.KW = pc.cin, pc.cin_pad, pc.kh, pc.kw
-    fmt = 0 if pc._small() else ops.w_format()
+    fmt = 0 if (pc._small() or pc.force_f32) else ops.w_format()
     dfmt = ops.w_format()
     kf = pc.kh * pc.kw * pc.cin_pad
     if need_f:

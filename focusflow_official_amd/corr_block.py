@@ -8,6 +8,7 @@ import torch
 from . import fn, ops
 
 PYRAMID_DTYPES = ("fp32", "fp16")
+_MAX_PYRAMID_BYTES = int(os.environ.get("FF_MAX_PYRAMID_BYTES", str(3900 * 1000 * 1000)))      # (tests lower it to exercise the chunking)
 
 
 class CorrBlock:
@@ -32,6 +33,18 @@ class CorrBlock:
         self.grad_pyr = None
         self._token = None
         fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+        # The lookup kernel addresses the four levels of a pyramid through ONE buffer resource (32-bit byte offsets): a batch
+        # whose pyramid would pass 4 GB - configs[4] beyond 22 pairs: 177 MB of fp16 planes per pair - is built and looked up
+        # in batch chunks, each with its own allocation (inference; a recorded pass keeps one pyramid for its backward).
+        self._chunks = None
+        b, h, w, _ = fmap1.shape
+        per_pair = h * w * sum(ops.TiledPyramid.plane_elems(h, w, l, self.half) for l in range(4)) * (2 if self.half else 4) if fmap1.is_cuda else 0
+        if per_pair * b >= _MAX_PYRAMID_BYTES and b > 1 and not fn.recording(fmap1, fmap2):
+            per = max(1, _MAX_PYRAMID_BYTES // per_pair)
+            self._chunks = [(lo, min(b, lo + per), CorrBlock(fmap1[lo:lo + per], fmap2[lo:lo + per], num_levels, radius, pyramid_dtype))
+                            for lo in range(0, b, per)]
+            self.pyr, self._nk, self._pairs, self._padded = None, num_levels * (2 * radius + 1) ** 2, b, None
+            return
         if fn.recording(fmap1, fmap2):
             self._token = fn.CorrBuildFn.apply(fmap1, fmap2, self, self.half)      # sets self.pyr
         else:
@@ -45,10 +58,10 @@ class CorrBlock:
 
     def batch_slice(self, lo: int, hi: int) -> "CorrBlock":
         """The same pyramid restricted to pairs lo..hi-1 (views, no copy; inference: one update loop per batch slice)."""
-        assert self._token is None, "batch_slice is an inference-only view"
+        assert self._token is None and self._chunks is None, "batch_slice is an inference-only view of an unchunked pyramid"
         q = self.pyr.levels[0].shape[0] // self._pairs
         v = object.__new__(CorrBlock)
-        v.num_levels, v.radius, v.half, v.grad_pyr, v._token = self.num_levels, self.radius, self.half, None, None
+        v.num_levels, v.radius, v.half, v.grad_pyr, v._token, v._chunks = self.num_levels, self.radius, self.half, None, None, None
         v.pyr = ops.TiledPyramid([lv[lo * q:hi * q] for lv in self.pyr.levels], self.pyr.h0, self.pyr.w0, self.pyr.half)
         v._pairs, v._nk, v._padded = hi - lo, self._nk, None
         return v
@@ -56,9 +69,19 @@ class CorrBlock:
     @property
     def corr_pyramid(self):
         """The reference's attribute: [(B*Q, h_l, w_l) fp32 planes] (converted from the tiled storage on demand)."""
+        if self._chunks is not None:
+            return [torch.cat([blk.pyr.rowmajor(l) for _, _, blk in self._chunks], 0) for l in range(self.num_levels)]
         return [self.pyr.rowmajor(l) for l in range(self.num_levels)]
 
     def __call__(self, coords: torch.Tensor, want_taps: bool = False):
+        if self._chunks is not None:
+            assert not want_taps, "taps of a chunked CorrBlock: ask the chunks"
+            if self._padded is None:
+                b, h, w, _ = coords.shape
+                self._padded = torch.zeros((b, h, w, (self._nk + 31) // 32 * 32), dtype=torch.float32, device=coords.device)
+            for lo, hi, blk in self._chunks:
+                ops.corr_lookup_tiled(blk.pyr, coords[lo:hi], out=self._padded[lo:hi][..., :self._nk])
+            return self._padded
         if self._token is not None and not want_taps:
             return fn.LookupFn.apply(self._token, self, coords)
         if want_taps or torch.is_grad_enabled():

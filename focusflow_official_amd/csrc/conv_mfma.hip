@@ -322,6 +322,13 @@ extern "C" int ff_conv2d_fwd(const FFConvParams* pp, void* stream) {
     FF_REQUIRE(p.ep_mode != FF_EP_MOTION_TAIL || split_in, "ff_conv2d_fwd: FF_EP_MOTION_TAIL belongs to convolutions over split-pair inputs");
     FF_REQUIRE(p.y_fmt != FF_FMT_SPLIT || (p.y_fmt_from >= 0 && p.y_fmt_from % 32 == 0 && p.y_ld % 4 == 0 && ff::aligned16(p.y) && !p.res2),
                "ff_conv2d_fwd: split-pair output: y_fmt_from %% 32 == 0, y_ld %% 4 == 0, 16-byte aligned y, no res2");
+    // a pixel's split-pair chunk is 128 bytes = 32 channels: the x1 half of the LAST chunk lies at channels (Cout & ~31) + 16 .. + 31
+    // of the row, so a split output needs room for Cout rounded up to 32 (FF_EP_MOTION_TAIL: Cout + 2) floats per pixel
+    {
+        const int cout_sp = (p.Cout + (p.ep_mode == FF_EP_MOTION_TAIL ? 2 : 0) + 31) / 32 * 32;
+        FF_REQUIRE(p.y_fmt != FF_FMT_SPLIT || p.y_ld >= cout_sp, "ff_conv2d_fwd: split-pair output: y_ld %d < Cout rounded up to 32 channels (%d)", p.y_ld, cout_sp);
+        FF_REQUIRE(!p.y2 || p.y2_ld >= cout_sp, "ff_conv2d_fwd: split-pair second output: y2_ld %d < Cout rounded up to 32 channels (%d)", p.y2_ld, cout_sp);
+    }
     if (p.ep_mode == FF_EP_COORDS) {
         FF_REQUIRE(p.w_format == FF_W_F32 && p.Cout == 2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 && p.groups == 1 &&
                    dlh == 1 && dlw == 1 && p.act == FF_ACT_NONE && !p.res && p.ep_a && p.ep_b && ff::aligned16(p.ep_b) && (reinterpret_cast<uintptr_t>(p.ep_a) & 7) == 0,

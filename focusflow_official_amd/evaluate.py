@@ -15,6 +15,8 @@ not part of the hot path.  Dataset roots default to the reference's relative pat
 """
 import numpy as np
 import torch
+
+from . import ops
 import torch.utils.data as data
 
 from . import datasets
@@ -78,6 +80,7 @@ def evaluate_loader(model, loader, iters, pad_mode=None, sparse=False, device=No
         if padder is not None:
             flow_pr, mask1 = padder.unpad(flow_pr), padder.unpad(mask1)
         meter.add(flow_pr, flow_gt, mask1, valid_gt if sparse else None)
+    ops.guard_check(sync=True)        # the always-on range guard looks at a forward when the next one starts: the last one here
     return meter
 
 

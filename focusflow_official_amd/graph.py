@@ -6,6 +6,8 @@ the host can issue them.  Every libfocusflow_hip entry point only enqueues work 
 hipGraph on ROCm and its graph-aware allocator provides the intermediate buffers."""
 import torch
 
+from . import ops
+
 
 class GraphedForward:
     """Capture `model(image1, image2, mask1, mask2, raft_iters, test_mode=True)` for fixed shapes.
@@ -24,13 +26,29 @@ class GraphedForward:
             for _ in range(warmup):      # packs weights, sets kernel attributes, warms the allocator
                 model(*self.static_in, raft_iters=raft_iters, test_mode=True)
         torch.cuda.current_stream().wait_stream(side)
+        ops.guard_check(sync=True)          # the warm-up forwards decided the routes (exact context convolutions or not): capture those
+        # the always-on range guard inside a graph: the probes go to a static pair of words (zeroed by a captured fill), which
+        # every replay copies to the host for the asynchronous look at the next call
+        self._guard_words = torch.zeros(2, dtype=torch.int32, device=self.static_in[0].device) if ops.RANGE_GUARD else None
+        st = ops._guard_state()
+        st["capture_words"] = self._guard_words
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self.out = model(*self.static_in, raft_iters=raft_iters, test_mode=True)
+        try:
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self.out = model(*self.static_in, raft_iters=raft_iters, test_mode=True)
+        finally:
+            st["capture_words"] = None
 
     def __call__(self, *inputs):
         for dst, src in zip(self.static_in, inputs):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
+        ops.guard_check()                   # (raises if an earlier replay left the split formats' range)
         self.graph.replay()
+        if self._guard_words is not None:
+            ops.guard_queue(self._guard_words, "GraphedForward replay", getattr(self.model, "flow_net", None))
         return self.out
+
+    def check_range(self):
+        """Wait for the replays issued so far and raise if one of them left the fp16-split formats' range (ops: the always-on guard)."""
+        ops.guard_check(sync=True)

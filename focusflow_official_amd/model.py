@@ -77,6 +77,8 @@ class FF_RAFT_FUSION(nn.Module):
     # updates that leave the version counters alone.
     def invalidate_packed(self) -> int:
         from .cce import invalidate_packed
+        # new weights: what earlier forwards showed about the activation range no longer holds (ops: the always-on guard)
+        self.flow_net._guard_hist, self.flow_net._guard_level, self.flow_net._exact_ctx = False, 0.0, False
         return invalidate_packed(self)
 
     def load_state_dict(self, *args, **kwargs):
@@ -121,8 +123,9 @@ class FF_RAFT_FUSION(nn.Module):
             m1 = ops.mask_prepare(MASK_MODES[modal], mask1, image1, self._table)
             m2 = i2 if modal == "context" else ops.prep_input(None, b, h, w, image1, fill=255.0)
         ops.guard_begin(image1.device)       # (raises if an EARLIER forward left the split formats' range: ops.guard_check)
+        self.flow_net._guard_handled = False
         out = self.flow_net(i1, i2, m1, m2, iters=raft_iters, flow_init=flow_init, test_mode=test_mode)
-        ops.guard_end("FF_RAFT_FUSION.forward")
+        ops.guard_end("FF_RAFT_FUSION.forward", owner=self.flow_net, handled=self.flow_net._guard_handled)
         ops.check_range("FF_RAFT_FUSION.forward")      # debug mode FF_CHECK_RANGE=1 only (one host sync)
         return out
 

@@ -262,7 +262,11 @@ def conv2d(xs: Sequence[Tensor], wpack: Tensor, bias: Optional[Tensor], cout: in
     ho = (h + 2 * pad[0] - dilation * (kh - 1) - 1) // stride + 1
     wo = (w + 2 * pad[1] - dilation * (kw - 1) - 1) // stride + 1
     if out is None:
-        out = empty_nhwc(b, ho, wo, (cout + 3) // 4 * 4, x0)[..., :cout] if cout % 4 else empty_nhwc(b, ho, wo, cout, x0)
+        if y_split is not False:      # a split-pair chunk is 32 channels: the buffer holds Cout rounded up to 32 (the x1 half of the last chunk)
+            full = empty_nhwc(b, ho, wo, (cout + 31) // 32 * 32, x0)
+            out = full if full.shape[3] == cout else full[..., :cout]
+        else:
+            out = empty_nhwc(b, ho, wo, (cout + 3) // 4 * 4, x0)[..., :cout] if cout % 4 else empty_nhwc(b, ho, wo, cout, x0)
     p = FFConvParams()
     cin = 0
     for i, x in enumerate(xs):
@@ -548,61 +552,118 @@ def check_range(what: str = "forward pass"):
 
 # ---- the always-on guard ---------------------------------------------------------------------------------------------------
 # Two tensors per forward decide whether a checkpoint / input stays inside the split formats' range: the context encoder's
-# output (no norm behind its last convolution: |x| ~ 700 on the synthetic test weights) and the feature maps the correlation
-# volume is built from.  Their max|x| is measured in every forward (two read-only passes,
-# ff_range_probe: ~15 us), copied to pinned host memory without a synchronisation, and looked at when the NEXT
-# forward starts - or on demand (FF_RAFT_FUSION.check_range(): one host sync): an overflow raises FocusFlowHipError instead
-# of travelling on as inf / NaN flow.  FF_RANGE_GUARD=0 switches it off.
+# output (no norm behind its last convolution: |x| ~ 700 on the synthetic test weights; slot 0) and the feature maps the
+# correlation volume is built from (slot 1).  Their max|x| is measured in every forward (two read-only passes,
+# ff_range_probe: ~15 us).  What happens with the two numbers depends on what is known about the model (`owner` = the RAFT
+# module, which keeps the running maximum of what its forwards have shown):
+#   * CAREFUL forwards - the first one after the weights changed, and every one while the running maximum is within a
+#     factor 4 of the limit - read the words synchronously behind the encoders (one host sync, ~1 ms of lost run-ahead) and
+#     act BEFORE the values meet a split convolution: a context output beyond the limit switches the module to its exact-fp32
+#     route for the convolutions that read it (SepConvGRU.prepare: `_exact_ctx`, sticky, logged) - the flow of THAT forward is
+#     right; feature maps beyond the limit have no local repair (the correlation values they produce overflow the next
+#     layer as well) and raise.
+#   * all other forwards copy the words to pinned host memory without a synchronisation and look at them when the NEXT
+#     forward starts (or on demand: FF_RAFT_FUSION.check_range(), one host sync): a value that jumped past the limit from
+#     below a quarter of it in one step raises FocusFlowHipError then - the flow of that pass was not valid - and arms the
+#     exact route for what follows.
+# The state lives in the per-thread policy object (two models driven from two threads do not see each other's words); hipGraph
+# captures take a caller-provided static word (graph.GraphedForward) and are checked after each replay.
+# Not covered: the encoders' INTERMEDIATE tensors and training tensors (debug mode FF_CHECK_RANGE=1).  FF_RANGE_GUARD=0: off.
 RANGE_GUARD = os.environ.get("FF_RANGE_GUARD", "1") != "0"
-_guard_word = None          # device word of the running forward
-_guard_pending = []         # [(pinned host word, event, what)] of finished forwards, not looked at yet
+GUARD_MARGIN = 4.0
+
+
+def _guard_state():
+    st = policy.__dict__.get("_guard")
+    if st is None:
+        st = policy.__dict__["_guard"] = {"words": None, "pending": [], "capture_words": None}
+    return st
 
 
 def guard_begin(device):
-    global _guard_word
-    _guard_word = None
+    st = _guard_state()
+    st["words"] = None
     if torch.cuda.is_current_stream_capturing():      # (no event queries, host copies or fresh words inside a hipGraph capture)
+        if RANGE_GUARD and st["capture_words"] is not None:
+            st["words"] = st["capture_words"]
+            st["words"].zero_()                         # (a captured fill: every replay starts from zero)
         return
     guard_check()
     if RANGE_GUARD:
-        _guard_word = torch.zeros(1, dtype=torch.int32, device=device)
+        st["words"] = torch.zeros(2, dtype=torch.int32, device=device)
 
 
-def guard_probe(x: Tensor):
-    """max|x| of an NHWC tensor into the running forward's guard word (no copy, no sync)."""
-    if _guard_word is None:
+def guard_probe(x: Tensor, slot: int):
+    """max|x| of an NHWC tensor into slot 0 (context encoder output) / 1 (feature maps) of the running forward's guard words."""
+    w = _guard_state()["words"]
+    if w is None:
         return
-    b, h, w, c = x.shape
-    _hip.call("ff_range_probe", _p(x), _ld(x), b * h * w, c, _p(_guard_word), _stream())
+    b, h, ww, c = x.shape
+    _hip.call("ff_range_probe", _p(x), _ld(x), b * h * ww, c, _p(w[slot:slot + 1]), _stream())
 
 
-def guard_end(what: str):
-    global _guard_word
-    if _guard_word is None:
+def guard_careful(owner) -> bool:
+    """Should this forward read its guard words synchronously (see above)?"""
+    st = _guard_state()
+    if st["words"] is None or torch.cuda.is_current_stream_capturing():
+        return False
+    return (not getattr(owner, "_guard_hist", False)) or getattr(owner, "_guard_level", 0.0) * GUARD_MARGIN >= X_LIMIT
+
+
+def guard_read_now():
+    """(max|context output|, max|feature maps|) of the running forward so far: one host synchronisation."""
+    w = _guard_state()["words"]
+    a, b = w.view(torch.float32).tolist()
+    return a, b
+
+
+def guard_note(owner, m_ctx: float, m_fmap: float):
+    """Fold one forward's maxima into the owner's running level."""
+    m = max(m_ctx, m_fmap) if m_ctx == m_ctx and m_fmap == m_fmap else float("inf")
+    owner._guard_level = max(getattr(owner, "_guard_level", 0.0), m)
+    owner._guard_hist = True
+
+
+def guard_end(what: str, owner=None, handled: bool = False):
+    """End of a forward: queue its words for the asynchronous look (handled: a careful forward has read them already)."""
+    st = _guard_state()
+    w, st["words"] = st["words"], None
+    if w is None or handled or torch.cuda.is_current_stream_capturing():
         return
-    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-    host.copy_(_guard_word, non_blocking=True)
+    guard_queue(w, what, owner)
+
+
+def guard_queue(words: Tensor, what: str, owner=None):
+    host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+    host.copy_(words, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    _guard_pending.append((host, ev, what))
-    _guard_word = None
+    _guard_state()["pending"].append((host, ev, what, owner))
 
 
 def guard_check(sync: bool = False):
     """Look at the guard words of finished forwards (all of them if sync, else those whose copy has arrived)."""
-    while _guard_pending:
-        host, ev, what = _guard_pending[0]
+    pending = _guard_state()["pending"]
+    while pending:
+        host, ev, what, owner = pending[0]
         if not ev.query():
             if not sync:
                 return
             ev.synchronize()
-        _guard_pending.pop(0)
-        m = float(host.view(torch.float32).item())
-        if not (m < X_LIMIT):
-            _guard_pending.clear()
+        pending.pop(0)
+        m_ctx, m_fmap = host.view(torch.float32).tolist()
+        if owner is not None:
+            guard_note(owner, m_ctx, m_fmap)
+        ctx_bad = not (m_ctx < X_LIMIT) and not (getattr(owner, "_exact_ctx", False) and m_ctx < float("inf"))
+        if ctx_bad or not (m_fmap < X_LIMIT):
+            pending.clear()
+            if owner is not None and ctx_bad and m_ctx < float("inf"):
+                owner._exact_ctx = True            # the next forward of this model is right
             raise _hip.FocusFlowHipError(
-                f"{what}: an encoder output reached |x| = {m:.6g}; the fp16-split conv formats need |x| < {X_LIMIT:g} "
-                "(csrc/ff_common.h) - the flow of that pass is not valid.  Run this checkpoint / input with FF_CONV_PRECISION=fp32.")
+                f"{what}: an encoder output reached |x| = {max(m_ctx, m_fmap):.6g}; the fp16-split conv formats need |x| < {X_LIMIT:g} "
+                "(csrc/ff_common.h) - the flow of that pass is not valid.  "
+                + ("The context features' convolutions run on the exact-fp32 route from now on." if ctx_bad and m_fmap < X_LIMIT and m_ctx < float("inf")
+                   else "Run this checkpoint / input with FF_CONV_PRECISION=fp32."))
 
 
 def _zero_stats(s, c, device):

@@ -16,8 +16,10 @@ def _cv_fwd(one, two, out=None, act=0):
     tiles, chunks = b * ((h + 7) // 8) * ((w + 15) // 16), (c + 15) // 16
     splits = min(chunks, 256 // tiles) if (tiles < 128 and chunks >= 4) else 1
     ws = torch.empty(splits * b * h * w * 81, dtype=torch.float32, device=one.device) if splits > 1 else None
-    _hip.call("ff_pwc_costvolume_fwd_ex", _p(one), _ld(one), _p(two), _ld(two), _p(out), _ld(out), b, h, w, c, act, _p(ws), splits,
-              _stream())
+    # (bench.py times these launches: label "pwc_costvolume", note = the launch's algorithmic bytes - both feature maps read once,
+    # the 81 channels written once)
+    ops._timed_call("pwc_costvolume", "ff_pwc_costvolume_fwd_ex", _p(one), _ld(one), _p(two), _ld(two), _p(out), _ld(out), b, h, w, c, act, _p(ws), splits,
+                    _stream(), note=(b * h * w * (2 * c + 81) * 4, (b, h, w, c), splits))
     return out
 
 

@@ -45,6 +45,9 @@ class RAFT(nn.Module):
         self.fnet = BasicParallelFusionLayer(3, mc, output_dim=256, norm_fn="instance", dropout=dropout, cfg=cfg)
         self.cnet = BasicParallelFusionLayer(3, mc, output_dim=hdim + cdim, norm_fn="batch", dropout=dropout, cfg=cfg)
         self.update_block = BasicUpdateBlock(self.corr_levels, self.corr_radius, hidden_dim=hdim)
+        # the always-on range guard's memory of this model (ops.guard_*): running max|x| of the two guarded encoder outputs, and
+        # the sticky repair - the context features' convolutions on the exact-fp32 route
+        self._guard_hist, self._guard_level, self._exact_ctx, self._guard_handled = False, 0.0, False, False
 
     # -- reference API (raft.py:104-148) ------------------------------------
     def freeze_bn(self):
@@ -124,8 +127,27 @@ class RAFT(nn.Module):
             cnet.record_stream(main)
         else:
             cnet = self.cnet(image1, mask1)
-        ops.guard_probe(cnet)           # the always-on range guard: the two encoder outputs (ops.guard_begin)
-        ops.guard_probe(f12)
+        ops.guard_probe(cnet, 0)        # the always-on range guard: the two encoder outputs (ops.guard_begin)
+        ops.guard_probe(f12, 1)
+        if ops.guard_careful(self):     # first forward on these weights, or the range is within a factor 4 of the limit: look NOW
+            m_ctx, m_fmap = ops.guard_read_now()
+            ops.guard_note(self, m_ctx, m_fmap)
+            self._guard_handled = True
+            if not (m_fmap < ops.X_LIMIT) or not (m_ctx < float("inf")):
+                raise _hip.FocusFlowHipError(
+                    f"RAFT.forward: an encoder output reached |x| = {max(m_ctx, m_fmap):.6g}; the fp16-split conv formats need |x| < {ops.X_LIMIT:g} "
+                    "(csrc/ff_common.h).  Feature maps beyond it have no local exact route (the correlation values they produce overflow the "
+                    "next layer as well), and an infinite context output means a layer INSIDE the encoder overflowed.  Run this checkpoint / "
+                    "input with FF_CONV_PRECISION=fp32.")
+            if not (m_ctx < ops.X_LIMIT) and not self._exact_ctx:
+                if fn.recording(cnet):
+                    raise _hip.FocusFlowHipError(
+                        f"RAFT.forward: the context encoder's output reached |x| = {m_ctx:.6g} (limit {ops.X_LIMIT:g}) in a RECORDED pass; the "
+                        "exact-fp32 repair covers inference only.  Train this checkpoint with FF_CONV_PRECISION=fp32.")
+                import warnings
+                warnings.warn(f"FF-RAFT: the context encoder's output reached |x| = {m_ctx:.6g} (limit of the fp16-split conv formats: "
+                              f"{ops.X_LIMIT:g}); the convolutions that read it run on the exact-fp32 MFMA route from now on")
+                self._exact_ctx = True
         taped = fn.recording(cnet)
         if taped:
             net = fn.ActFn.apply(cnet[..., :128], ACT_TANH)
@@ -137,7 +159,7 @@ class RAFT(nn.Module):
             ops.act_copy(cnet[..., 128:], inp, ACT_RELU)
         coords1 = ops.coords_init(b, h8, w8, cnet, flow_init)      # never differentiated (raft.py:216)
         # the context features' share of the GRU gate convolutions does not change over the iterations
-        gru_pre = self.update_block.gru.prepare(inp) if _GRU_CTX_ONCE and (taped or fused_train or not torch.is_grad_enabled()) else None
+        gru_pre = self.update_block.gru.prepare(inp, exact=self._exact_ctx and not taped) if _GRU_CTX_ONCE and (taped or fused_train or not torch.is_grad_enabled()) else None
         if fused_train:
             lp = train_loop.loop_params(self.update_block)
             pre = [t for zq in gru_pre for t in zq]

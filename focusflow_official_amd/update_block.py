@@ -68,13 +68,19 @@ class SepConvGRU(nn.Module):
         self._q_hm = [PackedConv(g.convs, cin_slices=hm) for g in self._q]
         self._zr_ctx = [PackedConv(g.convs, cin_slices=ctx, use_bias=False) for g in self._zr]
         self._q_ctx = [PackedConv(g.convs, cin_slices=ctx, use_bias=False) for g in self._q]
+        # the same in exact-fp32 rows (conv_mfma.hip): the always-on range guard's repair when the context features leave the
+        # fp16-split formats' range (RAFT._exact_ctx)
+        self._zr_ctx32 = [PackedConv(g.convs, cin_slices=ctx, use_bias=False, force_f32=True) for g in self._zr]
+        self._q_ctx32 = [PackedConv(g.convs, cin_slices=ctx, use_bias=False, force_f32=True) for g in self._q]
 
-    def prepare(self, inp):
+    def prepare(self, inp, exact=False):
         """The context features' contribution to z|r and q of both passes, [(zr_pre, q_pre)] x 2.  Recorded passes too:
         autograd then sums the twelve pre-activation gradients that reach each share and runs the share's weight and
-        input gradient ONCE (sum_t inp (x) g_t = inp (x) sum_t g_t)."""
+        input gradient ONCE (sum_t inp (x) g_t = inp (x) sum_t g_t).  exact (inference): the exact-fp32 rows - `inp` has left
+        the split formats' range (RAFT._exact_ctx); the results are fp32 addends of the gates, which saturate."""
         assert inp.shape[3] == 128
-        return [(fn.conv(zc, inp), fn.conv(qc, inp)) for zc, qc in zip(self._zr_ctx, self._q_ctx)]
+        zr, q = (self._zr_ctx32, self._q_ctx32) if exact else (self._zr_ctx, self._q_ctx)
+        return [(fn.conv(zc, inp), fn.conv(qc, inp)) for zc, qc in zip(zr, q)]
 
     def run_split(self, h, hs, motion, pre):
         """Inference on split-pair activations: h fp32 (the element-wise steps read it), hs = the same state as ops.SplitT

@@ -282,6 +282,29 @@ def _lookup_case(ops, pyr_cpu, coords_nchw, half=False):
 
 
 @pytest.mark.parametrize("half", [False, True], ids=["fp32", "fp16"])
+def test_corr_block_in_batch_chunks_beyond_the_4gb_resource(half, monkeypatch):
+    """The lookup kernel addresses a pyramid through one buffer resource (32-bit offsets): a batch whose pyramid would pass
+    4 GB (configs[4] beyond 22 pairs) is built and looked up in batch chunks.  With the limit lowered so that 5 pairs make
+    3 chunks, the lookups equal the unchunked block's bit for bit."""
+    from focusflow_official_amd import corr_block
+    g = torch.Generator().manual_seed(7)
+    b, h, w = 5, 16, 24
+    f1, f2 = (torch.randn(b, h, w, 256, generator=g).to(DEV) for _ in range(2))
+    coords = (orc.coords_grid(b, h, w) + torch.rand(b, 2, h, w, generator=g) * 8 - 4).permute(0, 2, 3, 1).contiguous().to(DEV)
+    with torch.no_grad():
+        whole = corr_block.CorrBlock(f1, f2, pyramid_dtype="fp16" if half else "fp32")
+        assert whole._chunks is None
+        ref = whole(coords).clone()
+        per_pair = h * w * sum(lv.shape[1] for lv in whole.pyr.levels) * (2 if half else 4)
+        monkeypatch.setattr(corr_block, "_MAX_PYRAMID_BYTES", 2 * per_pair + 1)
+        chunked = corr_block.CorrBlock(f1, f2, pyramid_dtype="fp16" if half else "fp32")
+        assert chunked._chunks is not None and [(lo, hi) for lo, hi, _ in chunked._chunks] == [(0, 2), (2, 4), (4, 5)]
+        assert torch.equal(chunked(coords), ref)
+        for a, c in zip(chunked.corr_pyramid, whole.corr_pyramid):
+            assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "fp16"])
 @pytest.mark.parametrize("h,w", [(48, 64), (46, 62), (16, 24), (17, 19), (68, 120)])
 def test_lookup_taps_bit_exact_and_values(ops, h, w, half):
     g = torch.Generator().manual_seed(w)
@@ -542,31 +565,32 @@ def test_reduced_precision_mode_end_to_end_epe_against_the_references_tf32_level
 def test_check_range_debug_mode_reports_activations_beyond_the_split_format(det_sd):
     """FF_CHECK_RANGE=1 / ops.CHECK_RANGE: the fp16-split conv formats read x as f16(4 x) + residual, so |x| >= 16376
     becomes inf - silently, apart from a NaN flow.  The debug mode measures max|x| of every forward conv input and the model
-    raises at the end of the pass; the same weights pass cleanly, and with the check off nothing is measured."""
+    raises at the end of the pass; the same weights pass cleanly, and with the check off nothing is measured.  The always-on
+    guard (ops.guard_*) sees the same pass through its two probes: asynchronously while the model's history says the range
+    is far away, synchronously (inside the forward) once it is not."""
     from focusflow_official_amd import _hip, ops as hops
     m = _model(det_sd)
     inp = [t.to(DEV) for t in orc.shifted_pair(1, 128, 160, seed=2)]
     hops.CHECK_RANGE = True
     try:
         with torch.no_grad():
-            m(*inp, raft_iters=2, test_mode=True)                      # in range: no error
-            with torch.no_grad():
-                m.flow_net.cnet.norm1.weight.mul_(2.0e4)                # folded BatchNorm scale: activations of ~1e4 .. 1e5
-            m.invalidate_packed()
+            m(*inp, raft_iters=2, test_mode=True)                      # in range: no error (first forward on these weights: a careful one)
+            m.check_range()
+            assert m.flow_net._guard_hist and 1.0 < m.flow_net._guard_level < hops.X_LIMIT / hops.GUARD_MARGIN
+            # an in-place change that the packed-weight caches follow by themselves (version counters): the guard keeps its history,
+            # so the next forward is NOT careful
+            m.flow_net.cnet.norm1.weight.mul_(2.0e4)                    # folded BatchNorm scale: activations of ~1e4 .. 1e5
             with pytest.raises(_hip.FocusFlowHipError, match="16376"):
-                m(*inp, raft_iters=2, test_mode=True)
+                m(*inp, raft_iters=2, test_mode=True)                  # the debug mode raises at the end of the pass
     finally:
         hops.CHECK_RANGE = False
-    # The always-on guard (ops.guard_*: max|x| of the two encoder outputs, every forward, no synchronisation) saw the same
-    # pass: it raises on demand or when the next forward starts - never silently returns the inf / NaN flow.
+    # the always-on guard saw the same pass: it raises on demand or when the next forward starts - never silently returns the flow
     with pytest.raises(_hip.FocusFlowHipError, match="16376"):
         m.check_range()
-    with torch.no_grad():
-        m(*inp, raft_iters=2, test_mode=True)                          # debug check off: this call itself returns ...
-        with pytest.raises(_hip.FocusFlowHipError, match="16376"):
-            torch.cuda.synchronize()
-            m(*inp, raft_iters=2, test_mode=True)                      # ... and the next one reports it
-    hops._guard_pending.clear()
+    # ... and the model's running level is beyond the limit now: every forward looks at its words before it goes on
+    with torch.no_grad(), pytest.raises(_hip.FocusFlowHipError, match="16376"):
+        m(*inp, raft_iters=2, test_mode=True)
+    hops._guard_state()["pending"].clear()
     monkey_guard = hops.RANGE_GUARD
     hops.RANGE_GUARD = False
     try:
@@ -575,6 +599,33 @@ def test_check_range_debug_mode_reports_activations_beyond_the_split_format(det_
         m.check_range()
     finally:
         hops.RANGE_GUARD = monkey_guard
+
+
+def test_context_output_beyond_the_split_range_is_repaired_on_the_exact_route(det_sd):
+    """The reference has no activation range (fp32 everywhere, ff_raft.py:142-145 scales only the inputs).  A checkpoint whose
+    context encoder ends in large values - here its last convolution scaled x 50: |x| ~ 35 000 against the split formats'
+    16 376 - is caught by the always-on guard in the first forward on those weights, BEFORE the values meet a split
+    convolution: the context features' share of the GRU gates (the only reader) runs on the exact-fp32 MFMA route, a warning is
+    logged, the flow of that very forward matches the oracle; later forwards keep the route without further synchronisation."""
+    from focusflow_official_amd import ops as hops
+    sd = {k: v.clone() for k, v in det_sd.items()}
+    for k in ("flow_net.cnet.conv2.weight", "flow_net.cnet.conv2.bias"):
+        sd[k] *= 50.0
+    m = _model(sd)
+    inp = orc.shifted_pair(1, 128, 160, seed=3)
+    with torch.no_grad():
+        with pytest.warns(UserWarning, match="exact-fp32"):
+            lo, up = m(*[t.to(DEV) for t in inp], raft_iters=4, test_mode=True)
+        assert m.flow_net._exact_ctx and m.flow_net._guard_level >= hops.X_LIMIT
+        ref_lo, ref_up = orc.ffraft_forward(sd, *inp, raft_iters=4, test_mode=True)
+        close(up.cpu(), ref_up, rtol=0, atol=1e-3, what="flow_up with the repaired context share")
+        close(lo.cpu(), ref_lo, rtol=0, atol=1e-3, what="flow_low with the repaired context share")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                              # the second forward: same route, nothing new to say
+            lo2, up2 = m(*[t.to(DEV) for t in inp], raft_iters=4, test_mode=True)
+        assert torch.equal(up2, up)
+    m.check_range()
 
 
 def test_gru_steps_in_the_conv_epilogues_are_bit_identical(det_sd, monkeypatch):

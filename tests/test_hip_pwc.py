@@ -43,6 +43,27 @@ def test_cost_volume_forward_backward(b, c, h, w):
     close(nchw(td.grad), two.grad, what="grad two")
 
 
+def test_cost_volume_hand_derived_known_answers():
+    """The HIP cost volume against cases written down from the formula of correlation.py:46-98 (generating script with the
+    derivation: tests/golden/make_golden_pwc_known_answers.py): one-hot features -> exactly one non-zero value in the channel
+    of that displacement, all-ones -> the in-image indicator (zero padding), a coordinate ramp -> displaced coordinates
+    (channel k -> k + 1 moves +1 in x, k -> k + 9 moves +1 in y).  These pin channel order, sign and borders without either
+    restatement of the kernel."""
+    from conftest import load_golden
+    from focusflow_official_amd import pwc
+    g = load_golden("pwc_costvolume_known")
+    for n in sorted({k.rsplit(".", 1)[0] for k in g}):
+        one, two, top = (torch.from_numpy(g[n + s]) for s in (".one", ".two", ".top"))
+        c = one.shape[1]
+        pad = (-c) % 4                                   # the kernels read channels in groups of four: zero channels add nothing ...
+        o4 = torch.nn.functional.pad(one, (0, 0, 0, 0, 0, pad))
+        t4 = torch.nn.functional.pad(two, (0, 0, 0, 0, 0, pad))
+        out = nchw(pwc.FunctionCorrelation(nhwc(o4), nhwc(t4))) * ((c + pad) / c)      # ... but the mean is over the padded count
+        close(out, top, tol=1e-6, what=n)
+        if n.startswith("A_") and "outside" not in n:
+            assert int((out != 0).sum()) == 1, n
+
+
 def test_cost_volume_properties_full_size():
     """BASELINE config 4 level-2 size (112x256, C=32): displacement structure."""
     from focusflow_official_amd import pwc

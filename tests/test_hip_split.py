@@ -273,6 +273,28 @@ def test_split_inputs_fail_loudly_where_no_kernel_reads_them(ops):
         ops.conv2d([xs, nhwc(x)], _pack(ops, torch.randn(64, 128, 3, 3, generator=g), 128), None, 64, 3, 3, 1, (1, 1), w_fmt=1)   # mixed formats
 
 
+def test_split_outputs_need_room_for_whole_chunks(ops):
+    """A split-pair output row holds whole 32-channel chunks: 48 channels in a 48-wide buffer would put the x1 half of the
+    second chunk into the next pixel - the C ABI refuses it, ops.conv2d allocates the padded buffer."""
+    from focusflow_official_amd._hip import FocusFlowHipError
+    g = torch.Generator().manual_seed(3)
+    x = nhwc(torch.randn(1, 64, 8, 16, generator=g))
+    w = _pack(ops, torch.randn(48, 64, 3, 3, generator=g) / 24, 64)
+    tight = torch.empty(1, 8, 16, 48, device=DEV)
+    with pytest.raises(FocusFlowHipError, match="rounded up to 32"):
+        ops.conv2d([x], w, None, 48, 3, 3, 1, (1, 1), w_fmt=1, y_split=True, out=tight)
+    xs = ops.split_copy(x)
+    with pytest.raises(FocusFlowHipError, match="rounded up to 32"):
+        ops.conv2d([xs], w, None, 48, 3, 3, 1, (1, 1), w_fmt=1, y_split=True, out=tight)
+    sp = ops.conv2d([x], w, None, 48, 3, 3, 1, (1, 1), w_fmt=1, y_split=True)          # allocates 64 channels per pixel
+    assert sp.t.stride(2) == 64
+    plain = ops.conv2d([x], w, None, 48, 3, 3, 1, (1, 1), w_fmt=1)
+    wide = torch.zeros(1, 8, 16, 64, device=DEV)
+    wide[..., :48] = plain
+    got = ops.split_copy(sp.t.as_strided((1, 8, 16, 64), (8 * 16 * 64, 16 * 64, 64, 1)), to_split=False)
+    close(got[..., :48].cpu(), plain.cpu(), rtol=0, atol=1e-5, what="48-channel split-pair output")
+
+
 @pytest.mark.parametrize("size", [(1, 128, 160, 4), (2, 136, 200, 3), (1, 384, 512, 12)])
 def test_forward_with_and_without_split_activations(det_sd, size, monkeypatch):
     """The whole forward: split-pair activations in the update block on (default) and off give the same flow; both sit

@@ -54,6 +54,20 @@ def test_bench_launches_its_own_ranks_without_torchrun():
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["shard"] == [0, 8] and d["ms_per_step"] >= 19.0
 
 
+@pytest.mark.parametrize("flags,graph", [(["--graph"], True), ([], True), (["--eager"], False)])
+def test_two_ranks_replay_a_graph_by_default_and_still_emit_one_line(flags, graph):
+    """Multi-rank forward steps are replayed from a hipGraph unless --eager (host-independent ranks); the launcher, the
+    sharding and the single JSON line do not change with the flag."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0", "--harness-selftest"] + flags
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["shard"] == [0, 8] and d["hipgraph"] is graph
+
+
 def test_self_launch_propagates_a_rank_failure():
     """No GPU here: the forward bench must fail in every rank, and the launcher must return non-zero instead of hanging."""
     import torch

@@ -364,3 +364,22 @@ def test_pwc_cost_volume_two_independent_restatements_agree(b, c, h, w):
     # the volume is not symmetric in its arguments: swapping them mirrors the displacement
     k2 = corr_c.pwc_costvolume_kernel(two.numpy(), one.numpy())
     assert np.abs(k2 - k).max() > 1e-3
+
+
+def test_pwc_cost_volume_hand_derived_known_answers():
+    """Channel order, displacement sign and zero padding of the FF-PWC cost volume, pinned by cases written down from the
+    formula of correlation.py:46-98 (tests/golden/make_golden_pwc_known_answers.py: one-hot features -> one-hot displacement
+    channel, all-ones -> the in-image indicator, a coordinate ramp -> the displaced coordinates) - independently of the two
+    restatements, which both have to reproduce them exactly."""
+    from oracle import corr_c, pwc_ref
+    g = load_golden("pwc_costvolume_known")
+    names = sorted({k.rsplit(".", 1)[0] for k in g})
+    assert len(names) == 6
+    for n in names:
+        one, two, top = g[n + ".one"], g[n + ".two"], g[n + ".top"]
+        a = pwc_ref.cost_volume(torch.from_numpy(one), torch.from_numpy(two)).numpy()
+        k = corr_c.pwc_costvolume_kernel(one, two)
+        np.testing.assert_allclose(a, top, rtol=0, atol=1e-5 * max(1.0, float(np.abs(top).max())), err_msg=n + " (pwc_ref.cost_volume)")
+        np.testing.assert_allclose(k, top, rtol=0, atol=1e-5 * max(1.0, float(np.abs(top).max())), err_msg=n + " (corr_oracle.c)")
+        if n.startswith("A_") and "outside" not in n:
+            assert np.count_nonzero(a) == 1 and np.count_nonzero(k) == 1, n

@@ -26,9 +26,11 @@ for k, c in allc.items():
     out = []
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         out.append(f"matrix pipe busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (c['GRBM_GUI_ACTIVE'] / 8) * 100:.1f} % of the kernel's cycles")
-    if "SQ_INSTS_VALU_MFMA_MOPS_F16" in c and "SQ_INSTS_VALU" in c:
+    if c.get("SQ_INSTS_VALU_MFMA_MOPS_F16") and "SQ_INSTS_VALU" in c:      # (a kernel without MFMAs - the lookup - has the counter at 0)
         flop = c["SQ_INSTS_VALU_MFMA_MOPS_F16"] * 512
         out.append(f"{flop / 1e9:.2f} GFLOP of f16 MFMA; vector instructions (MFMAs included) per 16 384-FLOP MFMA {c['SQ_INSTS_VALU'] / (flop / 16384):.2f}")
+    elif "SQ_INSTS_VALU" in c and "SQ_WAVES" in c and c["SQ_WAVES"]:
+        out.append(f"no MFMA; {c['SQ_INSTS_VALU'] / c['SQ_WAVES']:.1f} vector instructions per wave")
     if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
         out.append(f"LDS bank conflicts {c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'] * 100:.1f} % of the LDS-active cycles")
     if "TCC_EA0_RDREQ_sum" in c:
