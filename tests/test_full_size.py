@@ -47,6 +47,50 @@ def test_config3_training_step_8x368x496_it12(det_sd):
     assert torch.isfinite(gn) and gn > 0
 
 
+def test_config3_gradients_8x368x496_it12_against_cpu_autograd(det_sd):
+    """The per-GPU share of BASELINE configs[2] - EIGHT pairs of 368 x 496, 12 iterations - through forward and backward, the
+    gradients of sixteen named parameters against CPU autograd through the oracle (fp32, one run: ~1 min on the box's host
+    cores).  The one-pair test below cannot see a cross-sample slip of a backward kernel (a batch stride, a per-image table
+    indexed by the wrong image, the T x B stacking of the recorded update loop); here every sample contributes a different
+    gradient and a slip shows up as O(1) of the tensor's maximum.  Bound: 2e-2 of the maximum (the whole-network rule of
+    test_hip_backward._check_grad_spread - the test weights make the recurrence ill-conditioned, see there)."""
+    from focusflow_official_amd import FF_RAFT_FUSION
+    from test_hip_backward import _cfg, _oracle_grads
+    m = FF_RAFT_FUSION(use_fusion="parallel", fusion_channels=256, fuse_cnet=True, cfg=_cfg())
+    m.load_state_dict(det_sd, strict=True)
+    m = m.to(DEV).train()
+    m.flow_net.freeze_bn()
+    b, h, w, iters = 8, 368, 496, 12
+    inp = orc.shifted_pair(b, h, w, seed=61)
+    gen = torch.Generator().manual_seed(62)
+    flow_gt = (torch.randn(b, 2, h, w, generator=gen) * 5).clamp(-400, 400)
+    valid = torch.ones(b, h, w)
+    loss_fn = lambda preds: orc.sequence_l1(preds, flow_gt.to(preds[0]), valid.to(preds[0]))[0]  # noqa: E731
+    preds = m(*[t.to(DEV) for t in inp], raft_iters=iters)
+    loss = loss_fn(preds)
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(16)
+    g32, last32 = _oracle_grads(det_sd, inp, iters, loss_fn, torch.float32)
+    err = float((preds[-1].detach().cpu() - last32).abs().max())
+    assert err <= 2e-3, f"last prediction: {err:.3e} px from the oracle's fp32 run"
+    params = dict(m.named_parameters(remove_duplicate=False))
+    names = ["flow_net.fnet.conv1.weight", "flow_net.fnet.layer1.0.conv1.weight", "flow_net.fnet.layer2.0.conv2.weight", "flow_net.fnet.conv2.weight",
+             "flow_net.fnet.fusion3.img2mask.conv.weight", "flow_net.cnet.layer2.0.downsample.0.weight", "flow_net.cnet.norm1.weight",
+             "flow_net.cnet.mask_layer3.0.conv1.weight", "flow_net.update_block.encoder.convc1.weight", "flow_net.update_block.encoder.convf1.weight",
+             "flow_net.update_block.encoder.conv.weight", "flow_net.update_block.gru.convq1.weight", "flow_net.update_block.gru.convz2.weight",
+             "flow_net.update_block.flow_head.conv1.weight", "flow_net.update_block.flow_head.conv2.weight", "flow_net.update_block.mask.2.weight"]
+    report = []
+    for name in names:
+        got, want = params[name].grad.cpu().double(), g32[name].double()
+        scale = float(want.abs().max())
+        rel = float((got - want).abs().max()) / scale
+        report.append(f"{name}: {rel:.2e} of max")
+    print("\n".join(report))
+    for name, line in zip(names, report):
+        assert float(line.split(": ")[1].split(" ")[0]) <= 2e-2, "\n".join(report)
+
+
 def test_full_resolution_backward_1x368x496_it12_against_cpu_autograd(det_sd):
     """The backward at FULL resolution (one FlyingChairs-sized pair, 12 iterations, frozen BatchNorm as train.py:192-193
     runs the later stages): loss, last prediction and sampled parameter gradients against CPU autograd through the oracle
