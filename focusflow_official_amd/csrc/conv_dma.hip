@@ -63,6 +63,9 @@ constexpr unsigned OOB = 0x7fffffffu;     // + any soffset < 2^31 stays below 2^
 // one LDS-DMA piece: 64 lanes x 16 bytes -> 1 KB at LDS address `dst` (M0), source = rsrc base + voff + soff
 __device__ __forceinline__ void dma_piece(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned dst, unsigned soff) {
     unsigned keep;
+    // (uniform values: when the scalar registers run short the allocator parks them in a vector register, which these operands do not take)
+    dst = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
+    soff = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                  "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
