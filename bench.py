@@ -773,8 +773,7 @@ def main():
         n_lookups = lk[0]
         per_launch_ms = lk[1] / max(1, n_lookups) * 1e-3
         per_q = LOOKUP_BYTES_PER_QUERY[args.pyramid]
-        # queries per LAUNCH from the launches actually seen: one lookup per iteration covers the rank's whole batch,
-        # unless the opt-in FF_UPDATE_SPLIT runs the loop on batch slices (then every launch covers a slice)
+        # queries per LAUNCH from the launches actually seen (one lookup per iteration covers the rank's whole batch)
         timed_steps = 1 if args.graph else args.steps
         q = int(round(q * args.iters * timed_steps / max(1, n_lookups)))
         achieved = per_q * q / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0

@@ -21,12 +21,12 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 EPS = 1e-5
 
 
-_NORM_ON_LOAD = os.environ.get("FF_NORM_ON_LOAD", "1") != "0"      # measurement switch (ResidualBlock conv2 normalises while loading)
+_NORM_ON_LOAD = True      # ResidualBlock conv2 normalises while loading (inference; tests compare with the materialised route)
 
 
 _ALL_PACKED = weakref.WeakSet()      # every PackedConv alive: prepack() finds the ones of a model here
-_DMA_FRAG = os.environ.get("FF_DMA_FRAG", "1") != "0"   # A/B switch: fragment-order weights for the split-pair convolutions
-_PREPACK = os.environ.get("FF_PREPACK", "1") != "0"     # A/B switch: all stale weight layouts of a training step in one launch
+_DMA_FRAG = True          # fragment-order weights for conv_dma.hip
+_PREPACK = True           # all stale weight layouts of a training step in one launch (tests switch it off to compare)
 _serial = [0]
 
 
@@ -311,7 +311,7 @@ def train_streams() -> bool:
     if v is not None:
         return v != "0"
     return not (torch.distributed.is_available() and torch.distributed.is_initialized())
-_BRANCH_STREAMS = os.environ.get("FF_BRANCH_STREAMS", "1") != "0"   # mask branch of the CCE encoder on a side stream (inference)
+_BRANCH_STREAMS = True    # mask branch of the CCE encoder on a side stream
 _branch_streams = {}
 
 
@@ -322,14 +322,8 @@ def _branch_stream(device):
     return _branch_streams[key]
 
 
-# Split-pair activations inside the eval-BatchNorm (context) encoder's residual blocks: OPT-IN (FF_ENC_SPLIT=1).  Built, tested and
-# measured in round 4: 601.7 -> 604-606 pairs/s end to end (inside the noise), and per layer a wash at 8 x 192 x 256 x 64 - conv_dma.hip
-# saves the second convolution of a block 10 us of 109, the first one pays 13 us for writing the format as 2-byte stores from
-# conv_patch.hip's one-channel-per-lane epilogue (tools/conv_table.py: 11.7 ms of convolutions per step without, 12.4 with).
-_ENC_SPLIT = os.environ.get("FF_ENC_SPLIT", "0") == "1"
-_ENC_DUAL = os.environ.get("FF_ENC_DUAL", "0") == "1"
 _FUSION_PAIR = os.environ.get("FF_FUSION_PAIR", "1") != "0"   # fusion units 1-3 as ff_fusion_pair_fwd launches with lazy normalised inputs (inference; A/B switch)
-_PAIR_FUSION = os.environ.get("FF_PAIR_FUSION", "1") != "0"   # both 1x1 convs of a fusion unit in one launch (inference)
+_PAIR_FUSION = True       # both 1x1 convs of a fusion unit in one launch where ff_fusion_pair_fwd has no instance (inference)
 
 
 def invalidate_packed(module: nn.Module) -> int:
@@ -628,39 +622,9 @@ class BasicParallelFusionLayer(nn.Module):
             x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
         return self._conv_norm(y, blk._p2, blk.norm2, ACT_RELU, res=x, lazy=lazy_out and self.norm_fn == "instance" and not torch.is_grad_enabled())
 
-    def _split_ok(self, blk: ResidualBlock):
-        """Eval-mode BatchNorm (the context encoder at inference): scale / shift ride in the conv epilogues, so every
-        activation between the block's 3x3 convolutions is final when it is stored - it can leave in the split-pair format
-        (ops.SplitT) and the consumer runs on conv_dma.hip, as in the update block.  Not with InstanceNorm: its
-        coefficients exist only after the whole plane, the consumer normalises raw fp32 values while it loads them."""
-        p2 = blk._p2
-        return (_ENC_SPLIT and self.norm_fn == "batch" and not blk.norm1.training and not blk.norm2.training and not torch.is_grad_enabled()
-                and ops.w_format() in (_hip.W_F16X3, _hip.W_F16) and (p2.kh, p2.kw, p2.stride) == (3, 3, 1) and p2.cin % 32 == 0 and p2.cout % 32 == 0
-                and blk._p1.cout % 32 == 0)
-
-    def _block_split(self, blk: ResidualBlock, x, xs, want_split):
-        """One residual block with split-pair activations inside: x fp32 (the residual), xs its split-pair copy or None ->
-        (y fp32, y split-pair or None).  Same arithmetic as _block: the two formats give a convolution the same bits."""
-        p1, p2 = blk._p1, blk._p2
-        sc1, sh1 = ops.bn_fold(blk.norm1)
-        sc2, sh2 = ops.bn_fold(blk.norm2)
-        dma1 = xs is not None and (p1.kh, p1.kw, p1.stride) == (3, 3, 1) and p1.cin % 32 == 0
-        t = p1(xs if dma1 else x, act=ACT_RELU, ch_scale=sc1, ch_shift=sh1, y_split=True)
-        if blk.downsample is not None:
-            x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
-        if want_split:
-            return p2(t, act=ACT_RELU, ch_scale=sc2, ch_shift=sh2, res=x, act_res=ACT_RELU, y2_split=True)
-        return p2(t, act=ACT_RELU, ch_scale=sc2, ch_shift=sh2, res=x, act_res=ACT_RELU), None
-
     def _run_stage(self, stage, x, lazy_out=False):
         if lazy_out:
             return self._block(stage[1], self._block(stage[0], x), True)
-        if self._split_ok(stage[0]) and self._split_ok(stage[1]):
-            # (_ENC_DUAL: block 0 also writes its output as a split pair so that block 1's first convolution runs conv_dma.hip
-            # too.  Measured per layer at 8 x 192 x 256 x 64: the second output costs conv2 47 us (152 against 105), the DMA
-            # route saves conv1 10 (99 against 109) - off.)
-            y, ys = self._block_split(stage[0], x, None, _ENC_DUAL)
-            return self._block_split(stage[1], y, ys, False)[0]
         return self._block(stage[1], self._block(stage[0], x))
 
     def _branches(self, fm, fx, m, x):

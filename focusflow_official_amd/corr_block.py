@@ -56,16 +56,6 @@ class CorrBlock:
         self._pairs = fmap1.shape[0]
         self._padded = None
 
-    def batch_slice(self, lo: int, hi: int) -> "CorrBlock":
-        """The same pyramid restricted to pairs lo..hi-1 (views, no copy; inference: one update loop per batch slice)."""
-        assert self._token is None and self._chunks is None, "batch_slice is an inference-only view of an unchunked pyramid"
-        q = self.pyr.levels[0].shape[0] // self._pairs
-        v = object.__new__(CorrBlock)
-        v.num_levels, v.radius, v.half, v.grad_pyr, v._token, v._chunks = self.num_levels, self.radius, self.half, None, None, None
-        v.pyr = ops.TiledPyramid([lv[lo * q:hi * q] for lv in self.pyr.levels], self.pyr.h0, self.pyr.w0, self.pyr.half)
-        v._pairs, v._nk, v._padded = hi - lo, self._nk, None
-        return v
-
     @property
     def corr_pyramid(self):
         """The reference's attribute: [(B*Q, h_l, w_l) fp32 planes] (converted from the tiled storage on demand)."""

@@ -398,7 +398,7 @@ extern "C" int ff_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, 
     const bool vec = C % 4 == 0 && Cpad % 4 == 0 && dy_ld % 4 == 0 && g_ld % 4 == 0 && ff::aligned16(dy) && ff::aligned16(g) &&
                      (act == FF_ACT_NONE || (y_ld % 4 == 0 && ff::aligned16(y))) && npix * (Cpad / 4) < (1ll << 31);
     // (four items per thread and trip; at most FF_ACT_BWD_BLOCKS blocks: every block ends in an atomicMax on ONE word)
-    static const int cap = getenv("FF_ACT_BWD_BLOCKS") ? atoi(getenv("FF_ACT_BWD_BLOCKS")) : 512;
+    static const int cap = ff::tune_env("FF_ACT_BWD_BLOCKS") ? atoi(ff::tune_env("FF_ACT_BWD_BLOCKS")) : 512;
     const int gv = (int)std::min<long long>(std::max<long long>((npix * (Cpad / 4) + 1023) / 1024, 1), cap);
     if (vec && act == FF_ACT_NONE)
         act_bwd_vec_kernel<false><<<gv, 256, 0, static_cast<hipStream_t>(stream)>>>(dy, dy_ld, y, y_ld, g, g_ld, (unsigned)npix, C, Cpad, act, scale, amax);
@@ -438,7 +438,7 @@ extern "C" int ff_norm_bwd(const float* x, int x_ld, const float* dy, int dy_ld,
     norm_bwd_stats_kernel<<<g1, 256, 0, s>>>(a);
     int gx = (int)(((long long)HW * (C / 4) + 255) / 256);
     // at most ~FF_NORM_BWD_BLOCKS blocks in all when max|dx| is wanted: every block then ends in an atomicMax on ONE word
-    static const int cap = getenv("FF_NORM_BWD_BLOCKS") ? atoi(getenv("FF_NORM_BWD_BLOCKS")) : 1024;
+    static const int cap = ff::tune_env("FF_NORM_BWD_BLOCKS") ? atoi(ff::tune_env("FF_NORM_BWD_BLOCKS")) : 1024;
     const int gmax = dx_amax ? std::max(1, cap / B) : 1024;
     if (gx > gmax) gx = gmax;
     norm_bwd_apply_kernel<<<dim3(gx, B), 256, 0, s>>>(a);

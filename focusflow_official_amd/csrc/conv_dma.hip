@@ -571,7 +571,7 @@ int launch_tile(DArgs& a, int th, hipStream_t s) {
     a.n_tiles = (a.p.Cout + (a.p.ep_mode == FF_EP_MOTION_TAIL ? 2 : 0) + 63) / 64;
     if (th == 8) {
         // 3x3 and 5x1: two 23-24 KB patch buffers, three blocks per CU; 1x5: two 20 KB buffers, four
-        if constexpr (KH == 1) { static const bool occ4 = !(getenv("FF_DMA_OCC4") && atoi(getenv("FF_DMA_OCC4")) == 0); if (occ4) return launch_ep<KH, KW, 8, 1, TERMS, 4>(a, s); }
+        if constexpr (KH == 1) { static const bool occ4 = !(ff::tune_env("FF_DMA_OCC4") && atoi(ff::tune_env("FF_DMA_OCC4")) == 0); if (occ4) return launch_ep<KH, KW, 8, 1, TERMS, 4>(a, s); }
         return launch_ep<KH, KW, 8, 1, TERMS, 3>(a, s);
     }
     return launch_ep<KH, KW, 4, 1, TERMS, 4>(a, s);      // (five waves per SIMD would cap the registers at 96: the 5x1 instances spill)
@@ -621,7 +621,7 @@ F32Route f32_route(const FFConvParams& p, int cin) {
     // every layer routed, the encoders' included), with two or three chunks per tile it loses (64 -> 64 at 16 x 192 x 256: 215
     // against 203 us, 96 -> 96: 144 against 136): a tile of two chunks is over before the first patch's round trip and the
     // epilogue's stores are paid off, and conv_patch.hip hides them with four blocks per CU.  FF_DMA_F32_MINCH overrides (A/B).
-    static const int min_chunks = getenv("FF_DMA_F32_MINCH") ? atoi(getenv("FF_DMA_F32_MINCH")) : 4;
+    static const int min_chunks = ff::tune_env("FF_DMA_F32_MINCH") ? atoi(ff::tune_env("FF_DMA_F32_MINCH")) : 4;
     if (cin / 32 < min_chunks) return no;
     long long max_bytes = (long long)(p.Cout + 15) * ((p.KH * p.KW * cin + 31) / 32) * 128;
     for (int i = 0; i < FF_MAX_SEG && p.x_c[i]; ++i) {
@@ -755,7 +755,7 @@ int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s) {
     // "All channels" layout (launch_allch): where 6 x 16 tiles give about one block per CU - the update block's 3x3 layers at
     // 8 pairs: 256 blocks.  More tiles than CUs would run as rounds of one block per CU with nothing to overlap the prologue and
     // epilogue phases: the 64-channel blocks (three per CU, out of phase) are better there.  FF_DMA_ALLCH=0: A/B switch.
-    static const bool allch_on = !(getenv("FF_DMA_ALLCH") && atoi(getenv("FF_DMA_ALLCH")) == 0);
+    static const bool allch_on = !(ff::tune_env("FF_DMA_ALLCH") && atoi(ff::tune_env("FF_DMA_ALLCH")) == 0);
     const long long tiles6 = (long long)p.B * ((p.H + 5) / 6) * a.tiles_x;
     if (allch_on && k33 && !getenv("FF_DMA_TILE") && tiles6 >= 192 && tiles6 <= 272 && (p.ep_mode == FF_EP_NONE || p.ep_mode == FF_EP_MOTION_TAIL)) {
         const int ct = (couts + 15) / 16;          // 16-channel tiles
@@ -763,7 +763,7 @@ int conv2d_fwd_dma(const FFConvParams& p, int cin, hipStream_t s) {
         if (ct > 4 && ct <= 8) return t3 ? launch_allch<1, 8, 3, 2>(a, s) : launch_allch<1, 8, 1, 2>(a, s);
         // 512 channels (the flow / mask heads): two 16-wave blocks of 256 channels per tile, one block per CU at a time at four
         // waves per SIMD (16 waves x TWO channel tiles each spills at the 128 registers that leaves)
-        static const bool heads16 = !(getenv("FF_DMA_HEADS16") && atoi(getenv("FF_DMA_HEADS16")) == 0);
+        static const bool heads16 = !(ff::tune_env("FF_DMA_HEADS16") && atoi(ff::tune_env("FF_DMA_HEADS16")) == 0);
         if (heads16 && ct > 16 && ct <= 32) return t3 ? launch_allch<1, 16, 3, 4>(a, s) : launch_allch<1, 16, 1, 4>(a, s);
     }
     if (k33) return t3 ? launch_tile<3, 3, 3>(a, th, s) : launch_tile<3, 3, 1>(a, th, s);

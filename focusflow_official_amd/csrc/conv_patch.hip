@@ -573,7 +573,7 @@ int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
     // 16-24 % faster on the small shape (tools/proto/mfma_shape.hip), but the whole kernel is not bound by its matrix
     // loop: per-layer times are equal within 1 % (12.70 vs 12.73 ms of convolutions per step) and the normalise-on-load
     // variant spills (+13 % on its layers).
-    static const bool mf16 = getenv("FF_MFMA16") && atoi(getenv("FF_MFMA16")) == 1;
+    static const bool mf16 = ff::tune_env("FF_MFMA16") && atoi(ff::tune_env("FF_MFMA16")) == 1;
     if (a.p.stats_part) {        // partial InstanceNorm statistics of the output from the epilogue (validated by the caller)
         if (a.p.in_scale) conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, true, false, false, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
         else conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, false, false, false, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
@@ -603,7 +603,7 @@ int launch_occ(const PArgs& a, size_t lds, hipStream_t s) {
         splitk_finish_kernel<<<(unsigned)std::min<long long>((total + 255) / 256, 2048), 256, 0, s>>>(a.p, splits, npix);
         return ff::check_launch("ff_conv2d_fwd(patch, split-K)");
     }
-    static const bool pin = !(getenv("FF_PATCH_PIN") && atoi(getenv("FF_PATCH_PIN")) == 0);      // A/B switch
+    static const bool pin = !(ff::tune_env("FF_PATCH_PIN") && atoi(ff::tune_env("FF_PATCH_PIN")) == 0);      // A/B switch
     if (a.p.in_scale) {          // normalise-on-load variant
         conv_patch_kernel_occ<TERMS, NITEM, TM, TN, OCC, true, 0, true><<<(unsigned)blocks, 256, lds, s>>>(a);
         return ff::check_launch("ff_conv2d_fwd(patch)");
@@ -670,8 +670,8 @@ int launch(const PArgs& a, size_t lds, hipStream_t s) {
 namespace ff {
 // returns FF_OK if launched, 1 if the shape is not eligible (caller falls back to conv_split)
 int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
-    static const bool enabled = !getenv("FF_NO_PATCH_CONV");
-    static const bool dbg = getenv("FF_DEBUG_DISPATCH") != nullptr;
+    static const bool enabled = !ff::tune_env("FF_NO_PATCH_CONV");
+    static const bool dbg = ff::tune_env("FF_DEBUG_DISPATCH") != nullptr;
     if (dbg) fprintf(stderr, "[ff] patch? en=%d stride=%d dil=%d,%d groups=%d k=%dx%d pad=%d,%d cin=%d xc=%d,%d,%d fmt=%d\n", (int)enabled, p.stride,
                      p.dil_h, p.dil_w, p.groups, p.KH, p.KW, p.pad_h, p.pad_w, cin, p.x_c[0], p.x_c[1], p.x_c[2], p.w_format);
     if (!enabled) return 1;
@@ -697,8 +697,8 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     // block at 1/8 resolution: 4 rows).  The larger register tiles (FF_PATCH_TH=16: 256 pixels; FF_PATCH_TN=2: 128
     // channels) exist for measurement only - they halve weight or LDS traffic per MFMA but run at 2 blocks per CU and
     // lose 13-18 %.
-    static const int force_th = getenv("FF_PATCH_TH") ? atoi(getenv("FF_PATCH_TH")) : 0;
-    static const int force_tn = getenv("FF_PATCH_TN") ? atoi(getenv("FF_PATCH_TN")) : 0;
+    static const int force_th = ff::tune_env("FF_PATCH_TH") ? atoi(ff::tune_env("FF_PATCH_TH")) : 0;
+    static const int force_tn = ff::tune_env("FF_PATCH_TN") ? atoi(ff::tune_env("FF_PATCH_TN")) : 0;
     auto nblocks = [&](int th, int tn) { return (long long)p.B * ((p.H + th - 1) / th) * a.tiles_x * ((p.Cout + 64 * tn - 1) / (64 * tn)); };
     int th = nblocks(8, 1) < 512 ? 4 : 8, tn = 1;
     if (force_th) th = force_th;
@@ -706,13 +706,13 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     a.tiles_y = (p.H + th - 1) / th;
     a.n_tiles = (p.Cout + 64 * tn - 1) / (64 * tn);
     const int npix = (th + p.KH - 1) * (TW + p.KW - 1);
-    static const int lds_pad = getenv("FF_PATCH_LDS_PAD") ? atoi(getenv("FF_PATCH_LDS_PAD")) : 0;   // occupancy experiments
+    static const int lds_pad = ff::tune_env("FF_PATCH_LDS_PAD") ? atoi(ff::tune_env("FF_PATCH_LDS_PAD")) : 0;   // occupancy experiments
     const int nitem = (npix * 8 + 255) / 256;
     const bool t3 = p.w_format == FF_W_F16X3;
     // Occupancy is what this kernel responds to (3 -> 2 blocks per CU: +15-25 % time; 3 -> 4: -5-10 %): with ONE weight
     // buffer (a second barrier per tap instead) the 8-row tile needs 35 KB of LDS and the 4-row tile 25 KB, so 4 / 5
     // blocks fit a CU once the registers are capped to match (amdgpu_waves_per_eu).
-    static const int wb1 = getenv("FF_PATCH_WB1") ? atoi(getenv("FF_PATCH_WB1")) : 3;   // bit 0: 8-row tiles, bit 1: 4-row tiles
+    static const int wb1 = ff::tune_env("FF_PATCH_WB1") ? atoi(ff::tune_env("FF_PATCH_WB1")) : 3;   // bit 0: 8-row tiles, bit 1: 4-row tiles
     // (the one-term reduced-precision mode runs the same high-occupancy variants: 496 -> 559 pairs/s end to end)
     const bool occ = (t3 || p.w_format == FF_W_F16) && tn == 1 && ((th == 8 && nitem <= 6 && (wb1 & 1)) || (th == 4 && nitem <= 4 && (wb1 & 2)));
     const size_t lds = ((npix * ROWP + 255) & ~255) + (occ ? 1 : 2) * 64 * tn * ROWP + lds_pad;
@@ -728,7 +728,7 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
     // split-pair output (y_fmt; y2 belongs to split-pair inputs = conv_dma.hip): the 32x32x16 epilogue of the high-occupancy
     // variants writes it; everything else declines (the im2col kernel takes the convolution)
     if (p.y_fmt != FF_FMT_F32) {
-        static const bool mf16 = getenv("FF_MFMA16") && atoi(getenv("FF_MFMA16")) == 1;
+        static const bool mf16 = ff::tune_env("FF_MFMA16") && atoi(ff::tune_env("FF_MFMA16")) == 1;
         if (!occ || p.ep_mode || p.splitk > 1 || mf16) return 1;
     }
     // split-K (FFConvParams.splitk, see conv2d_splitk_hint): the 4-row high-occupancy variant only
@@ -757,7 +757,7 @@ int conv2d_fwd_patch(const FFConvParams& p, int cin, hipStream_t s) {
 // caller runs ff_norm_stats over the output instead).  Same eligibility and tile choice as conv2d_fwd_patch's
 // high-occupancy variants: 2 entries (one per wave row) per 8x16 / 4x16 tile.
 int conv2d_stats_parts(const FFConvParams& p, int cin) {
-    static const bool enabled = !getenv("FF_NO_PATCH_CONV") && !(getenv("FF_CONV_STATS") && atoi(getenv("FF_CONV_STATS")) == 0);
+    static const bool enabled = !ff::tune_env("FF_NO_PATCH_CONV") && !(getenv("FF_CONV_STATS") && atoi(getenv("FF_CONV_STATS")) == 0);
     if (!enabled || (p.w_format != FF_W_F16X3 && p.w_format != FF_W_F16) || p.res2 || p.ep_mode || p.x_amax) return 0;
     const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
     if (p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1) return 0;
@@ -765,7 +765,7 @@ int conv2d_stats_parts(const FFConvParams& p, int cin) {
     if (cin % 32) return 0;
     for (int i = 0; i < FF_MAX_SEG; ++i)
         if (p.x_c[i] % 32) return 0;
-    if (getenv("FF_PATCH_TH") || getenv("FF_PATCH_TN") || getenv("FF_PATCH_WB1")) return 0;
+    if (ff::tune_env("FF_PATCH_TH") || ff::tune_env("FF_PATCH_TN") || ff::tune_env("FF_PATCH_WB1")) return 0;
     long long max_bytes = (long long)p.Cout * ((p.KH * p.KW * cin + 31) / 32) * ROWB;
     for (int i = 0; i < FF_MAX_SEG; ++i)
         if (p.x_c[i]) max_bytes = std::max(max_bytes, (long long)p.B * p.H * p.W * p.x_ld[i] * 4);
@@ -782,7 +782,7 @@ int conv2d_stats_parts(const FFConvParams& p, int cin) {
 // conv2d_fwd_patch's 4-row variant; worth it when the plane is so small that the blocks do not even cover the CUs and
 // the reduction is long: every split needs >= 2 chunks, the grid is brought to ~768 blocks at most.
 int conv2d_splitk_hint(const FFConvParams& p, int cin) {
-    static const bool enabled = !getenv("FF_NO_PATCH_CONV") && !(getenv("FF_SPLITK") && atoi(getenv("FF_SPLITK")) == 0);
+    static const bool enabled = !ff::tune_env("FF_NO_PATCH_CONV") && !(ff::tune_env("FF_SPLITK") && atoi(ff::tune_env("FF_SPLITK")) == 0);
     if (!enabled || p.w_format != FF_W_F16X3 || p.in_scale || p.res2) return 0;
     const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
     if (p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1) return 0;

@@ -352,7 +352,7 @@ int launch_u(const KernArgs& a, hipStream_t s) {
     k.m_tiles = (a.M + BM - 1) / BM;
     k.n_tiles = (a.p.Cout + BN - 1) / BN;
     dim3 grid(k.m_tiles * k.n_tiles, a.p.groups);
-    static const int occ = getenv("FF_SPLIT_OCC") ? atoi(getenv("FF_SPLIT_OCC")) : 1;
+    static const int occ = ff::tune_env("FF_SPLIT_OCC") ? atoi(ff::tune_env("FF_SPLIT_OCC")) : 1;
     if constexpr (NST == 1 && WM == 2 && TM == 2 && TN == 1) {
         if (occ) {
             conv_split_kernel_occ<WM, WN, TM, TN, TERMS, UNI, 4><<<grid, 256, lds / 2, s>>>(k);
@@ -372,7 +372,7 @@ int launch_u(const KernArgs& a, hipStream_t s) {
 template <int WM, int WN, int TM, int TN, int TERMS, int NST>
 int launch_n(const KernArgs& a, hipStream_t s) {
     const FFConvParams& p = a.p;
-    static const bool allow = !getenv("FF_SPLIT_NO_UNI");
+    static const bool allow = !ff::tune_env("FF_SPLIT_NO_UNI");
     bool uni = allow && a.Cin % 32 == 0 && p.KH * p.KW <= 64;
     long long max_bytes = (long long)p.Cout * a.w_row_bytes;
     for (int i = 0; i < FF_MAX_SEG; ++i) {
@@ -388,7 +388,7 @@ int launch(const KernArgs& a, hipStream_t s) {
     // Ring depth 1 = plain double buffering.  Depth 3 was measured SLOWER end to end for the 128-row
     // tiles (200+ registers -> 2 blocks/CU instead of 3) and +3% for the 64x64 tile; FF_SPLIT_NST
     // overrides for tuning runs.
-    static const int nst = getenv("FF_SPLIT_NST") ? atoi(getenv("FF_SPLIT_NST")) : (TM * TN == 1 ? 3 : 1);
+    static const int nst = ff::tune_env("FF_SPLIT_NST") ? atoi(ff::tune_env("FF_SPLIT_NST")) : (TM * TN == 1 ? 3 : 1);
     if (nst >= 3) return launch_n<WM, WN, TM, TN, TERMS, 3>(a, s);
     if (nst == 2) return launch_n<WM, WN, TM, TN, TERMS, 2>(a, s);
     return launch_n<WM, WN, TM, TN, TERMS, 1>(a, s);
@@ -398,7 +398,7 @@ template <int TERMS>
 int dispatch(const KernArgs& a, hipStream_t s) {
     const FFConvParams& p = a.p;
     const long long M = a.M, g = p.groups;
-    static const int force = getenv("FF_SPLIT_TILE") ? atoi(getenv("FF_SPLIT_TILE")) : -1;   // tuning only
+    static const int force = ff::tune_env("FF_SPLIT_TILE") ? atoi(ff::tune_env("FF_SPLIT_TILE")) : -1;   // tuning only
     if (force == 0) return launch<2, 2, 1, 1, TERMS>(a, s);
     if (force == 1) return launch<2, 2, 2, 1, TERMS>(a, s);
     if (force == 2) return launch<2, 2, 2, 2, TERMS>(a, s);
@@ -407,7 +407,7 @@ int dispatch(const KernArgs& a, hipStream_t s) {
     // (blocks per CU) beats tile size: the 128x128 three-term tile needs 270 registers = 1 block/CU and
     // measured 1.8x slower end to end than 128x64 (3 blocks/CU).  Keep 128x128 for the 1-term mode only.
     auto blocks = [&](int bm, int bn) { return g * ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
-    static const bool big1 = getenv("FF_SPLIT_F16_128") && atoi(getenv("FF_SPLIT_F16_128")) == 1;     // one-term mode: the 128 x 128 tile lost to 128 x 64 at 4 blocks per CU (391 vs 224 us on the 1x1 fusion convs)
+    static const bool big1 = ff::tune_env("FF_SPLIT_F16_128") && atoi(ff::tune_env("FF_SPLIT_F16_128")) == 1;     // one-term mode: the 128 x 128 tile lost to 128 x 64 at 4 blocks per CU (391 vs 224 us on the 1x1 fusion convs)
     if (big1 && TERMS == 1 && p.Cout > 96 && (p.Cout % 128 == 0 || p.Cout > 192) && blocks(128, 128) >= 512) return launch<2, 2, 2, 2, TERMS>(a, s);
     if (p.Cout > 64 && p.Cout <= 96 && blocks(128, 96) >= 512) return launch<4, 1, 1, 3, TERMS>(a, s);
     if (blocks(128, 64) >= 512) return launch<2, 2, 2, 1, TERMS>(a, s);

@@ -241,7 +241,7 @@ namespace ff {
 // Which convolutions take this route: 7x7, stride 2, padding 3, one NHWC4 segment, f16x3 rows, Cout <= 64, no activation or
 // relu, no residual / normalise-on-load / gradient scale / GRU epilogue / K split.
 static bool stem_eligible(const FFConvParams& p, int cin) {
-    static const bool enabled = !(getenv("FF_STEM_CONV") && atoi(getenv("FF_STEM_CONV")) == 0);
+    static const bool enabled = !(ff::tune_env("FF_STEM_CONV") && atoi(ff::tune_env("FF_STEM_CONV")) == 0);
     const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
     return enabled && p.w_format == FF_W_F16X3 && p.groups == 1 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad_h == 3 && p.pad_w == 3 &&
            dlh == 1 && dlw == 1 && cin == 4 && p.x_c[0] == 4 && p.x_c[1] == 0 && p.x_ld[0] % 4 == 0 && p.Cout <= 64 && !p.res && !p.res2 &&
@@ -264,9 +264,9 @@ int conv2d_fwd_stem(const FFConvParams& p, int cin, hipStream_t s) {
     if (total >= (1ll << 31)) return 1;
     a.total_tiles = (int)total;
     a.w_row_bytes = (long long)((7 * 7 * 4 + 31) / 32) * 128;
-    static const int per_cu = getenv("FF_STEM_BLOCKS_PER_CU") ? atoi(getenv("FF_STEM_BLOCKS_PER_CU")) : 2;
+    static const int per_cu = ff::tune_env("FF_STEM_BLOCKS_PER_CU") ? atoi(ff::tune_env("FF_STEM_BLOCKS_PER_CU")) : 2;
     const int blocks = (int)std::min<long long>(total, 256ll * std::max(1, per_cu));
-    static const int late = getenv("FF_STEM_LATE") ? atoi(getenv("FF_STEM_LATE")) : 3;      // bit 0: statistics variant, bit 1: plain
+    static const int late = ff::tune_env("FF_STEM_LATE") ? atoi(ff::tune_env("FF_STEM_LATE")) : 3;      // bit 0: statistics variant, bit 1: plain
     if (p.stats_part) {
         if (late & 1) conv_stem_kernel<true, true><<<blocks, 256, 0, s>>>(a);
         else conv_stem_kernel<true, false><<<blocks, 256, 0, s>>>(a);

@@ -232,7 +232,7 @@ int launch(const WpArgs& a, size_t lds, int splits, hipStream_t s) {
 namespace ff {
 // returns FF_OK if launched, 1 if the shape is not eligible (the caller falls back to conv_wgrad_split.hip)
 int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hipStream_t s) {
-    static const bool enabled = !(getenv("FF_WGRAD_PATCH") && atoi(getenv("FF_WGRAD_PATCH")) == 0);
+    static const bool enabled = !(ff::tune_env("FF_WGRAD_PATCH") && atoi(ff::tune_env("FF_WGRAD_PATCH")) == 0);
     if (!enabled || p.w_format != FF_W_F16X3) return 1;
     const int dlh = p.dil_h ? p.dil_h : 1, dlw = p.dil_w ? p.dil_w : 1;
     if (p.stride != 1 || dlh != 1 || dlw != 1 || p.groups != 1) return 1;
@@ -257,7 +257,7 @@ int conv2d_wgrad_patch(const FFConvParams& p, float* dw, float* db, int cin, hip
     // Pixel splits: at most one resident wave of blocks (2 per CU: every block ends in NT x 16 atomic wave-instructions and
     // restages from scratch, so more, shorter blocks lost 10-25 % in tools/wgrad_table.py), and the fewest blocks that
     // keep the longest block's tile count.
-    static const int target = getenv("FF_WGRAD_PATCH_BLOCKS") ? atoi(getenv("FF_WGRAD_PATCH_BLOCKS")) : 512;   // tuning knob
+    static const int target = ff::tune_env("FF_WGRAD_PATCH_BLOCKS") ? atoi(ff::tune_env("FF_WGRAD_PATCH_BLOCKS")) : 512;   // tuning knob
     int splits = std::max(1, std::min(a.tiles, target / combos));
     a.tiles_per_block = (a.tiles + splits - 1) / splits;
     splits = (a.tiles + a.tiles_per_block - 1) / a.tiles_per_block;

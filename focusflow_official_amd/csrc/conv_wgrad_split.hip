@@ -244,7 +244,7 @@ int launch(WsArgs& a, int M, hipStream_t s) {
     const long long tiles = (long long)a.n1_tiles * a.n2_tiles;
     // every block ends in BN1 x BN2 fp32 atomics: as many blocks as the chip holds at once (2 per CU at 72 KB of LDS), not
     // more - 1 536 blocks cost the 1x1 and 7x7 layers 30-50 % (tools/wgrad_table.py: 17.8 -> 16.3 ms per step in total)
-    static const int target = getenv("FF_WGRAD_BLOCKS") ? atoi(getenv("FF_WGRAD_BLOCKS")) : 512;   // tuning knob
+    static const int target = ff::tune_env("FF_WGRAD_BLOCKS") ? atoi(ff::tune_env("FF_WGRAD_BLOCKS")) : 512;   // tuning knob
     int splits = (int)((target + tiles - 1) / tiles);
     if (splits > nchunks) splits = nchunks;
     if (splits < 1) splits = 1;
@@ -276,7 +276,7 @@ int conv2d_wgrad_split(const FFConvParams& p, float* dw, float* db, int M, int c
     a.Cin = cin;
     a.K = p.KH * p.KW * cin;
     // a 128-row tile of output channels would be half empty for Cout <= 64 (and 3/4 full for 96): go wide in k instead
-    static const int tile = getenv("FF_WGRAD_TILE") ? atoi(getenv("FF_WGRAD_TILE")) : 0;   // tuning: 1 = 128x64, 2 = 128x128 always
+    static const int tile = ff::tune_env("FF_WGRAD_TILE") ? atoi(ff::tune_env("FF_WGRAD_TILE")) : 0;   // tuning: 1 = 128x64, 2 = 128x128 always
     if (p.Cout <= 64) return launch<64, 128>(a, M, s);
     // 128 x 128 pays where the tile is full and the reduction long (tools/wgrad_table.py: 256 -> 192 3x3 181 -> 158 us,
     // 128 -> 512 3x3 196 -> 181, 96 -> 96 3x3 159 -> 140); narrow or short problems lose blocks and run 15-50 % slower

@@ -448,7 +448,7 @@ extern "C" int ff_corr_build(const void* f1_split, const void* f2_split, void* c
     }
     hipEvent_t ev0, ev1;          // null unless ff_launch_timing_begin(FF_TIME_CORR_BUILD) is in effect
     ff::launch_timing_events(FF_TIME_CORR_BUILD, &ev0, &ev1);
-    static const int lds_pad = getenv("FF_CORR_BUILD_LDS_PAD") ? atoi(getenv("FF_CORR_BUILD_LDS_PAD")) : 0;   // occupancy experiments
+    static const int lds_pad = ff::tune_env("FF_CORR_BUILD_LDS_PAD") ? atoi(ff::tune_env("FF_CORR_BUILD_LDS_PAD")) : 0;   // occupancy experiments
     if (lds_pad) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_build_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + lds_pad);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_build_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + lds_pad);

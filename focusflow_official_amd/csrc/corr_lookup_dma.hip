@@ -430,9 +430,9 @@ int lookup_dma_fwd(const void* const* levels, int half, const float* coords, lon
     a.out_bytes = (unsigned)out_bytes;
     a.out_ld = out_ld;
     // one wave per block; 16 blocks per CU with two buffers (9.5 KB of LDS each), 11 with three (14 KB)
-    static const int env_wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 0;
-    static const int env_depth = getenv("FF_LOOKUP_DEPTH") ? atoi(getenv("FF_LOOKUP_DEPTH")) : 1;      // A/B switch
-    static const int env_bw = getenv("FF_LOOKUP_BLOCK_WAVES") ? atoi(getenv("FF_LOOKUP_BLOCK_WAVES")) : 1;
+    static const int env_wpc = ff::tune_env("FF_LOOKUP_WAVES_PER_CU") ? atoi(ff::tune_env("FF_LOOKUP_WAVES_PER_CU")) : 0;
+    static const int env_depth = ff::tune_env("FF_LOOKUP_DEPTH") ? atoi(ff::tune_env("FF_LOOKUP_DEPTH")) : 1;      // A/B switch
+    static const int env_bw = ff::tune_env("FF_LOOKUP_BLOCK_WAVES") ? atoi(ff::tune_env("FF_LOOKUP_BLOCK_WAVES")) : 1;
 #ifdef FF_LAB      // timing-only ablations (WRONG results): lab build only (tools/build_lab.sh), not in libfocusflow_hip.so
     const char* abl_s = getenv("FF_LOOKUP_ABLATE3");
     const int abl = abl_s ? atoi(abl_s) : 0;

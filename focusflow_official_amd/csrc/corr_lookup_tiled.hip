@@ -1,14 +1,8 @@
-// CorrBlock.__call__ (corr.py:29-50 + bilinear_sampler, utils.py:57-71) on the TILED pyramid of corr_layout.h,
-// fp32 or fp16 storage, 4 levels, radius 4; and its backward (scatter into tiled fp32 gradient planes) plus the pooling
-// backward chain on tiled planes.
-//
-// Forward: ONE WAVE PER QUERY, software-pipelined as the row-major kernel was (taps -> window loads in flight during the
-// previous query's blend -> LDS -> blend), but a window is fetched as whole 128-byte tiles: the 11 x 11 values a level
-// needs lie in 2-3 x 3-4 tiles (fp32, 8 x 4) or 2-3 x 2-3 tiles (fp16, 8 x 8) instead of 11-15 row pieces of 128-byte
-// lines.  4 lanes fetch one tile (32 bytes each); the tile range is computed from the taps actually needed (offset -4 ..
-// offset +4, +1), tiles outside the plane are zeros (grid_sample's zero padding), elements of an edge tile beyond the
-// plane are zero in memory (the builders guarantee it).  The coordinate arithmetic is the separately rounded fp32 replay
-// of corr.hip (tap indices bit-identical to the reference).
+// CorrBlock.__call__ (corr.py:29-50 + bilinear_sampler, utils.py:57-71) on the TILED pyramid of corr_layout.h: the entry point
+// of the forward (the kernel is corr_lookup_dma.hip's; the round-2 tile-fetching kernel that lived here was its fallback for
+// pyramids beyond one 4 GB buffer resource - CorrBlock now builds such batches in chunks, and it is gone), the BACKWARD
+// (scatter into tiled fp32 gradient planes) and the pooling backward chain on tiled planes.  The coordinate arithmetic is
+// the separately rounded fp32 replay of corr.hip (tap indices bit-identical to the reference).
 #pragma clang fp contract(off)
 #include <cstdlib>
 #include "ff_common.h"
@@ -18,17 +12,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-struct TLookupArgs {
-    const char* lvl[4];
-    long long plane_bytes[4];
-    int h[4], w[4], ntx[4], nty[4];
-    const float* coords;
-    float* out;
-    int* taps;
-    long long queries;
-    int out_ld;
-};
 
 // One separately-rounded replay of the sampler's coordinate chain (corr.py:41-43, utils.py:61-62, ATen's un-normalise).
 __device__ __forceinline__ void tap_1d(float c, float inv_scale, int off, int n, int& i0, float& w1) {
@@ -40,191 +23,6 @@ __device__ __forceinline__ void tap_1d(float c, float inv_scale, int off, int n,
     const float f = floorf(u);
     i0 = (int)f;
     w1 = __fsub_rn(u, f);
-}
-
-// LDS window of one level, row-major, THREE tile columns wide (a window spans at most 3): fp32 16 rows x 24 columns at a
-// 112-byte pitch, fp16 24 rows x 24 columns at an 80-byte pitch.  The pitch is what keeps the blend's reads nearly
-// conflict-free: 32 lanes read a block of ~9 rows x 4 columns, and with 28 (20) dwords per row consecutive rows start
-// 4 banks apart, so only rows 8 apart share banks (at the natural 32 / 16 dwords per row every row started on the same
-// bank: a 9-way conflict that cost more than all the arithmetic of the kernel).  1.8 KB (1.9 KB) per level keeps the
-// block under 10 KB of LDS: 16 one-wave blocks per CU.
-constexpr int LVL_BYTES = 1920;
-
-
-struct __attribute__((aligned(8))) TapEntry {      // 8 bytes: one ds_read_b64 (the LDS pipe is this kernel's busiest unit)
-    int off;        // byte offset of tap 0 in the level window (x: column part, y: level base + row part)
-    float w1;       // fractional weight of tap 1; tap 0 weighs 1 - w1 (ATen: separately rounded subtraction)
-};
-
-// Instruction count is what bounds this kernel (one wave per query, ~24 queries per SIMD at B = 8), next to the number
-// of cache lines a load instruction touches (a version whose lanes each fetched a whole tile - 64 lines per
-// instruction - ran slower than one with twice the instructions).  So:
-//   taps     lanes 0..35 = (level, offset) replay the x- and y- tap chains and publish, per axis, ONE 16-byte table
-//            entry (window offset of tap 0, weight, 1 - weight); tap 1 is the next element of the row-major window.
-//   staging  a level's window is at most 3 x 4 (fp32) / 3 x 3 (fp16) tiles inside a fixed 4 x 4 slot grid anchored at
-//            the tile of tap (-4, -4).  Eight lanes fetch one tile (16 bytes each), one load instruction = 8 whole
-//            128-byte lines = two tile rows of one level, 8 instructions per query.  The level is fixed per instruction,
-//            so the window geometry sits in scalar registers.  Slots past the window re-read the window's edge tile (no
-//            extra traffic), tiles outside the plane's tile grid become zeros (grid_sample's zero padding).  Elements
-//            of an edge tile beyond the plane are zero in memory (ff_corr_build / ff_corr_retile guarantee it).  The
-//            tiles are written to LDS UN-tiled (row-major window), so the blend needs one address per output.
-//   blend    324 outputs = 2 table reads + 2 two-element LDS reads + 11 separately rounded fp32 ops each.
-// ABL: timing-only ablation bits (FF_LOOKUP_ABLATE, WRONG results): 1 no output stores, 2 no window loads, 4 no blend,
-// 8 no tap chains after the first query, 16 no window stores to LDS.  A template parameter: as run-time tests inside the
-// blend they cost the fp16 kernel 60 % (43 instead of 26 us).
-template <bool HALF, int ABL = 0>
-__global__ __launch_bounds__(64) void lookup_tiled_kernel(const TLookupArgs a) {
-    constexpr int TSH = HALF ? 3 : 2;      // log2(tile height)
-    constexpr int ESZ = HALF ? 2 : 4;
-    constexpr int MAXR = HALF ? 3 : 4;     // tile rows a window can span
-    constexpr int PITCH = HALF ? 80 : 112; // window row pitch in bytes (3 tile columns x 8 elements + padding, see LVL_BYTES)
-    __shared__ __attribute__((aligned(16))) char win[4 * LVL_BYTES];
-    __shared__ TapEntry tab[2][2][4][9];   // [buf][axis][level][offset]
-    __shared__ __attribute__((aligned(16))) int geo[2][4][4];           // [buf][level]{tx0, ty0, ntc, ntr}
-    __shared__ __attribute__((aligned(16))) int slot[2][64];            // [buf][lane group g][load i]: tile offset | need
-    const int lane = threadIdx.x;
-    const int t_lv = min(lane / 9, 3), t_o = lane - (lane / 9) * 9;   // tap role (lanes < 36)
-    const float t_inv = 1.f / (float)(1 << t_lv);
-    const int t_h = a.h[0] >> t_lv, t_w = a.w[0] >> t_lv;
-    // staging role: 16-byte piece s_p of tile column s_tc, tile row s_trh (+ 2 for the odd instruction of a level)
-    const int s_p = lane & 7, s_tc = (lane >> 3) & 3, s_trh = lane >> 5;
-    // LDS position of the piece (row-major window): fp32 piece = tile row p >> 1, half p & 1 ; fp16 piece = tile row p
-    const int s_dst = (s_trh << TSH) * PITCH + s_tc * 8 * ESZ + (HALF ? s_p * PITCH : (s_p >> 1) * PITCH + (s_p & 1) * 16);
-    // slot role: lane L prepares ONE of the 64 tile slots of a query - load i = L & 7 (level i >> 1, tile rows
-    // (i & 1) * 2 + {0, 1}) of the eight lanes of group g = L >> 3 (tile row half g >> 2, tile column g & 3) - so that
-    // issue_loads is two table reads and eight and-ors instead of ten vector instructions per load.
-    const int b_lv = (lane & 7) >> 1, b_row = (lane & 1) * 2 + (lane >> 5), b_col = (lane >> 3) & 3;
-    const int b_ntx = a.ntx[b_lv], b_nty = a.nty[b_lv];
-
-    auto publish_taps = [&](long long q, float cx, float cy, int buf) {
-        int x0, y0;
-        float wx, wy;
-        tap_1d(cx, t_inv, t_o - 4, t_w, x0, wx);
-        tap_1d(cy, t_inv, t_o - 4, t_h, y0, wy);
-        const int xlo = __shfl(x0, t_lv * 9), ylo = __shfl(y0, t_lv * 9);            // taps of offset -4
-        const int xhi = __shfl(x0, t_lv * 9 + 8) + 1, yhi = __shfl(y0, t_lv * 9 + 8) + 1;   // last tap read: offset +4, +1
-        const int tx0 = xlo >> 3, ty0 = ylo >> TSH;
-        if (lane < 36) {
-            // window coordinates of tap 0, clamped so that a wild coordinate (and its +1 neighbour) stays inside the window
-            const int wxc = min(max(x0 - tx0 * 8, 0), 22), wyc = min(max(y0 - (ty0 << TSH), 0), (MAXR << TSH) - 2);
-            TapEntry ex, ey;
-            ex.off = wxc * ESZ;
-            ex.w1 = wx;
-            ey.off = t_lv * LVL_BYTES + wyc * PITCH;
-            ey.w1 = wy;
-            tab[buf][0][t_lv][t_o] = ex;
-            tab[buf][1][t_lv][t_o] = ey;
-            if (t_o == 0) {
-                int4 g4 = make_int4(tx0, ty0, min(max((xhi >> 3) - tx0 + 1, 1), 3), min(max((yhi >> TSH) - ty0 + 1, 1), MAXR));
-                *reinterpret_cast<int4*>(&geo[buf][t_lv][0]) = g4;
-            }
-            if (a.taps) {
-                int* t = a.taps + (q * 4 + t_lv) * 18;
-                t[t_o] = x0;
-                t[9 + t_o] = y0;
-            }
-        }
-        // the slot table of this query (same wave: LDS operations complete in program order)
-        const int4 g4 = *reinterpret_cast<const int4*>(&geo[buf][b_lv][0]);
-        const int gtx = g4.x + min(b_col, g4.z - 1), gty = g4.y + min(b_row, g4.w - 1);   // slots past the window re-read its edge
-        const bool in = (unsigned)gtx < (unsigned)b_ntx && (unsigned)gty < (unsigned)b_nty;
-        const int need1 = (b_col < g4.z && b_row < g4.w) ? 1 : 0;
-        slot[buf][lane] = (in ? (gty * b_ntx + gtx) * 128 : 0x7ffffff0) | need1;
-    };
-
-    u32x4 rv[8];         // instruction i = level i >> 1, tile rows (i & 1) * 2 + {0, 1}
-    int se[8];           // slot entries of the loads in flight; bit 0: the tile lies inside the window (only those go to LDS)
-    // Buffer loads over ONE plane (resource = the query's plane of the level, range-checked): a tile outside the plane's
-    // tile grid gets an out-of-range offset and the hardware returns zeros - grid_sample's zero padding without a select.
-    auto issue_loads = [&](long long q, int buf) {
-        const int4 e0 = *reinterpret_cast<const int4*>(&slot[buf][(lane >> 3) * 8]);
-        const int4 e1 = *reinterpret_cast<const int4*>(&slot[buf][(lane >> 3) * 8 + 4]);
-        se[0] = e0.x; se[1] = e0.y; se[2] = e0.z; se[3] = e0.w;
-        se[4] = e1.x; se[5] = e1.y; se[6] = e1.z; se[7] = e1.w;
-#pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char*>(a.lvl[lv] + q * a.plane_bytes[lv]), 0, (int)a.plane_bytes[lv], 0x00020000);
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int off = (ABL & 2) ? 0x7ffffff0 : ((se[lv * 2 + hf] & ~1) | (s_p * 16));          // the out-of-range marker stays out of range
-                rv[lv * 2 + hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-            }
-        }
-    };
-    auto store_window = [&]() {     // the fourth tile column of the slot grid only exists for the loads' lane layout
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (se[i] & 1)           // ntc <= 3, ntr <= MAXR: never the fourth column / a row past the image
-                *reinterpret_cast<u32x4*>(&win[(i >> 1) * LVL_BYTES + (i & 1) * (2 << TSH) * PITCH + s_dst]) = rv[i];
-    };
-
-    // blend roles: output k = lane + 64 j -> (level, ia, ib): loop-invariant table entries
-    int bx[6], by[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int k = min(lane + 64 * j, 323);
-        const int lv = k / 81, rem = k - lv * 81;
-        const int ia = rem / 9, ib = rem - ia * 9;
-        bx[j] = lv * 9 + ia;
-        by[j] = lv * 9 + ib;
-    }
-
-    long long q = blockIdx.x;
-    if (q >= a.queries) return;
-
-    int cur = 0;
-    const float2* cptr = reinterpret_cast<const float2*>(a.coords);
-    publish_taps(q, cptr[q].x, cptr[q].y, 0);
-    __syncthreads();
-    issue_loads(q, 0);
-    // coordinates travel two queries ahead of the blend (their load latency would otherwise sit in front of every tap chain)
-    long long qn = q + gridDim.x;
-    float2 cn = cptr[qn < a.queries ? qn : q];
-    for (;;) {
-        const bool has_next = qn < a.queries;
-        const long long qs = has_next ? qn : q;          // the last round re-stages its own query: nothing under a branch
-        const long long qnn = qn + gridDim.x;
-        const float2 cnn = cptr[qnn < a.queries ? qnn : qs];   // past the end: the query that is re-staged then
-        if (!(ABL & 16)) store_window();                                  // waits for this query's window loads
-        if (!(ABL & 8)) publish_taps(qs, cn.x, cn.y, cur ^ 1);
-        __syncthreads();                                 // win + both table sets visible
-        issue_loads(qs, cur ^ 1);                        // in flight during the blend below
-        float* orow = a.out + q * a.out_ld;
-        const TapEntry* tx = &tab[cur][0][0][0];
-        const TapEntry* ty = &tab[cur][1][0][0];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            if (ABL & 4) break;
-            const TapEntry ex = tx[bx[j]], ey = ty[by[j]];
-            const char* p = &win[ey.off + ex.off];
-            float v00, v01, v10, v11;
-            if (HALF) {
-                v00 = (float)*reinterpret_cast<const _Float16*>(p);
-                v01 = (float)*reinterpret_cast<const _Float16*>(p + 2);
-                v10 = (float)*reinterpret_cast<const _Float16*>(p + PITCH);
-                v11 = (float)*reinterpret_cast<const _Float16*>(p + PITCH + 2);
-            } else {
-                v00 = *reinterpret_cast<const float*>(p);
-                v01 = *reinterpret_cast<const float*>(p + 4);
-                v10 = *reinterpret_cast<const float*>(p + PITCH);
-                v11 = *reinterpret_cast<const float*>(p + PITCH + 4);
-            }
-            // nw*s*e + ne*s*w + sw*n*e + se*n*w  (ATen's weight naming): s = 1 - wy, e = 1 - wx
-            const float e0 = __fsub_rn(1.f, ex.w1), s0 = __fsub_rn(1.f, ey.w1);
-            float o = __fmul_rn(v00, __fmul_rn(s0, e0));
-            o = __fadd_rn(o, __fmul_rn(v01, __fmul_rn(s0, ex.w1)));
-            o = __fadd_rn(o, __fmul_rn(v10, __fmul_rn(ey.w1, e0)));
-            o = __fadd_rn(o, __fmul_rn(v11, __fmul_rn(ey.w1, ex.w1)));
-            if ((j < 5 || lane < 4) && (!(ABL & 1) || o == 12345.678f)) orow[lane + 64 * j] = o;
-        }
-        if (!has_next) break;
-        __syncthreads();                                 // everyone done reading win before it is overwritten
-        q = qn;
-        qn = qnn;
-        cn = cnn;
-        cur ^= 1;
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -578,48 +376,12 @@ extern "C" int ff_corr_lookup_tiled_fwd(const void* const* levels, int half, con
     FF_REQUIRE(levels && coords && out, "ff_corr_lookup_tiled_fwd: null pointer");
     FF_REQUIRE(queries > 0 && out_ld >= 324, "ff_corr_lookup_tiled_fwd: out_ld %d < 324", out_ld);
     FF_REQUIRE((h0 >> 3) >= 2 && (w0 >> 3) >= 2, "ff_corr_lookup_tiled_fwd: level 3 is %dx%d; the sampler divides by (n-1)", h0 >> 3, w0 >> 3);
-    const ff::CorrLayout L = ff::corr_layout(h0, w0, half != 0);
-    TLookupArgs a;
-    fill_levels(L, a.h, a.w, a.ntx, a.nty);
-    for (int l = 0; l < 4; ++l) {
+    for (int l = 0; l < 4; ++l)
         FF_REQUIRE(levels[l] != nullptr && ff::aligned16(levels[l]), "ff_corr_lookup_tiled_fwd: level %d null or misaligned", l);
-        a.lvl[l] = static_cast<const char*>(levels[l]);
-        a.plane_bytes[l] = (long long)L.plane[l] * (half ? 2 : 4);
-    }
-    // round-3 kernel (corr_lookup_dma.hip) whenever the four levels lie within 4 GB of each other (ops.TiledPyramid
-    // allocates them as one buffer); FF_LOOKUP_IMPL=2 keeps the round-2 kernel below (A/B runs, read at every call)
-    {
-        const char* impl = getenv("FF_LOOKUP_IMPL");
-#ifdef FF_LAB
-        const bool lab_old = getenv("FF_LOOKUP_ABLATE") != nullptr;      // the round-2 kernel's ablations: lab build only
-#else
-        constexpr bool lab_old = false;
-#endif
-        if (!(impl && atoi(impl) == 2) && !lab_old) {
-            const int r = ff::lookup_dma_fwd(levels, half, coords, queries, h0, w0, out, out_ld, taps_dbg, static_cast<hipStream_t>(stream));
-            if (r != 1) return r;
-        }
-    }
-    a.coords = coords;
-    a.out = out;
-    a.taps = taps_dbg;
-    a.queries = queries;
-    a.out_ld = out_ld;
-    // one wave per block, 10.1 KB of LDS each: 16 blocks fit a CU
-    static const int wpc = getenv("FF_LOOKUP_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_WAVES_PER_CU")) : 16;
-    const long long blocks = queries < 256ll * wpc ? queries : 256ll * wpc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-#ifdef FF_LAB      // timing-only ablations (WRONG results): lab build only
-    static const int abl = getenv("FF_LOOKUP_ABLATE") ? atoi(getenv("FF_LOOKUP_ABLATE")) : 0;
-#define FF_LK_ABL(V_) if (abl == V_) { if (half) lookup_tiled_kernel<true, V_><<<(unsigned)blocks, 64, 0, s>>>(a); \
-                                       else lookup_tiled_kernel<false, V_><<<(unsigned)blocks, 64, 0, s>>>(a); \
-                                       return ff::check_launch("ff_corr_lookup_tiled_fwd"); }
-    FF_LK_ABL(1) FF_LK_ABL(3) FF_LK_ABL(7) FF_LK_ABL(11) FF_LK_ABL(19) FF_LK_ABL(31)
-#undef FF_LK_ABL
-#endif
-    if (half) lookup_tiled_kernel<true><<<(unsigned)blocks, 64, 0, s>>>(a);
-    else lookup_tiled_kernel<false><<<(unsigned)blocks, 64, 0, s>>>(a);
-    return ff::check_launch("ff_corr_lookup_tiled_fwd");
+    const int r = ff::lookup_dma_fwd(levels, half, coords, queries, h0, w0, out, out_ld, taps_dbg, static_cast<hipStream_t>(stream));
+    FF_REQUIRE(r != 1, "ff_corr_lookup_tiled_fwd: the four levels must lie within 4 GB of each other (one buffer resource; allocate them "
+                       "as ops.TiledPyramid does) with fewer than 2^24 queries per call - build and look up larger batches in chunks (CorrBlock does)");
+    return r;
 }
 
 extern "C" int ff_corr_lookup_tiled_bwd(float* const* dlevels, const float* coords, const float* dout, int dout_ld,
@@ -638,7 +400,7 @@ extern "C" int ff_corr_lookup_tiled_bwd(float* const* dlevels, const float* coor
     a.dout = dout;
     a.dout_ld = dout_ld;
     a.queries = queries;
-    static const int bwd_wpc = getenv("FF_LOOKUP_BWD_WAVES_PER_CU") ? atoi(getenv("FF_LOOKUP_BWD_WAVES_PER_CU")) : 20;
+    static const int bwd_wpc = ff::tune_env("FF_LOOKUP_BWD_WAVES_PER_CU") ? atoi(ff::tune_env("FF_LOOKUP_BWD_WAVES_PER_CU")) : 20;
     const long long blocks = queries < 256ll * bwd_wpc ? queries : 256ll * bwd_wpc;
     lookup_tiled_bwd_kernel<<<(unsigned)blocks, 64, 0, static_cast<hipStream_t>(stream)>>>(a);
     return ff::check_launch("ff_corr_lookup_tiled_bwd");

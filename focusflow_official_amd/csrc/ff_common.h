@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include "focusflow_hip.h"
 
 namespace ff {
@@ -109,6 +110,15 @@ int conv2d_splitk_hint(const FFConvParams& p, int cin);                       //
 // corr_lookup_dma.hip: the LDS-DMA lookup; 1 = not eligible (levels more than 4 GB apart)
 int lookup_dma_fwd(const void* const* levels, int half, const float* coords, long long queries, int h0, int w0, float* out,
                    int out_ld, int* taps_dbg, hipStream_t s);
+
+// Tuning overrides (tile shapes, blocks per CU, launch caps ...): measurements behind every default are in docs/history.md.  They
+// exist in the LAB build only (tools/build_lab.sh: -DFF_LAB); the product library reads none of them, so a stray variable in a
+// shell cannot change what a benchmark measures.  The product's own switches - A/B of shipped routes - use getenv directly.
+#ifdef FF_LAB
+inline const char* tune_env(const char* name) { return getenv(name); }
+#else
+inline const char* tune_env(const char*) { return nullptr; }
+#endif
 
 __host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -417,7 +417,7 @@ extern "C" int ff_mask_upsample_fwd(const float* hid, int hid_ld, const void* w_
         attr = true;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int waves = getenv("FF_MASK_UPSAMPLE_WAVES") ? atoi(getenv("FF_MASK_UPSAMPLE_WAVES")) : 12;     // 12 (default) or 6
+    static const int waves = ff::tune_env("FF_MASK_UPSAMPLE_WAVES") ? atoi(ff::tune_env("FF_MASK_UPSAMPLE_WAVES")) : 12;     // 12 (default) or 6
     if (waves == 12) {
         static bool attr12 = false;
         if (!attr12) {

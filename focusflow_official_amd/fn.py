@@ -178,10 +178,10 @@ def unpack_group(pc, dw: Tensor, db: Tensor) -> List[Optional[Tensor]]:
 
 
 _scope: Optional[GraphScope] = None
-_UNPACK_GROUP = os.environ.get("FF_UNPACK_GROUP", "1") != "0"   # A/B switch: one gradient-unpacking launch per packed convolution
-_LOOKUP_BWD_ALL = os.environ.get("FF_LOOKUP_BWD_ALL", "1") != "0"   # A/B switch: one lookup-backward launch per pass instead of one per iteration
-_ZERO_ARENA = os.environ.get("FF_ZERO_ARENA", "1") != "0"    # A/B switch: one zero fill per pass for the backward's accumulation buffers
-_AMAX_HINT = os.environ.get("FF_AMAX_HINT", "1") != "0"      # A/B switch: the norm backward measures max|dx| for the conv it feeds
+_UNPACK_GROUP = True     # one gradient-unpacking launch per packed convolution (tests switch it off to compare)
+_LOOKUP_BWD_ALL = True   # one lookup-backward launch per pass instead of one per iteration
+_ZERO_ARENA = True       # one zero fill per pass for the backward's accumulation buffers
+_AMAX_HINT = True        # the norm backward measures max|dx| for the conv it feeds
 
 
 def begin_graph(device=None) -> GraphScope:

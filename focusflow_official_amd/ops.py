@@ -523,10 +523,10 @@ def begin_forward(device):
 # kernel the backward uses for its gradient scales) and the model raises at the end of the forward pass that overflowed.
 CHECK_RANGE = os.environ.get("FF_CHECK_RANGE", "0") == "1"
 # InstanceNorm statistics from the producing convolution's epilogue (FFConvParams.stats_part) instead of a pass over its output
-CONV_STATS = os.environ.get("FF_CONV_STATS", "1") != "0"
+CONV_STATS = True
 # ... and in recorded (training) passes: off - at the 46 x 62 planes of the training crop most tiles are ragged (the slow
 # per-pixel branch of the epilogue) and the statistics pass it replaces is short: 70.3 vs 69.6 ms per step (A/B, round 3)
-CONV_STATS_TRAIN = os.environ.get("FF_CONV_STATS_TRAIN", "0") == "1"
+CONV_STATS_TRAIN = False
 X_LIMIT = 16376.0
 _range_word = None
 

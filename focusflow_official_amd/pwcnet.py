@@ -41,7 +41,7 @@ def _pad4(c):
 VOLP, FLP = 96, 16
 
 
-_DIRECT_DECONV = os.environ.get("FF_DIRECT_DECONV", "1") != "0"     # A/B switch: ff_deconv4x4s2_small for netUpflow / netUpfeat
+_DIRECT_DECONV = True     # ff_deconv4x4s2_small for netUpflow / netUpfeat
 
 class _Packed:
     """Packed weights of one conv whose input is a padded-piece buffer: `pieces` = [(real, padded), ...]."""

@@ -10,12 +10,11 @@ from .corr_block import CorrBlock
 from .ops import ACT_RELU, ACT_TANH
 from .update_block import BasicUpdateBlock, split_activations
 
-_COORDS_EPILOGUE = os.environ.get("FF_COORDS_EPILOGUE", "1") != "0"   # A/B switch: coords1 += delta inside the flow head's last convolution (inference)
-_MASK_UPSAMPLE = os.environ.get("FF_MASK_UPSAMPLE", "1") != "0"   # A/B switch: mask conv 2 + convex up-sampling as one kernel (inference)
-_GRU_CTX_ONCE = os.environ.get("FF_GRU_CTX_ONCE", "1") != "0"      # measurement switch (see SepConvGRU.prepare)
-_STREAMS_MIN_PIXELS = int(os.environ.get("FF_STREAMS_MIN_PIXELS", "700000"))   # below: host-bound, the fork / join events cost more than they gain
-_ENC_STREAMS = os.environ.get("FF_ENC_STREAMS", "1") != "0"           # cnet on a second stream beside fnet (inference)
-_UPDATE_SPLIT = int(os.environ.get("FF_UPDATE_SPLIT", "1"))         # experiment: update loop of n batch slices on n streams
+_COORDS_EPILOGUE = True   # coords1 += delta inside the flow head's last convolution (inference)
+_MASK_UPSAMPLE = True     # mask conv 2 + convex up-sampling as one kernel (inference)
+_GRU_CTX_ONCE = True      # the context features' share of the GRU gates once per forward (SepConvGRU.prepare)
+_STREAMS_MIN_PIXELS = int(os.environ.get("FF_STREAMS_MIN_PIXELS", "700000"))   # (a test forces the streams on at its small sizes)   # below: host-bound, the fork / join events cost more than they gain
+_ENC_STREAMS = True       # cnet on a second stream beside fnet
 
 
 class RAFT(nn.Module):
@@ -167,14 +166,6 @@ class RAFT(nn.Module):
                 return list(train_loop.UpdateLoopFn.apply(self.update_block, corr_fn, coords1, iters, net, *pre, fmap1.contiguous(), fmap2.contiguous(), *lp))
             if fn.recording(fmap1, fmap2):      # (not eligible after all: the per-operation tape needs the pyramid on the tape)
                 corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
-        if (_UPDATE_SPLIT > 1 and test_mode and not taped and not torch.is_grad_enabled() and b % _UPDATE_SPLIT == 0
-                and not ops.policy.single_stream and not torch.cuda.is_current_stream_capturing()):
-            # Opt-in (FF_UPDATE_SPLIT=2): the update loop of n batch slices on n streams, the iterations issued alternately.
-            # At 1/8 resolution every kernel of the loop is a 5-90 us launch with several us of ramp; two independent
-            # chains fill each other's: +3 % at 8 pairs per step.  Not the default: every launch of the loop - the lookup
-            # first of all - then covers half the batch, i.e. the kernel the bench's roofline is quoted on runs as two
-            # half-size, ramp-dominated launches.
-            return self._split_loop(net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8)
         flow4, flow_up, flow_predictions = self._loop(net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8, taped, test_mode)
         if test_mode:
             return ops.nhwc_to_nchw(flow4[..., :2]), flow_up
@@ -188,8 +179,9 @@ class RAFT(nn.Module):
         return out["flow4"], out["flow_up"], out["preds"]
 
     def _loop_steps(self, net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8, taped, test_mode, out):
-        """The same as a generator that yields after every iteration (so that _split_loop can issue the iterations of
-        several batch slices alternately, each on its own stream); results land in `out`."""
+        """The same as a generator that yields after every iteration; results land in `out`.  (Two half batches on two streams,
+        the iterations issued alternately, were +2.5-3 % under graph replay in rounds 3 / 4 - and halved the lookup's launches;
+        removed in round 5, docs/history.md.)"""
         cnet = net
         flow_predictions = []
         flow_up = None
@@ -234,38 +226,3 @@ class RAFT(nn.Module):
                 flow_predictions.append(flow_up)
             out.update(flow4=flow4, flow_up=flow_up, preds=flow_predictions)
             yield
-
-    def _split_loop(self, net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8):
-        n = _UPDATE_SPLIT
-        m = b // n
-        main = torch.cuda.current_stream()
-        if not hasattr(self, "_split_streams") or len(self._split_streams) != n:
-            self._split_streams = [torch.cuda.Stream(device=net.device) for _ in range(n)]
-        fork = torch.cuda.Event()
-        fork.record(main)
-        # one generator per slice, advanced in turn: the host feeds every stream an iteration at a time (issuing one
-        # slice's twelve iterations before the next one's only serialises two half-size loops: 408 instead of 518 pairs/s)
-        res, gens = [{} for _ in range(n)], []
-        for k, st in enumerate(self._split_streams):
-            lo, hi = k * m, (k + 1) * m
-            st.wait_event(fork)
-            with torch.cuda.stream(st):
-                pre = None if gru_pre is None else [(z[lo:hi], q[lo:hi]) for z, q in gru_pre]
-                gens.append(self._loop_steps(net[lo:hi], inp[lo:hi], corr_fn.batch_slice(lo, hi), coords1[lo:hi], pre, iters,
-                                             m, h8, w8, False, True, res[k]))
-        for _ in range(iters):
-            for st, g in zip(self._split_streams, gens):
-                with torch.cuda.stream(st):
-                    next(g)
-        outs = []
-        for st, r in zip(self._split_streams, res):
-            with torch.cuda.stream(st):
-                low = ops.nhwc_to_nchw(r["flow4"][..., :2])
-                for t in (low, r["flow_up"]):
-                    t.record_stream(main)
-                join = torch.cuda.Event()
-                join.record(st)
-            outs.append((low, r["flow_up"], join))
-        for _, _, join in outs:
-            main.wait_event(join)
-        return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)

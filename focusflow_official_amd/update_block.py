@@ -17,8 +17,8 @@ from .cce import PackedConv
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 
 
-_SIDE_STREAM = os.environ.get("FF_SIDE_STREAM", "1") != "0"      # measurement switch (BasicMotionEncoder.run)
-_GRU_EPILOGUE = os.environ.get("FF_GRU_EPILOGUE", "1") != "0"    # r*h and the state blend in the conv epilogues (inference); 0: ff_gru_rh / ff_gru_blend launches
+_SIDE_STREAM = True      # the motion encoder's flow branch on a second stream (inference; +0.7-1.2 %, docs/history.md)
+_GRU_EPILOGUE = True    # r*h and the state blend in the conv epilogues (inference); tests switch it off to compare with ff_gru_rh / ff_gru_blend
 # Inference: the activations BETWEEN the convolutions of the update block travel in the split-pair format (ops.SplitT) - the
 # producers' epilogues write what the consumers' loaders would have made of fp32, the consumers take their patches by LDS-DMA
 # (csrc/conv_dma.hip).  Same bits as the fp32 route.  FF_SPLIT_ACT=0: A/B switch back to fp32 tensors and conv_patch.hip.
@@ -32,8 +32,8 @@ _side_streams = {}
 
 
 def _side_stream(device):
-    # one side stream per (device, stream the caller runs on): two update loops on two streams (RAFT._split_loop) must
-    # not funnel their flow branches through one queue
+    # one side stream per (device, stream the caller runs on): two forwards on two streams must not funnel their flow
+    # branches through one queue
     key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)

@@ -56,7 +56,8 @@ def test_conv_params_struct_layout(lib_path):
 def test_stats_parts_hint_is_host_logic(lib_path):
     """ff_conv2d_stats_parts (no GPU work): which convolutions can deliver the InstanceNorm statistics of their output
     from the epilogue, and how many partial entries per (image, channel) the caller must provide - 2 per 8 x 16 (or 4 x 16)
-    output tile of the patch kernel and of the 7x7 stride-2 stem kernel, 0 for everything else."""
+    output tile of the patch kernel and of the 7x7 stride-2 stem kernel, 1 per tile where conv_dma.hip's fp32-input route takes
+    the layer (128 input channels and more), 0 for everything else."""
     from focusflow_official_amd import _hip
     lib = ctypes.CDLL(lib_path)
     lib.ff_conv2d_stats_parts.restype = ctypes.c_int
@@ -76,7 +77,9 @@ def test_stats_parts_hint_is_host_logic(lib_path):
         return lib.ff_conv2d_stats_parts(ctypes.byref(p))
 
     assert parts(64, 64, 3, 1, 16, 192, 256) == 24 * 16 * 2          # 8-row tiles
-    assert parts(128, 128, 3, 1, 1, 46, 62) == 12 * 4 * 2            # few blocks: 4-row tiles, ragged plane
+    assert parts(128, 128, 3, 1, 1, 46, 62) == 12 * 4                # four 32-channel chunks: conv_dma.hip's fp32-input route, ONE entry per 4 x 16 tile (few blocks: 4-row tiles, ragged plane)
+    assert parts(128, 128, 3, 1, 16, 48, 64) == 6 * 4                # ... 8-row tiles
+    assert parts(96, 96, 3, 1, 1, 46, 62) == 12 * 4 * 2              # three chunks: the patch kernel, two entries per tile
     assert parts(4, 64, 7, 2, 16, 384, 512) == 24 * 16 * 2           # the stem: 192 x 256 output
     assert parts(64, 64, 3, 1, 16, 192, 256, fmt=_hip.W_F16) == 24 * 16 * 2
     assert parts(64, 64, 3, 1, 16, 192, 256, fmt=_hip.W_F32) == 0    # exact-fp32 rows: the generic kernel

@@ -1090,21 +1090,6 @@ def test_split_k_convolution_small_plane_long_reduction(cin, cout, h, w, k, res)
     assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
-def test_update_loop_on_batch_slices_opt_in():
-    """FF_UPDATE_SPLIT=2 (read once per process: a child process): the update loop of the two batch halves on two streams,
-    iterations issued alternately (RAFT._split_loop).  The batch-of-eight consistency test and the B = 2 bit-identity
-    test of the lazy up-sampling run through it."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, FF_UPDATE_SPLIT="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__),
-                        "-k", "config1_384x512_and_batch_consistency or skip_unused_upsample_is_bit_identical"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "2 passed" in r.stdout
-
-
 @pytest.mark.gpu
 def test_memory_probe_moves_the_bytes_it_reports():
     """ff_probe_memory_kernel (bench.py's memory-only companion of the lookup): every stored byte comes from the source

@@ -337,40 +337,6 @@ def test_patch_kernel_writes_split_pair_outputs(ops, shape):
     close(nchw(plain), ref, rtol=2e-5, what="conv + folded BatchNorm + residual")
 
 
-@pytest.mark.parametrize("size", [(2, 128, 144), (1, 200, 136)])
-def test_context_encoder_with_and_without_split_activations(det_sd, size, monkeypatch):
-    """The eval-BatchNorm encoder (cnet), opt-in route: residual blocks with split-pair activations between their two
-    convolutions (the second one of every block on conv_dma.hip; with FF_ENC_DUAL=1 also the first one of a stage's second
-    block) against the fp32 route - same values up to the summation order inside a
-    32-channel chunk - and the whole forward against the oracle."""
-    from focusflow_official_amd import cce
-    b, h, w = size
-    inp = [t.to(DEV) for t in orc.shifted_pair(b, h, w, seed=5)]
-    m = _model(det_sd)
-    from focusflow_official_amd import ops as _ops
-    seen = []
-    orig = _ops.conv2d
-
-    def spy(xs, *a, **kw):
-        seen.append(any(isinstance(x, _ops.SplitT) for x in xs))
-        return orig(xs, *a, **kw)
-
-    monkeypatch.setattr(cce, "_ENC_SPLIT", True)          # opt-in (FF_ENC_SPLIT=1): measured neutral end to end, see cce.py
-    with torch.no_grad():
-        monkeypatch.setattr(_ops, "conv2d", spy)
-        lo_s, up_s = m(*inp, raft_iters=2, test_mode=True)
-        n_split_on = sum(seen)
-        seen.clear()
-        monkeypatch.setattr(cce, "_ENC_SPLIT", False)
-        lo_p, up_p = m(*inp, raft_iters=2, test_mode=True)
-        n_split_off = sum(seen)
-        ref_lo, ref_up = orc.ffraft_forward(det_sd, *[t.cpu() for t in inp], raft_iters=2, test_mode=True)
-    assert n_split_on - n_split_off == 12, (n_split_on, n_split_off)        # 2 branches x 3 stages x the second convolution of both blocks
-    close(up_s.cpu(), up_p.cpu(), rtol=0, atol=1e-4, what="context encoder: split-pair activations on vs off")
-    close(up_s.cpu(), ref_up, rtol=0, atol=1e-3, what="split-pair encoder vs oracle")
-    close(lo_s.cpu(), ref_lo, rtol=0, atol=1e-3, what="flow_low vs oracle")
-
-
 def _fusion_ref(v_img, v_mask, wa, ba, wb, bb):
     """parallel_fusion.py:98-150, '1x1conv': img' = img + conv(mask), mask' = mask + conv(img), in fp64 (NCHW in / out)."""
     img, mask = v_img.double(), v_mask.double()
