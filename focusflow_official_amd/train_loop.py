@@ -25,6 +25,16 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 Tensor = torch.Tensor
 
 ENABLED = os.environ.get("FF_TRAIN_LOOP", "1") != "0"      # A/B switch: 0 = the per-operation tape of fn.py
+WCHUNK = int(os.environ.get("FF_TRAIN_WCHUNK", "4"))       # iterations per weight-gradient slab (A/B: 12 = one launch per convolution, at the end)
+WGRAD_SIDE_STREAM = os.environ.get("FF_TRAIN_WGRAD_STREAM", "1") != "0"      # A/B switch: the slabs on a side stream beside the input-gradient chain
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
 
 
 def _convs_of(ub):
@@ -161,6 +171,45 @@ class UpdateLoopFn(torch.autograd.Function):
         dh_valid = False
         st = ops._stream
         p = ops._p
+        # ---- weight gradients: per convolution ONE buffer for all iterations, filled by a few launches over slabs of WCHUNK
+        # iterations (the stacks are ordinary batches of images) that run on a SIDE STREAM beside the input-gradient chain of the
+        # earlier iterations: that chain is eleven dependent launches of ~200 blocks per iteration, the slab contractions are what
+        # fills the rest of the chip meanwhile.  The kernels accumulate with atomics, so the slabs simply add up.
+        hin, hmid, mot = S["hin"][:T * b], S["hmid"], S["motion"]
+        jobs = [(S["corr"], G["c1"], W_C1), (S["c1"], G["c2f2"][..., :192], W_C2), (S["flow4"][:T * b], G["f1"], W_F1),
+                (S["f1"], G["c2f2"][..., 192:], W_F2), (S["c2f2"], G["m"], W_M),
+                ([hin, mot], G["zr"][0], W_ZR1), ([S["rh"][0], mot], G["q"][0], W_Q1), ([hmid, mot], G["zr"][1], W_ZR2),
+                ([S["rh"][1], mot], G["q"][1], W_Q2), (S["hin"][b:], G["hid"], W_HID), (S["hid"][..., :256], G["dflow"], W_FLOW),
+                (S["hid"][..., 256:], G["mask"], W_MASK)]
+        acc = []
+        for pc, (xs, g, wi), want in zip(convs, jobs, want_w):
+            if not want:
+                acc.append(None)
+                continue
+            kdim = pc.kh * pc.kw * sum(x.shape[3] for x in (xs if isinstance(xs, list) else [xs]))
+            z = torch.zeros(pc.cout * kdim + pc.cout, dtype=torch.float32, device=dev)
+            acc.append((z[:pc.cout * kdim].view(pc.cout, kdim), z[pc.cout * kdim:]))
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if WGRAD_SIDE_STREAM else main
+        pending_hi = T                      # iterations [t, pending_hi) have complete gradient stacks and no weight-gradient launch yet
+
+        def wgrad_slab(lo_t, hi_t):
+            """Weight gradients of iterations lo_t .. hi_t - 1 (their G slices are complete on the main stream)."""
+            if hi_t <= lo_t:
+                return
+            if side is not main:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+            with torch.cuda.stream(side):
+                wmax = words[lo_t:hi_t].amax(0, keepdim=True).contiguous() if hi_t - lo_t > 1 else words[lo_t:hi_t]
+                for pc, (xs, g, wi), a_ in zip(convs, jobs, acc):
+                    if a_ is None:
+                        continue
+                    xs = xs if isinstance(xs, list) else [xs]
+                    ops.conv2d_wgrad([x[lo_t * b:hi_t * b] for x in xs], g[lo_t * b:hi_t * b], pc.cout, pc.kh, pc.kw, pc.stride, pc.pad,
+                                     g_amax=wmax[0, wi:wi + 1], want_db=True, dw=a_[0], db=a_[1], dilation=pc.dil)
+
         for t in range(T - 1, -1, -1):
             lo, hi = t * b, (t + 1) * b
             wd = lambda i, t=t: words[t, i:i + 1]                 # noqa: E731
@@ -204,6 +253,9 @@ class UpdateLoopFn(torch.autograd.Function):
             if want_w[2]:        # convf1's input is the flow (no gradient): only its weights need d f1
                 _dgrad(enc._f2, gc2f2[..., 192:], wd(W_F2), 128, d_f1)
                 ops.act_bwd_into(d_f1, S["f1"][lo:hi], ACT_RELU, G["f1"][lo:hi], wd(W_F1))
+            if pending_hi - t >= WCHUNK or t == 0:
+                wgrad_slab(t, pending_hi)
+                pending_hi = t
         # ---- everything below runs once per pass ----
         grads: List[Optional[Tensor]] = [None] * NF
         grads.append(dh if (need[NF] and dh_valid) else None)                      # d net0
@@ -232,27 +284,16 @@ class UpdateLoopFn(torch.autograd.Function):
             grads += [df1 if need[NF + 5] else None, df2 if need[NF + 6] else None]
         else:
             grads += [None, None]
-        # weight gradients: one launch per convolution over all T iterations (the stacks are batches of T * B images)
-        wmax = words.amax(0, keepdim=True).contiguous() if T > 1 else words       # max|g| over the iterations, per gradient stack
-        hin, hmid, mot = S["hin"][:T * b], S["hmid"], S["motion"]
-        jobs = [(S["corr"], G["c1"], W_C1), (S["c1"], G["c2f2"][..., :192], W_C2), (S["flow4"][:T * b], G["f1"], W_F1),
-                (S["f1"], G["c2f2"][..., 192:], W_F2), (S["c2f2"], G["m"], W_M),
-                ([hin, mot], G["zr"][0], W_ZR1), ([S["rh"][0], mot], G["q"][0], W_Q1), ([hmid, mot], G["zr"][1], W_ZR2),
-                ([S["rh"][1], mot], G["q"][1], W_Q2), (S["hin"][b:], G["hid"], W_HID), (S["hid"][..., :256], G["dflow"], W_FLOW),
-                (S["hid"][..., 256:], G["mask"], W_MASK)]
+        # parameter gradients: the slabs' sums, un-packed per convolution group (the side stream joins here)
+        if side is not main:
+            main.wait_stream(side)
         pos = NF + 7
-        for pc, (xs, g, wi), want in zip(convs, jobs, want_w):
+        for pc, a_ in zip(convs, acc):
             n = len(pc.params())
-            if not want or not dh_valid:
+            if a_ is None or not dh_valid:
                 grads += [None] * n
-                pos += n
-                continue
-            xs = xs if isinstance(xs, list) else [xs]
-            kdim = pc.kh * pc.kw * sum(x.shape[3] for x in xs)
-            z = torch.zeros(pc.cout * kdim + pc.cout, dtype=torch.float32, device=dev)
-            dw, db = z[:pc.cout * kdim].view(pc.cout, kdim), z[pc.cout * kdim:]
-            ops.conv2d_wgrad(xs, g, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, g_amax=wmax[0, wi:wi + 1], want_db=True, dw=dw, db=db, dilation=pc.dil)
-            gl = fn.unpack_group(pc, dw, db)
-            grads += [gv if need[pos + i] else None for i, gv in enumerate(gl)]
+            else:
+                gl = fn.unpack_group(pc, a_[0], a_[1])
+                grads += [gv if need[pos + i] else None for i, gv in enumerate(gl)]
             pos += n
         return tuple(grads)
