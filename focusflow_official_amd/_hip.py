@@ -105,6 +105,8 @@ _SIGS = {
     "ff_coords_step": [_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_gru_pass": [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
                     C.c_int, C.c_int, C.c_int, _fp],
+    "ff_gru_pass_rec": [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int,
+                        _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp],
     "ff_fusion_pair_fwd": [C.POINTER(FFFusionPair), _fp],
     "ff_gru_rh": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],
     "ff_gru_blend": [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _ll, C.c_int, _fp],

@@ -54,6 +54,7 @@ struct GArgs {
     const float* bq;                   // [128]
     float* y;  int y_ld;               // new state fp32
     float* y2; int y2_ld;              // new state split-pair
+    float* sv_z; float* sv_r; float* sv_q; int sv_ld;      // nullable (recorded passes): the gates on the tile's pixels, fp32 [..][128] each - what the backward differentiates through
     int B, H, W, tiles_x, tiles_y;
     unsigned long long* stamps;        // lab build only (FF_LAB): five s_memrealtime stamps per block
 };
@@ -298,8 +299,11 @@ __global__ __launch_bounds__(512) void gru_pass_kernel(const GArgs a) {
         for (int j = 0; j < NR; ++j) {
             f32x4 t = ar[j] * xinv + br;
             const f32x4 pv = rin[j] ? pr[j] : zero4, hv = rin[j] ? hh[j] : zero4;
+            f32x4 rv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = __fmul_rn(ff::fast_sigmoid(t[r] + pv[r]), hv[r]);
+            for (int r = 0; r < 4; ++r) { rv[r] = ff::fast_sigmoid(t[r] + pv[r]); t[r] = __fmul_rn(rv[r], hv[r]); }
+            if (a.sv_r && j >= ZOFF && j - ZOFF < TH && j < NREG && rin[j])      // r tile u + ZOFF sits on the output tile's row u (the same pixels as z and q)
+                *reinterpret_cast<f32x4*>(a.sv_r + (((long long)bimg * H + (ry0 + rrow[j])) * W + (rx0 + rcol[j])) * a.sv_ld + cw) = rv;
             if (!live[j]) continue;
             ff::ff_f16x4 h0, h1;
             ff::split_pair4(t, h0, h1);
@@ -380,14 +384,19 @@ __global__ __launch_bounds__(512) void gru_pass_kernel(const GArgs a) {
             const int y = y0 + u, x = x0 + pcol;
             if (!(y < H && x < W)) continue;
             const long long po = ((long long)bimg * H + y) * W + x;
-            f32x4 t = aq[u] * xinv + bq;
+            f32x4 t = aq[u] * xinv + bq, qv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float q = ff::fast_tanh(t[r] + pq[u][r]);
+                qv[r] = q;
                 t[r] = __fadd_rn(__fmul_rn(__fsub_rn(1.f, az[u][r]), hout[u][r]), __fmul_rn(az[u][r], q));
             }
             *reinterpret_cast<f32x4*>(a.y + po * a.y_ld + cw) = t;
             ff::store_split4(a.y2 + po * a.y2_ld, cw, t);
+            if (a.sv_z) {
+                *reinterpret_cast<f32x4*>(a.sv_z + po * a.sv_ld + cw) = az[u];
+                *reinterpret_cast<f32x4*>(a.sv_q + po * a.sv_ld + cw) = qv;
+            }
         }
     }
 #ifdef FF_LAB
@@ -401,11 +410,8 @@ int launch(const GArgs& a, hipStream_t s) {
     constexpr int PW = DIR == 0 ? 24 : 16, PH = DIR == 0 ? TH : TH + 8, RW = DIR == 0 ? 20 : 16, RH = DIR == 0 ? TH : TH + 4;
     constexpr int PBYTES = ((PH * PW + 7) / 8) * 1024, RPLANE = ((RH * RW + 7) / 8) * 1024;
     constexpr size_t lds = 2 * PBYTES + 4 * RPLANE;
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_pass_kernel<DIR, TH, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
-    }
+    // (per launch: the attribute is per device, and a process may drive several)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_pass_kernel<DIR, TH, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x;
     gru_pass_kernel<DIR, TH, TERMS><<<(unsigned)blocks, 512, lds, s>>>(a);
     return ff::check_launch("ff_gru_pass");
@@ -417,10 +423,10 @@ int launch(const GArgs& a, hipStream_t s) {
 extern "C" int ff_lab_gru_pass_stamps(void* buf) { g_stamps = static_cast<unsigned long long*>(buf); return 0; }      // lab build only
 #endif
 
-extern "C" int ff_gru_pass(int dir, const float* hs, int hs_ld, const float* motion, int mo_ld, const float* h, int h_ld,
-                           const float* zr_pre, int zr_pre_ld, const float* q_pre, int q_pre_ld, const void* wzr_frag, const void* wq_frag,
-                           const float* bzr, const float* bq, int w_format, float* y, int y_ld, float* y2, int y2_ld, int B, int H, int W,
-                           void* stream) {
+static int gru_pass_impl(int dir, const float* hs, int hs_ld, const float* motion, int mo_ld, const float* h, int h_ld,
+                         const float* zr_pre, int zr_pre_ld, const float* q_pre, int q_pre_ld, const void* wzr_frag, const void* wq_frag,
+                         const float* bzr, const float* bq, int w_format, float* y, int y_ld, float* y2, int y2_ld, float* sv_z, float* sv_r,
+                         float* sv_q, int sv_ld, int B, int H, int W, void* stream) {
     FF_REQUIRE(hs && motion && h && zr_pre && q_pre && wzr_frag && wq_frag && bzr && bq && y && y2, "ff_gru_pass: null pointer");
     FF_REQUIRE(dir == 0 || dir == 1, "ff_gru_pass: dir 0 (1x5) or 1 (5x1)");
     FF_REQUIRE(w_format == FF_W_F16X3 || w_format == FF_W_F16, "ff_gru_pass: a split weight format");
@@ -435,6 +441,9 @@ extern "C" int ff_gru_pass(int dir, const float* hs, int hs_ld, const float* mot
     a.hs = hs; a.hs_ld = hs_ld; a.mo = motion; a.mo_ld = mo_ld; a.h = h; a.h_ld = h_ld;
     a.zr_pre = zr_pre; a.zr_pre_ld = zr_pre_ld; a.q_pre = q_pre; a.q_pre_ld = q_pre_ld;
     a.wzr = wzr_frag; a.wq = wq_frag; a.bzr = bzr; a.bq = bq; a.y = y; a.y_ld = y_ld; a.y2 = y2; a.y2_ld = y2_ld;
+    FF_REQUIRE((sv_z != nullptr) == (sv_r != nullptr) && (sv_z != nullptr) == (sv_q != nullptr), "ff_gru_pass_rec: the three gate outputs come together");
+    FF_REQUIRE(!sv_z || (sv_ld % 4 == 0 && sv_ld >= 128 && ff::aligned16(sv_z) && ff::aligned16(sv_r) && ff::aligned16(sv_q)), "ff_gru_pass_rec: gate outputs: ld % 4, >= 128, 16-byte aligned");
+    a.sv_z = sv_z; a.sv_r = sv_r; a.sv_q = sv_q; a.sv_ld = sv_ld;
     a.B = B; a.H = H; a.W = W;
 #ifdef FF_LAB
     a.stamps = g_stamps;
@@ -444,13 +453,32 @@ extern "C" int ff_gru_pass(int dir, const float* hs, int hs_ld, const float* mot
     a.tiles_x = (W + 15) / 16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool t3 = w_format == FF_W_F16X3;
-    // tile height: 6 rows where that divides the plane (48 / 6 x 64 / 16 x 8 pairs = 256 blocks: one per CU), else 4
-    // (8-row tiles need more than 256 registers in the vertical pass).  FF_GRU_PASS_TH overrides (tuning, tests).
-    int th = H % 6 == 0 ? 6 : 4;
+    // tile height 6 or 4 (8-row tiles need more than 256 registers in the vertical pass): one block per CU, so a launch costs
+    // rounds of 256 blocks x (rows per tile + the fixed part of a block, ~2 rows' worth) - 48 / 6 x 64 / 16 x 8 pairs = 256 blocks
+    // = one round; the training crop's 46 rows take 6-row tiles too (8 x 8 x 4 = 256 blocks, the last tile row ragged) rather
+    // than 4-row ones (384 blocks: two rounds).  FF_GRU_PASS_TH overrides (tests walk both).
+    auto cost = [&](int t) { return (((long long)B * ((H + t - 1) / t) * a.tiles_x + 255) / 256) * (t + 2); };
+    int th = cost(6) <= cost(4) ? 6 : 4;
     if (const char* e = getenv("FF_GRU_PASS_TH")) th = atoi(e);
     a.tiles_y = (H + th - 1) / th;
 #define FF_GP(D_, T_) if (dir == D_ && th == T_) return t3 ? launch<D_, T_, 3>(a, s) : launch<D_, T_, 1>(a, s);
     FF_GP(0, 6) FF_GP(1, 6) FF_GP(0, 4) FF_GP(1, 4)
 #undef FF_GP
     return ff::fail(FF_EINVAL, "ff_gru_pass: tile height %d (4 or 6)", th);
+}
+
+extern "C" int ff_gru_pass(int dir, const float* hs, int hs_ld, const float* motion, int mo_ld, const float* h, int h_ld,
+                           const float* zr_pre, int zr_pre_ld, const float* q_pre, int q_pre_ld, const void* wzr_frag, const void* wq_frag,
+                           const float* bzr, const float* bq, int w_format, float* y, int y_ld, float* y2, int y2_ld, int B, int H, int W,
+                           void* stream) {
+    return gru_pass_impl(dir, hs, hs_ld, motion, mo_ld, h, h_ld, zr_pre, zr_pre_ld, q_pre, q_pre_ld, wzr_frag, wq_frag, bzr, bq, w_format, y, y_ld,
+                         y2, y2_ld, nullptr, nullptr, nullptr, 0, B, H, W, stream);
+}
+
+extern "C" int ff_gru_pass_rec(int dir, const float* hs, int hs_ld, const float* motion, int mo_ld, const float* h, int h_ld,
+                               const float* zr_pre, int zr_pre_ld, const float* q_pre, int q_pre_ld, const void* wzr_frag, const void* wq_frag,
+                               const float* bzr, const float* bq, int w_format, float* y, int y_ld, float* y2, int y2_ld, float* z, float* r,
+                               float* q, int gate_ld, int B, int H, int W, void* stream) {
+    return gru_pass_impl(dir, hs, hs_ld, motion, mo_ld, h, h_ld, zr_pre, zr_pre_ld, q_pre, q_pre_ld, wzr_frag, wq_frag, bzr, bq, w_format, y, y_ld,
+                         y2, y2_ld, z, r, q, gate_ld, B, H, W, stream);
 }

@@ -877,15 +877,24 @@ def gru_blend(z: Tensor, q: Tensor, h: Tensor, out: Optional[Tensor] = None) -> 
 
 
 def gru_pass(direction: int, hs, motion, h: Tensor, zr_pre: Tensor, q_pre: Tensor, wzr_frag: Tensor, wq_frag: Tensor, bzr: Tensor, bq: Tensor,
-             w_fmt: int):
-    """One SepConvGRU pass as one launch (ff_gru_pass): hs / motion SplitT, h fp32 -> (h' fp32, h' SplitT)."""
+             w_fmt: int, y: Optional[Tensor] = None, y2: Optional[Tensor] = None, gates=None):
+    """One SepConvGRU pass as one launch (ff_gru_pass): hs / motion SplitT, h fp32 -> (h' fp32, h' SplitT).  y / y2: existing
+    outputs; gates = (z, r, q) fp32 (B,H,W,128) tensors of one leading dimension: the recorded form (ff_gru_pass_rec) also
+    stores what the backward differentiates through."""
     b, hh, ww, c = h.shape
     assert c == 128 and hs.shape == h.shape and motion.shape == h.shape and zr_pre.shape == (b, hh, ww, 256) and q_pre.shape == h.shape
-    y, y2 = empty_nhwc(b, hh, ww, c, h), empty_nhwc(b, hh, ww, c, h)
+    y = empty_nhwc(b, hh, ww, c, h) if y is None else y
+    y2 = empty_nhwc(b, hh, ww, c, h) if y2 is None else y2
+    note = (2.0 * b * hh * ww * 384 * 384 * 5, w_fmt)
     # (timed with the convolutions in bench.py's roofline_conv: it IS two of them - 384 -> 256 and 384 -> 128, five taps)
-    _timed_call("conv", "ff_gru_pass", direction, _p(hs.t), _ld(hs.t), _p(motion.t), _ld(motion.t), _p(h), _ld(h), _p(zr_pre), _ld(zr_pre), _p(q_pre), _ld(q_pre),
-                _p(wzr_frag), _p(wq_frag), _p(bzr), _p(bq), w_fmt, _p(y), _ld(y), _p(y2), _ld(y2), b, hh, ww, _stream(),
-                note=(2.0 * b * hh * ww * 384 * 384 * 5, w_fmt))
+    if gates is None:
+        _timed_call("conv", "ff_gru_pass", direction, _p(hs.t), _ld(hs.t), _p(motion.t), _ld(motion.t), _p(h), _ld(h), _p(zr_pre), _ld(zr_pre), _p(q_pre), _ld(q_pre),
+                    _p(wzr_frag), _p(wq_frag), _p(bzr), _p(bq), w_fmt, _p(y), _ld(y), _p(y2), _ld(y2), b, hh, ww, _stream(), note=note)
+    else:
+        z, r, q = gates
+        assert z.shape == r.shape == q.shape == h.shape and _ld(z) == _ld(r) == _ld(q)
+        _timed_call("conv", "ff_gru_pass_rec", direction, _p(hs.t), _ld(hs.t), _p(motion.t), _ld(motion.t), _p(h), _ld(h), _p(zr_pre), _ld(zr_pre), _p(q_pre), _ld(q_pre),
+                    _p(wzr_frag), _p(wq_frag), _p(bzr), _p(bq), w_fmt, _p(y), _ld(y), _p(y2), _ld(y2), _p(z), _p(r), _p(q), _ld(z), b, hh, ww, _stream(), note=note)
     return y, SplitT(y2)
 
 

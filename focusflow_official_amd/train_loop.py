@@ -25,6 +25,9 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 Tensor = torch.Tensor
 
 ENABLED = os.environ.get("FF_TRAIN_LOOP", "1") != "0"      # A/B switch: 0 = the per-operation tape of fn.py
+# A/B switch: the recorded forward on the inference kernels (split-pair activations, conv_dma.hip, one launch per SepConvGRU pass with
+# the gates stored for the backward, mask convolution + up-sampling as one kernel); 0 = conv by conv on fp32 tensors
+FUSED_FWD = os.environ.get("FF_TRAIN_FUSED_FWD", "1") != "0"
 WCHUNK = int(os.environ.get("FF_TRAIN_WCHUNK", "4"))       # iterations per weight-gradient slab (A/B: 12 = one launch per convolution, at the end)
 WGRAD_SIDE_STREAM = os.environ.get("FF_TRAIN_WGRAD_STREAM", "1") != "0"      # A/B switch: the slabs on a side stream beside the input-gradient chain
 _side_streams = {}
@@ -74,6 +77,72 @@ def _dgrad(pc, g, amax, cin_tot, out, res=None):
                       w_fmt=dfmt, x_amax=amax if dfmt else None, dilation=d, out=out, res=res, w_frag=pc.frag_dgrad())
 
 
+def _forward_fused(ub, corr_fn, coords1, T, net0, pre):
+    """The recorded forward on the INFERENCE kernels (raft.py:218-231 through update_block.BasicUpdateBlock.run's split-pair route):
+    eleven launches per iteration instead of nineteen.  What the backward needs is kept as it is produced - convolution inputs in
+    the split-pair format they travel in (the backward turns the stacks back into fp32 with one pass each: (x0 + x1) / 4, 22
+    significant bits), the GRU's gates z, r, q in fp32 from the recorded form of the pass kernel, the heads' hidden tensor in
+    fp32; r * h and the 576-channel up-sampling mask are never stored (the backward recomputes them for all iterations at once)."""
+    b, h, w, _ = net0.shape
+    dev = net0.device
+    enc, gru = ub.encoder, ub.gru
+
+    def stack(c, n=T, zero=False):
+        return (torch.zeros if zero else torch.empty)((n * b, h, w, c), dtype=torch.float32, device=dev)
+
+    S = dict(fused=True, coords=torch.empty((T, b, h, w, 2), dtype=torch.float32, device=dev),
+             corr=stack(352, zero=True), c1=stack(256), c2f2=stack(256), f1=stack(128), flow4=stack(4, T + 1), motion=stack(128),
+             hin=stack(128, T + 1), hmid=stack(128), z=[stack(128), stack(128)], r=[stack(128), stack(128)], q=[stack(128), stack(128)], hid=stack(512))
+    S["hin"][:b].copy_(net0)
+    hcur = S["hin"][:b]
+    hs = ops.split_copy(hcur)
+    ops.coords_step(coords1, None, S["flow4"][:b], None)                       # flow = coords1 - coords0 (raft.py:219)
+    wf = [(zc.frag(), qc.frag(), zc.get()[1], qc.get()[1], zc.fmt) for zc, qc in zip(gru._zr_hm, gru._q_hm)]
+    outs = []
+    for t in range(T):
+        lo, hi = t * b, (t + 1) * b
+        S["coords"][t].copy_(coords1)
+        corr = S["corr"][lo:hi]
+        ops.corr_lookup_tiled(corr_fn.pyr, S["coords"][t], out=corr[..., :324])
+        c2f2, motion = S["c2f2"][lo:hi], S["motion"][lo:hi]
+        # motion encoder (update.py:89-97): every tensor between its convolutions leaves as a split pair
+        c1 = enc._c1p(corr, act=ACT_RELU, y_split=True, out=S["c1"][lo:hi])
+        cor = enc._c2(c1, act=ACT_RELU, y_split=True, out=c2f2[..., :192])
+        f1 = enc._f1(S["flow4"][lo:hi], act=ACT_RELU, y_split=True, out=S["f1"][lo:hi])
+        flo = enc._f2(f1, act=ACT_RELU, y_split=True, out=c2f2[..., 192:])
+        enc._cv([cor, flo], act=ACT_RELU, out=motion[..., :126], y_split=True, ep_motion_tail=coords1)      # + torch.cat([out, flow]) (update.py:97)
+        mos = ops.SplitT(motion)
+        # SepConvGRU (update.py:45-60): one launch per pass; z, r, q stay for the backward
+        for k in range(2):
+            hnew = S["hmid"][lo:hi] if k == 0 else S["hin"][hi:hi + b]
+            wzr, wq, bzr, bq, fmt = wf[k]
+            hcur, hs = ops.gru_pass(k, hs, mos, hcur, pre[k][0], pre[k][1], wzr, wq, bzr, bq, fmt, y=hnew,
+                                    gates=(S["z"][k][lo:hi], S["r"][k][lo:hi], S["q"][k][lo:hi]))
+        # heads (update.py:121-135): the flow head's last convolution takes the coordinate step, the mask head's the up-sampling
+        hid = ub._heads(hs, act=ACT_RELU, out=S["hid"][lo:hi])
+        ub._flow2(hid[..., :256], ep_coords=(coords1, S["flow4"][hi:hi + b]))
+        outs.append(ub.upsample(hid[..., 256:], S["flow4"][hi:hi + b]))
+    return S, outs
+
+
+def _materialise(ub, S, T, b):
+    """The stacks the backward reads, as fp32 tensors: after the conv-by-conv forward they are there already (plus r * h); after
+    the fused forward the split-pair stacks are turned back (one pass each), r * h = r (.) h and the up-sampling mask
+    0.25 * conv1x1(hidden) are recomputed for ALL iterations at once."""
+    if not S.get("fused"):
+        return S
+    S = dict(S)
+    for k in ("c1", "c2f2", "f1", "motion"):
+        S[k] = ops.split_copy(S[k], to_split=False)
+    hprev = [S["hin"][:T * b], S["hmid"]]
+    S["rh"] = [ops.gru_rh(S["r"][k], hprev[k]) for k in range(2)]
+    up = torch.empty(S["hid"].shape[:3] + (576,), dtype=torch.float32, device=S["hid"].device)
+    _fwd(ub._mask2, S["hid"][..., 256:], up, out_scale=0.25)
+    S["upmask"] = up
+    S["fused"] = False
+    return S
+
+
 class UpdateLoopFn(torch.autograd.Function):
     """(net0, zr_pre1, q_pre1, zr_pre2, q_pre2, fmap1, fmap2, *params) -> the T up-sampled flows.  coords1 is advanced in
     place (never differentiated, raft.py:216/220)."""
@@ -82,7 +151,13 @@ class UpdateLoopFn(torch.autograd.Function):
     def forward(ctx, ub, corr_fn, coords1, iters, net0, zr1, q1, zr2, q2, fmap1, fmap2, *params):
         b, h, w, _ = net0.shape
         T, dev = iters, net0.device
-        tb = T * b
+        ctx.ub, ctx.corr_fn, ctx.T, ctx.geom = ub, corr_fn, T, (b, h, w)
+        ctx.pre_shapes = [tuple(t.shape) for t in (zr1, q1, zr2, q2)]
+        ctx.save_for_backward(fmap1, fmap2)
+        ctx.set_materialize_grads(False)
+        if FUSED_FWD and ops.w_format() == _hip.W_F16X3:
+            ctx.S, outs = _forward_fused(ub, corr_fn, coords1, T, net0, [(zr1, q1), (zr2, q2)])
+            return tuple(outs)
 
         def stack(c, n=T, zero=False):
             return (torch.zeros if zero else torch.empty)((n * b, h, w, c), dtype=torch.float32, device=dev)
@@ -126,16 +201,16 @@ class UpdateLoopFn(torch.autograd.Function):
             _fwd(ub._mask2, hid[..., 256:], S["upmask"][lo:hi], out_scale=0.25)
             ops.coords_step(coords1, delta, S["flow4"][hi:hi + b], None)         # coords1 += delta; the new flow (raft.py:223)
             outs.append(ops.upsample_flow(S["flow4"][hi:hi + b], S["upmask"][lo:hi]))
-        ctx.ub, ctx.corr_fn, ctx.S, ctx.T, ctx.geom = ub, corr_fn, S, T, (b, h, w)
-        ctx.pre_shapes = [tuple(t.shape) for t in (zr1, q1, zr2, q2)]
-        ctx.save_for_backward(fmap1, fmap2)
-        ctx.set_materialize_grads(False)
+        zrs = S.pop("zr")
+        S["z"], S["r"] = [zr[..., :128] for zr in zrs], [zr[..., 128:] for zr in zrs]
+        ctx.S = S
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        ub, S, T = ctx.ub, ctx.S, ctx.T
+        ub, T = ctx.ub, ctx.T
         b, h, w = ctx.geom
+        S = _materialise(ub, ctx.S, T, b)
         fmap1, fmap2 = ctx.saved_tensors
         enc, gru = ub.encoder, ub.gru
         dev = S["hin"].device
@@ -230,13 +305,13 @@ class UpdateLoopFn(torch.autograd.Function):
             later_zc = None
             for k in (1, 0):
                 hprev = S["hin"][lo:hi] if k == 0 else S["hmid"][lo:hi]
-                zr, rh, q = S["zr"][k][lo:hi], S["rh"][k][lo:hi], S["q"][k][lo:hi]
+                zg, rg, q = S["z"][k][lo:hi], S["r"][k][lo:hi], S["q"][k][lo:hi]
                 gzr, gq = G["zr"][k][lo:hi], G["q"][k][lo:hi]
                 wz, wq = (W_ZR2, W_Q2) if k == 1 else (W_ZR1, W_Q1)
                 _hip.call("ff_gru_bwd_blend", p(dh), 128, p(later_zc), 256 if later_zc is not None else 0, p(dm) if later_zc is not None else None, 128,
-                          p(zr), 256, p(q), 128, p(hprev), 128, p(gzr), 256, p(gq), 128, p(dh), 128, p(wd(wz)), p(wd(wq)), npix, 128, st())
+                          p(zg), ops._ld(zg), p(q), 128, p(hprev), 128, p(gzr), 256, p(gq), 128, p(dh), 128, p(wd(wz)), p(wd(wq)), npix, 128, st())
                 _dgrad(gru._q_hm[k], gq, wd(wq), 256, dqc)                      # -> [d (r h) | d motion]
-                _hip.call("ff_gru_bwd_rh", p(dqc), 256, p(zr[..., 128:]), 256, p(hprev), 128, p(gzr[..., 128:]), 256, p(dh), 128, p(dm), 128,
+                _hip.call("ff_gru_bwd_rh", p(dqc), 256, p(rg), ops._ld(rg), p(hprev), 128, p(gzr[..., 128:]), 256, p(dh), 128, p(dm), 128,
                           1 if k == 1 else 0, p(wd(wz)), npix, 128, st())
                 _dgrad(gru._zr_hm[k], gzr, wd(wz), 256, dzc)                    # -> [d h | d motion]
                 later_zc = dzc

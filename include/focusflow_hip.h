@@ -57,7 +57,7 @@ const char* ff_last_error(void);
  *                layers of the update block); + ff_split_copy; FF_EP_MOTION_TAIL
  *   6 (round 4): entry points only: ff_fusion_pair_fwd / ff_fusion_pair_tile (FFFusionPair)
  *   7 (round 5): entry points only: ff_gru_bwd_blend / _rh / _out, ff_sum_stack, ff_upsample_flow_bwd_ex (the recorded
- *                update loop's backward) */
+ *                update loop's backward), ff_gru_pass_rec */
 #define FF_ABI_VERSION 7
 int ff_abi_version(void);
 
@@ -336,6 +336,13 @@ int ff_gru_pass(int dir, const float* hs, int hs_ld, const float* motion, int mo
                 const float* zr_pre, int zr_pre_ld, const float* q_pre, int q_pre_ld, const void* wzr_frag, const void* wq_frag,
                 const float* bzr, const float* bq, int w_format, float* y, int y_ld, float* y2, int y2_ld, int B, int H, int W,
                 void* stream);
+/* The same for RECORDED passes (round 5: the update loop as one autograd node, train_loop.py): the pass also leaves what its
+ * backward differentiates through - z, r and q = tanh(.) on the tile's pixels, fp32 [..][gate_ld >= 128] each (all three or
+ * none) - next to the new state; r * h is their product with the incoming state and is never stored. */
+int ff_gru_pass_rec(int dir, const float* hs, int hs_ld, const float* motion, int mo_ld, const float* h, int h_ld,
+                    const float* zr_pre, int zr_pre_ld, const float* q_pre, int q_pre_ld, const void* wzr_frag, const void* wq_frag,
+                    const float* bzr, const float* bq, int w_format, float* y, int y_ld, float* y2, int y2_ld, float* z, float* r,
+                    float* q, int gate_ld, int B, int H, int W, void* stream);
 /* ------------------------------------------------------------------------
  * One fusion unit of the Condition Control Encoder, type '1x1conv', both directions (parallel_fusion.py:98-150):
  *     y[0] = v0 + conv1x1(v1; w_frag[0]) + bias[0]        (img'  = img  + mask2img(mask))
