@@ -99,14 +99,14 @@ def host_issue_time(step, n=5):
 
 
 def pmc_traffic(queries, pyramid):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r04_lookup_traffic.json, r03_lookup_traffic_fp16.json:
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r05_lookup_traffic.json, r05_lookup_traffic_fp16.json:
     TCC_EA0_RDREQ x 128 B + WRITE_SIZE), scaled per query, and where the number comes from; (None, reason) if the
-    profile is absent.  PMC passes cannot run inside the timed process: the fp32 profile holds the lookup launches of this
-    very command under rocprofv3 --pmc (tools/prof_pmc.sh ... bench.py), the fp16 one the same kernel on the same shape in
-    tools/lookup_lab.cpp (tools/prof_pmc_bin.sh) - NOT a counter read in this run."""
-    name = "r04_lookup_traffic.json" if pyramid == "fp32" else "r03_lookup_traffic_fp16.json"      # (the fp16 instance of the kernel is unchanged since round 3)
+    profile is absent.  PMC passes cannot run inside the timed process: both profiles hold the lookup launches of bench.py
+    itself under rocprofv3 --pmc (tools/prof_pmc.sh ... bench.py: the headline command for fp32, --batch 16 --height 544
+    --width 960 --iters 32 --pyramid fp16 for BASELINE configs[4]) - NOT a counter read in this run."""
+    name = "r05_lookup_traffic.json" if pyramid == "fp32" else "r05_lookup_traffic_fp16.json"
     if not os.path.exists(os.path.join(ROOT, "profiles", name)):
-        name = name.replace("r04_", "r03_")
+        name = "r04_lookup_traffic.json" if pyramid == "fp32" else "r03_lookup_traffic_fp16.json"
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
@@ -446,7 +446,7 @@ def config4_measurements(device):
                 torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
             lk = ops.launch_timing_end(ops.TIME_LOOKUP)
-            q = b * 68 * 120
+            q = b * 68 * 120 * 32 * n // max(1, lk[0])     # (beyond the 4 GB buffer resource the pyramid is looked up in batch chunks: several launches per iteration)
             us = lk[1] / max(1, lk[0])
             out[f"pairs_{b}"] = {"value": round(b / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n, "warmup": 2,
                                  "finite": bool(torch.isfinite(o[1]).all()),
@@ -621,6 +621,8 @@ def secondary_measurements(args, device):
         targs = copy.copy(args)
         targs.batch, targs.height, targs.width, targs.iters = 8, 384, 512, 12      # -> 368 x 496 crops (train_setup)
         step, h, w = train_setup(targs, 1, 0, 0, device)
+        import gc
+        gc.collect()    # (the models of the legs before this one are garbage by now: their packed-weight caches should not be walked by this one's steps)
         nw = 4          # (the caching allocator and the backward's zero arena settle over the first three steps)
         for _ in range(nw):
             step()
@@ -629,10 +631,13 @@ def secondary_measurements(args, device):
         t0 = time.perf_counter()
         for _ in range(n):
             loss = step()
+        t1 = time.perf_counter()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
+        host_ms = (t1 - t0) / n * 1e3
         out["train_step"] = {"metric": f"training frame-pairs/sec FF-RAFT {h}x{w} iters=12 (fwd+MixLoss+bwd+clip+AdamW)",
                              "value": round(8 / dt, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt * 1e3, 2), "steps": n, "warmup": nw,
+                             "host_ms_per_step": round(host_ms, 2),      # time until the host has issued a step (it synchronises once per step, in the loss: losses.py:39-45)
                              "workload": "BASELINE configs[2] shape on ONE GPU: 8 pairs, MixLoss, no DDP", "finite_loss": bool(torch.isfinite(loss))}
         del step
     except Exception as e:          # noqa: BLE001 - reported, never fatal for the headline line

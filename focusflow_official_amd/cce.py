@@ -266,8 +266,18 @@ def prepack(owner: nn.Module, device) -> int:
     if ids is None or ids[0] != sum(1 for _ in owner.parameters()):
         ids = owner.__dict__["_ff_param_ids"] = (sum(1 for _ in owner.parameters()), {id(p) for p in owner.parameters()})
     device = torch.device(device)
+    # the owner's own PackedConvs, found once per (parameter set, PackedConvs ever made): a process with several models
+    # alive (bench.py's parity legs) otherwise pays for scanning and sorting all of theirs on every training step
+    mine = owner.__dict__.get("_ff_packed_mine")
+    if mine is None or mine[0] != (ids[0], _serial[0]):
+        found = sorted((pc for pc in _ALL_PACKED if type(pc) is PackedConv and id(pc.convs[0].weight) in ids[1]),
+                       key=lambda pc: pc._serial)
+        mine = owner.__dict__["_ff_packed_mine"] = ((ids[0], _serial[0]), [weakref.ref(pc) for pc in found])
     todo = []
-    for pc in sorted((pc for pc in _ALL_PACKED if type(pc) is PackedConv and (pc._used_f or pc._used_d)), key=lambda pc: pc._serial):
+    for ref in mine[1]:
+        pc = ref()
+        if pc is None or not (pc._used_f or pc._used_d):
+            continue
         w0 = pc.convs[0].weight
         if id(w0) not in ids[1] or w0.device != device or len(pc.convs) > _hip.PACK_MAX_MEMBERS \
                 or len(pc.cin_slices or ()) > _hip.PACK_MAX_SLICES:

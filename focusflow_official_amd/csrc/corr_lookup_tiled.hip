@@ -424,11 +424,7 @@ extern "C" int ff_corr_lookup_tiled_bwd_all(float* d0, const float* const* coord
     a.dout_ld = dout_ld;
     a.d0 = d0;
     a.queries = queries;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lookup_bwd_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr = true;
-    }
+    FF_ALLOW_DYNAMIC_LDS((&lookup_bwd_all_kernel), 64 * 1024);
     const long long blocks = queries < 256ll * 64 ? queries : 256ll * 64;
     lookup_bwd_all_kernel<<<(unsigned)blocks, LBA_THREADS, lds, static_cast<hipStream_t>(stream)>>>(a);
     return ff::check_launch("ff_corr_lookup_tiled_bwd_all");

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -119,6 +120,20 @@ inline const char* tune_env(const char* name) { return getenv(name); }
 #else
 inline const char* tune_env(const char*) { return nullptr; }
 #endif
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set once per (call site, device), also from several
+// threads (a process-wide `static bool once` left the second device without the opt-in).
+#define FF_ALLOW_DYNAMIC_LDS(kernel_, bytes_)                                                                                   \
+    do {                                                                                                                         \
+        static std::atomic<unsigned long long> ff_done_{0};                                                                      \
+        int ff_dev_ = 0;                                                                                                         \
+        (void)hipGetDevice(&ff_dev_);                                                                                            \
+        const unsigned long long ff_bit_ = 1ull << (ff_dev_ & 63);                                                               \
+        if (!(ff_done_.load(std::memory_order_relaxed) & ff_bit_)) {                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes_)); \
+            ff_done_.fetch_or(ff_bit_, std::memory_order_relaxed);                                                               \
+        }                                                                                                                        \
+    } while (0)
 
 __host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -221,8 +221,13 @@ int launch(const FArgs& a, hipStream_t s) {
     constexpr size_t lds = std::max<size_t>((size_t)2 * NCH * TP * 128, (size_t)TP * (2 * C * 4 + 16));
     static const int per_cu = ff::tune_env("FF_FUSION_BLOCKS_PER_CU") ? std::max(1, atoi(ff::tune_env("FF_FUSION_BLOCKS_PER_CU"))) : 2;
     const unsigned blocks = (unsigned)std::min<long long>(a.tiles, 256ll * per_cu);
-    if (a.p.w_format == FF_W_F16X3) fusion_pair_kernel<C, TP, 3><<<blocks, 256, lds, s>>>(a);
-    else fusion_pair_kernel<C, TP, 1><<<blocks, 256, lds, s>>>(a);
+    if (a.p.w_format == FF_W_F16X3) {
+        FF_ALLOW_DYNAMIC_LDS((&fusion_pair_kernel<C, TP, 3>), (int)lds);
+        fusion_pair_kernel<C, TP, 3><<<blocks, 256, lds, s>>>(a);
+    } else {
+        FF_ALLOW_DYNAMIC_LDS((&fusion_pair_kernel<C, TP, 1>), (int)lds);
+        fusion_pair_kernel<C, TP, 1><<<blocks, 256, lds, s>>>(a);
+    }
     return ff::check_launch("ff_fusion_pair_fwd");
 }
 

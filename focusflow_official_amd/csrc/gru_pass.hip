@@ -410,8 +410,7 @@ int launch(const GArgs& a, hipStream_t s) {
     constexpr int PW = DIR == 0 ? 24 : 16, PH = DIR == 0 ? TH : TH + 8, RW = DIR == 0 ? 20 : 16, RH = DIR == 0 ? TH : TH + 4;
     constexpr int PBYTES = ((PH * PW + 7) / 8) * 1024, RPLANE = ((RH * RW + 7) / 8) * 1024;
     constexpr size_t lds = 2 * PBYTES + 4 * RPLANE;
-    // (per launch: the attribute is per device, and a process may drive several)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_pass_kernel<DIR, TH, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    FF_ALLOW_DYNAMIC_LDS((&gru_pass_kernel<DIR, TH, TERMS>), (int)lds);
     const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x;
     gru_pass_kernel<DIR, TH, TERMS><<<(unsigned)blocks, 512, lds, s>>>(a);
     return ff::check_launch("ff_gru_pass");

@@ -410,25 +410,17 @@ extern "C" int ff_mask_upsample_fwd(const float* hid, int hid_ld, const void* w_
     a.out_scale = out_scale;
     const long long blocks = (a.P + PXB - 1) / PXB;
     FF_REQUIRE(blocks < (1ll << 31), "ff_mask_upsample_fwd: too many pixels");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_upsample_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_upsample_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE);
-        attr = true;
-    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int waves = ff::tune_env("FF_MASK_UPSAMPLE_WAVES") ? atoi(ff::tune_env("FF_MASK_UPSAMPLE_WAVES")) : 12;     // 12 (default) or 6
     if (waves == 12) {
-        static bool attr12 = false;
-        if (!attr12) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_upsample12_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_upsample12_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE);
-            attr12 = true;
-        }
+        if (w_format == FF_W_F16X3) FF_ALLOW_DYNAMIC_LDS((&mask_upsample12_kernel<3>), 3 * STAGE);
+        else FF_ALLOW_DYNAMIC_LDS((&mask_upsample12_kernel<1>), 3 * STAGE);
         if (w_format == FF_W_F16X3) mask_upsample12_kernel<3><<<(unsigned)blocks, NTHR12, 3 * STAGE, s>>>(a);
         else mask_upsample12_kernel<1><<<(unsigned)blocks, NTHR12, 3 * STAGE, s>>>(a);
         return ff::check_launch("ff_mask_upsample_fwd");
     }
+    if (w_format == FF_W_F16X3) FF_ALLOW_DYNAMIC_LDS((&mask_upsample_kernel<3>), 3 * STAGE);
+    else FF_ALLOW_DYNAMIC_LDS((&mask_upsample_kernel<1>), 3 * STAGE);
     if (w_format == FF_W_F16X3) mask_upsample_kernel<3><<<(unsigned)blocks, NTHR, 3 * STAGE, s>>>(a);
     else mask_upsample_kernel<1><<<(unsigned)blocks, NTHR, 3 * STAGE, s>>>(a);
     return ff::check_launch("ff_mask_upsample_fwd");
