@@ -94,6 +94,16 @@ class RAFT(nn.Module):
         # (fewer ragged last waves of blocks) and half the launches
         # Inference: the context encoder (BatchNorm folded: convolutions only) on a second stream beside the feature
         # encoder, whose InstanceNorm statistics / apply passes are memory-bound - the two use different parts of the chip.
+        # recorded passes: the whole update loop is one autograd node (train_loop.UpdateLoopFn); its parameters' gradients leave
+        # through a gate node created HERE, before the encoders, so that its backward runs after theirs (train_loop.LoopParamGate)
+        fused_train = (torch.is_grad_enabled() and train_loop.ENABLED and _GRU_CTX_ONCE and ops.w_format() in (_hip.W_F16X3, _hip.W_F16)
+                       and not test_mode)
+        loop_gate = None
+        if fused_train and train_loop.defer_param_grads():
+            lp = train_loop.loop_params(self.update_block)
+            if all(q is None or q.is_cuda for q in lp) and any(q is not None and q.requires_grad for q in lp):
+                box = {}
+                loop_gate = (box, train_loop.LoopParamGate.apply(box, *lp))
         ops.policy.encoder_streams_ok = b * hh * ww >= _STREAMS_MIN_PIXELS
         two_streams = (_ENC_STREAMS and ops.policy.encoder_streams_ok and not ops.policy.single_stream and (not torch.is_grad_enabled() or train_streams())
                        )      # (also while a hipGraph is being captured: one level of forks is capturable; the branch forks inside each encoder are not - cce._branches)
@@ -113,10 +123,7 @@ class RAFT(nn.Module):
         f12 = self.fnet(ops.cat_batch(image1, image2), ops.cat_batch(mask1, mask2))
         fmap1, fmap2 = f12[:b], f12[b:]
         self.fmap = fmap1
-        # recorded passes: the whole update loop is one autograd node (train_loop.UpdateLoopFn) that takes the feature maps
-        # themselves - the pyramid is then built outside the tape
-        fused_train = (torch.is_grad_enabled() and train_loop.ENABLED and _GRU_CTX_ONCE and ops.w_format() in (_hip.W_F16X3, _hip.W_F16)
-                       and not test_mode)
+        # the fused update-loop node takes the feature maps themselves - the pyramid is then built outside the tape
         if fused_train:
             corr_fn = CorrBlock(fmap1.detach(), fmap2.detach(), radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
         else:
@@ -163,7 +170,10 @@ class RAFT(nn.Module):
             lp = train_loop.loop_params(self.update_block)
             pre = [t for zq in gru_pre for t in zq]
             if fn.recording(net, *pre, fmap1, fmap2, *lp) and train_loop.eligible(self.update_block, corr_fn, net, gru_pre):
-                return list(train_loop.UpdateLoopFn.apply(self.update_block, corr_fn, coords1, iters, net, *pre, fmap1.contiguous(), fmap2.contiguous(), *lp))
+                if loop_gate is not None:
+                    return list(train_loop.UpdateLoopFn.apply(self.update_block, corr_fn, coords1, iters, loop_gate[0], net, *pre,
+                                                              fmap1.contiguous(), fmap2.contiguous(), loop_gate[1]))
+                return list(train_loop.UpdateLoopFn.apply(self.update_block, corr_fn, coords1, iters, None, net, *pre, fmap1.contiguous(), fmap2.contiguous(), *lp))
             if fn.recording(fmap1, fmap2):      # (not eligible after all: the per-operation tape needs the pyramid on the tape)
                 corr_fn = CorrBlock(fmap1, fmap2, radius=self.corr_radius, pyramid_dtype=self.corr_pyramid_dtype)
         flow4, flow_up, flow_predictions = self._loop(net, inp, corr_fn, coords1, gru_pre, iters, b, h8, w8, taped, test_mode)

@@ -33,6 +33,56 @@ WGRAD_SIDE_STREAM = os.environ.get("FF_TRAIN_WGRAD_STREAM", "1") != "0"      # A
 _side_streams = {}
 
 
+# The parameter gradients leave through a node of their own (LoopParamGate) that the model creates BEFORE the encoders run: the
+# autograd engine serves ready nodes latest-created first, so that node's backward - which joins the side stream and un-packs the
+# sums - runs after the encoders' backward has been issued instead of stalling the main stream behind the last slab of weight
+# gradients (a millisecond of an idle main stream per step in the kernel trace).  Single-process training only: under DDP the update
+# block's parameters would then be the LAST gradients to reach their bucket.
+DEFER_PARAM_GRADS = os.environ.get("FF_TRAIN_DEFER_WGRAD", "1") != "0"
+
+
+def defer_param_grads() -> bool:
+    return DEFER_PARAM_GRADS and WGRAD_SIDE_STREAM and not (torch.distributed.is_available() and torch.distributed.is_initialized())
+
+
+def _unpack_param_grads(convs, acc, need_of):
+    """acc[i]: (dw, db) sums of convs[i] or None -> the gradients in the order of loop_params(); need_of(j): parameter j wanted."""
+    grads, pos = [], 0
+    for pc, a_ in zip(convs, acc):
+        n = len(pc.params())
+        if a_ is None:
+            grads += [None] * n
+        else:
+            gl = fn.unpack_group(pc, a_[0], a_[1])
+            grads += [gv if need_of(pos + i) else None for i, gv in enumerate(gl)]
+        pos += n
+    return grads
+
+
+class LoopParamGate(torch.autograd.Function):
+    """(*loop_params) -> a one-element token that UpdateLoopFn takes as an input.  Its backward receives nothing through the
+    token; it picks up what UpdateLoopFn.backward left in `box` (the per-convolution gradient sums and the event behind the last
+    weight-gradient launch), waits for that event and returns the parameters' gradients."""
+
+    @staticmethod
+    def forward(ctx, box, *params):
+        ctx.box = box
+        ctx.set_materialize_grads(False)
+        return params[0].new_empty(1)
+
+    @staticmethod
+    def backward(ctx, _token):
+        job = ctx.box.pop("job", None)
+        n = len(ctx.needs_input_grad) - 1
+        if job is None:
+            return (None,) * (n + 1)
+        convs, acc, ev, _keep = job
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        need = ctx.needs_input_grad
+        return (None, *_unpack_param_grads(convs, acc, lambda j: need[1 + j]))
+
+
 def _side_stream(device):
     key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _side_streams:
@@ -145,13 +195,16 @@ def _materialise(ub, S, T, b):
 
 class UpdateLoopFn(torch.autograd.Function):
     """(net0, zr_pre1, q_pre1, zr_pre2, q_pre2, fmap1, fmap2, *params) -> the T up-sampled flows.  coords1 is advanced in
-    place (never differentiated, raft.py:216/220)."""
+    place (never differentiated, raft.py:216/220).  With a LoopParamGate, `params` is its token alone and `box` the gate's
+    mailbox: the parameter gradients then leave through the gate (see DEFER_PARAM_GRADS)."""
 
     @staticmethod
-    def forward(ctx, ub, corr_fn, coords1, iters, net0, zr1, q1, zr2, q2, fmap1, fmap2, *params):
+    def forward(ctx, ub, corr_fn, coords1, iters, box, net0, zr1, q1, zr2, q2, fmap1, fmap2, *params):
         b, h, w, _ = net0.shape
         T, dev = iters, net0.device
         ctx.ub, ctx.corr_fn, ctx.T, ctx.geom = ub, corr_fn, T, (b, h, w)
+        ctx.box = box
+        ctx.param_need = [q is not None and q.requires_grad for q in loop_params(ub)] if box is not None else None
         ctx.pre_shapes = [tuple(t.shape) for t in (zr1, q1, zr2, q2)]
         ctx.save_for_backward(fmap1, fmap2)
         ctx.set_materialize_grads(False)
@@ -216,13 +269,15 @@ class UpdateLoopFn(torch.autograd.Function):
         dev = S["hin"].device
         npix = b * h * w
         need = ctx.needs_input_grad
-        NF = 4                                           # non-tensor arguments of forward
+        NF = 5                                           # non-tensor arguments of forward
         convs = _convs_of(ub)
+        gated = ctx.box is not None
+        pneed = ctx.param_need if gated else list(need[NF + 7:])
         # which convolutions want parameter gradients (freeze_self: the flow head alone may train)
-        pos, want_w = NF + 7, []
+        pos, want_w = 0, []
         for pc in convs:
             n = len(pc.params())
-            want_w.append(any(need[pos + i] for i in range(n)))
+            want_w.append(any(pneed[pos + i] for i in range(n)))
             pos += n
         partial = any(d is None for d in douts)
         mk = torch.zeros if partial else torch.empty
@@ -359,16 +414,19 @@ class UpdateLoopFn(torch.autograd.Function):
             grads += [df1 if need[NF + 5] else None, df2 if need[NF + 6] else None]
         else:
             grads += [None, None]
-        # parameter gradients: the slabs' sums, un-packed per convolution group (the side stream joins here)
+        # parameter gradients: the slabs' sums, un-packed per convolution group.  Through the gate: left in its mailbox with the
+        # event behind the last slab (the token's own gradient stays None); otherwise the side stream joins here
+        if not dh_valid:
+            acc = [None] * len(acc)
+        if gated:
+            ev = None
+            if side is not main:
+                ev = torch.cuda.Event()
+                ev.record(side)
+            # (the stacks the slabs read were allocated on the main stream: they stay referenced until the gate has waited for the
+            # event, or the allocator would hand their memory to the encoders' backward while the side stream still reads it)
+            ctx.box["job"] = (convs, acc, ev, (S, G, words))
+            return tuple(grads + [None])
         if side is not main:
             main.wait_stream(side)
-        pos = NF + 7
-        for pc, a_ in zip(convs, acc):
-            n = len(pc.params())
-            if a_ is None or not dh_valid:
-                grads += [None] * n
-            else:
-                gl = fn.unpack_group(pc, a_[0], a_[1])
-                grads += [gv if need[pos + i] else None for i, gv in enumerate(gl)]
-            pos += n
-        return tuple(grads)
+        return tuple(grads + _unpack_param_grads(convs, acc, lambda j: pneed[j]))
