@@ -571,9 +571,9 @@ class BasicParallelFusionLayer(nn.Module):
         return nn.Sequential(ResidualBlock(cin, cout, self.norm_fn, stride), ResidualBlock(cout, cout, self.norm_fn, 1))
 
     # -- execution ---------------------------------------------------------
-    def _conv_norm(self, x, pc: PackedConv, norm, act, res=None, lazy=False):
+    def _conv_norm(self, x, pc: PackedConv, norm, act, res=None, lazy=False, take_res=False, defer_res=False):
         """act(norm(conv(x))) and, with `res`, relu(res + that).  lazy (InstanceNorm inference only): -> ops.LazyAct, the
-        normalisation left to the fusion unit that reads it."""
+        normalisation left to the fusion unit that reads it.  take_res / defer_res (recorded passes): fn.res_grad_fused."""
         relu = act == ACT_RELU
         params = [pc.convs[0].weight, pc.convs[0].bias]
         if self.norm_fn == "batch":
@@ -586,32 +586,36 @@ class BasicParallelFusionLayer(nn.Module):
                     return ops.LazyAct(y, st, y.shape[1] * y.shape[2], EPS, act, res)
                 return ops.norm_apply(y, st, True, EPS, act=act, res=res, out=y)
             if ops.CONV_STATS_TRAIN:
-                y, st = fn.conv(pc, x, want_stats=True)
+                y, st = fn.conv(pc, x, want_stats=True, take_res=take_res)
             else:
-                y = fn.conv(pc, x)
+                y = fn.conv(pc, x, take_res=take_res)
                 st = ops.norm_stats(y.detach(), per_sample=True)
-            return fn.NormFn.apply(y, None, None, res, True, False, EPS, relu, st)
+            return fn.NormFn.apply(y, None, None, res, True, False, EPS, relu, st, defer_res)
         if self.norm_fn == "batch":
             if norm.training:
-                y = fn.conv(pc, x)
+                y = fn.conv(pc, x, take_res=take_res and taped)
                 st = ops.norm_stats(y.detach(), per_sample=False)
                 b, h, w, _ = y.shape
                 ops.bn_update_running(norm, st, b * h * w)
                 norm.num_batches_tracked += 1
                 if taped:
-                    return fn.NormFn.apply(y, norm.weight, norm.bias, res, False, False, norm.eps, relu, st)
+                    return fn.NormFn.apply(y, norm.weight, norm.bias, res, False, False, norm.eps, relu, st, defer_res)
                 return ops.norm_apply(y, st, False, norm.eps, norm.weight, norm.bias, act=act, res=res, out=y)
             if taped:  # frozen BatchNorm inside a training step (raft.py:104-107): fixed statistics
-                y = fn.conv(pc, x)
+                y = fn.conv(pc, x, take_res=take_res)
                 n = float(y.shape[0] * y.shape[1] * y.shape[2])
                 rm, rv = norm.running_mean.double(), norm.running_var.double()
                 st = torch.stack([rm * n, (rv + rm * rm) * n], -1)[None].contiguous()
-                return fn.NormFn.apply(y, norm.weight, norm.bias, res, False, True, norm.eps, relu, st)
+                return fn.NormFn.apply(y, norm.weight, norm.bias, res, False, True, norm.eps, relu, st, defer_res)
             sc, sh = ops.bn_fold(norm)  # eval: scale/shift ride in the conv epilogue
             return pc(x, act=act, ch_scale=sc, ch_shift=sh, res=res, act_res=ACT_RELU)
         if taped:
             raise NotImplementedError("norm_fn='none' has no autograd path (unused by the reference configs)")
         return pc(x, act=act, res=res, act_res=ACT_RELU)  # 'none'
+
+    def _block_recorded(self, blk: ResidualBlock, x) -> bool:
+        """Both convolutions of the block and its two norms go through the tape, with x itself differentiated."""
+        return torch.is_grad_enabled() and x.requires_grad and self.norm_fn in ("instance", "batch")
 
     def _block(self, blk: ResidualBlock, x, lazy_out=False):
         p2 = blk._p2
@@ -627,10 +631,14 @@ class BasicParallelFusionLayer(nn.Module):
             if lazy_out:     # the stage's last block: relu(x + relu(norm2(t2))) is evaluated by the fusion unit's loader
                 return ops.LazyAct(t2, st2, t2.shape[1] * t2.shape[2], EPS, ACT_RELU, x)
             return ops.norm_apply(t2, st2, True, EPS, act=ACT_RELU, res=x, out=t2)
-        y = self._conv_norm(x, blk._p1, blk.norm1, ACT_RELU)
+        # recorded passes, plain blocks (the input is the skip connection): the skip's gradient is added inside conv1's
+        # input-gradient launch instead of by an autograd add over two activation-sized tensors
+        fuse = blk.downsample is None and self._block_recorded(blk, x) and fn.res_grad_fused(blk._p1)
+        y = self._conv_norm(x, blk._p1, blk.norm1, ACT_RELU, take_res=fuse)
         if blk.downsample is not None:
             x = self._conv_norm(x, blk._pd, blk.norm3, ACT_NONE)
-        return self._conv_norm(y, blk._p2, blk.norm2, ACT_RELU, res=x, lazy=lazy_out and self.norm_fn == "instance" and not torch.is_grad_enabled())
+        return self._conv_norm(y, blk._p2, blk.norm2, ACT_RELU, res=x, lazy=lazy_out and self.norm_fn == "instance" and not torch.is_grad_enabled(),
+                               defer_res=fuse)
 
     def _run_stage(self, stage, x, lazy_out=False):
         if lazy_out:

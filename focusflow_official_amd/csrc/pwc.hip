@@ -54,9 +54,12 @@ __device__ __forceinline__ void stage_halo(float* s, const float* src, int ld, i
 // order): the coarse pyramid levels are 1-16 tiles with 96-196 channels - one to sixteen blocks walking the channel
 // chunks one after the other on an empty chip (194 us for 7 x 16 pixels).
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void costvolume_fwd_kernel(const CvArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_one[TH * TW * LDP];
-    __shared__ __attribute__((aligned(16))) float s_two[HH * HW * LDP];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void costvolume_fwd_kernel(const CvArgs a) {      // (41 KB of LDS: three blocks per CU)
+    // (the two operand tiles, 40 KB; afterwards the same bytes hold the tile's finished volume [128 pixels][81], 40.5 KB)
+    constexpr int N_ONE = TH * TW * LDP, N_TWO = HH * HW * LDP, N_OUT = TH * TW * 81;
+    __shared__ __attribute__((aligned(16))) float s_all[N_ONE + N_TWO > N_OUT ? N_ONE + N_TWO : N_OUT];
+    float* const s_one = s_all;
+    float* const s_two = s_all + N_ONE;
     const int tiles_x = (a.W + TW - 1) / TW;
     const int b = blockIdx.y, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
@@ -67,42 +70,87 @@ __global__ __launch_bounds__(256) void costvolume_fwd_kernel(const CvArgs a) {
 #pragma unroll
     for (int i = 0; i < 45; ++i) acc[i] = 0.f;
     const int c_beg = SPLIT ? (int)blockIdx.z * a.c_per_split : 0, c_end = SPLIT ? min(a.C, c_beg + a.c_per_split) : a.C;
+    // staging items of this thread (fixed for the launch): 2 float4 of the `one` tile, 6 of the `two` halo; element offset of the
+    // pixel's channel 0, or -1 outside the image
+    const int sg = threadIdx.x & 3;                      // 4-channel group inside a chunk
+    int off1[2], off2[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = (threadIdx.x + 256 * i) >> 2;
+        const int yy = y0 + q / TW, xx = x0 + q % TW;
+        off1[i] = (yy < a.H && xx < a.W) ? ((b * a.H + yy) * a.W + xx) * a.one_ld : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int q = (threadIdx.x + 256 * i) >> 2;
+        const int yy = y0 - R + q / HW, xx = x0 - R + q % HW;
+        off2[i] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? ((b * a.H + yy) * a.W + xx) * a.two_ld : -1;
+    }
     for (int c0 = c_beg; c0 < c_end; c0 += CK) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < TH * TW * (CK / 4); e += 256) {
-            const int g = e % (CK / 4), q = e / (CK / 4);
-            const int yy = y0 + q / TW, xx = x0 + q % TW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (yy < a.H && xx < a.W && c0 + g * 4 < a.C)
-                v = *reinterpret_cast<const f32x4*>(a.one + (((long long)b * a.H + yy) * a.W + xx) * a.one_ld + c0 + g * 4);
-            *reinterpret_cast<f32x4*>(s_one + q * LDP + g * 4) = v;
+        const bool cok = c0 + sg * 4 < a.C;
+        f32x4 v1[2], v2[6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (off1[i] >= 0 && cok) v1[i] = *reinterpret_cast<const f32x4*>(a.one + off1[i] + c0 + sg * 4);
         }
-        stage_halo(s_two, a.two, a.two_ld, b, y0, x0, c0, a.H, a.W, a.C);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            v2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (off2[i] >= 0 && cok) v2[i] = *reinterpret_cast<const f32x4*>(a.two + off2[i] + c0 + sg * 4);
+        }
         __syncthreads();
 #pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(s_one + ((threadIdx.x + 256 * i) >> 2) * LDP + sg * 4) = v1[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(s_two + ((threadIdx.x + 256 * i) >> 2) * LDP + sg * 4) = v2[i];
+        __syncthreads();
+        // (one displacement row at a time: left to itself the compiler hoists all 180 fragment reads of a chunk above the
+        // arithmetic - 256 registers, 700 bytes of scratch per lane, one wave per SIMD: the kernel ran 7 x slower than its
+        // LDS traffic allows; the asm statements keep the reads of a row behind the arithmetic of the row before)
+#pragma unroll 1
         for (int g = 0; g < CK / 4; ++g) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(s_one + px * LDP + g * 4);
 #pragma unroll
             for (int ip = 0; ip < 5; ++ip) {
                 if (ip < np) {
                     const float* row = s_two + ((ly + R + p_lo + ip) * HW + lx) * LDP + g * 4;
+                    f32x4 bv[9];
 #pragma unroll
-                    for (int io = 0; io < 9; ++io) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(row + io * LDP);
-                        acc[ip * 9 + io] += av[0] * bv[0] + av[1] * bv[1] + av[2] * bv[2] + av[3] * bv[3];
-                    }
+                    for (int io = 0; io < 9; ++io) bv[io] = *reinterpret_cast<const f32x4*>(row + io * LDP);
+#pragma unroll
+                    for (int io = 0; io < 9; ++io)
+                        acc[ip * 9 + io] += av[0] * bv[io][0] + av[1] * bv[io][1] + av[2] * bv[io][2] + av[3] * bv[io][3];
                 }
+                // (ordered after this row's arithmetic through the accumulators, and no memory access crosses it)
+                asm volatile("" : "+v"(acc[ip * 9]), "+v"(acc[ip * 9 + 1]), "+v"(acc[ip * 9 + 2]), "+v"(acc[ip * 9 + 3]), "+v"(acc[ip * 9 + 4]),
+                             "+v"(acc[ip * 9 + 5]), "+v"(acc[ip * 9 + 6]), "+v"(acc[ip * 9 + 7]), "+v"(acc[ip * 9 + 8]) :: "memory");
             }
         }
     }
-    const int y = y0 + ly, x = x0 + lx;
-    if (y < a.H && x < a.W) {
-        const long long pix = ((long long)b * a.H + y) * a.W + x;
-        float* o = SPLIT ? a.ws + ((long long)blockIdx.z * a.B * a.H * a.W + pix) * 81 + (p_lo + 4) * 9
-                         : a.out + pix * a.out_ld + (p_lo + 4) * 9;
+    // A lane owns a pixel, and a pixel's 81 values are 324 consecutive bytes: stored from the accumulators, every store
+    // instruction wrote 64 single words into 64 different rows (the kernel spent most of its time there: 357 us for the 133 MB of
+    // the finest level).  The tile's volume goes through LDS instead (pitch 81 words: odd, the 64 pixels of a wave hit 64 banks)
+    // and leaves in element order - a wave instruction writes 256 consecutive bytes of one or two pixel rows.
+    __syncthreads();
+    {
+        float* so = s_all + px * 81 + (p_lo + 4) * 9;
 #pragma unroll
-        for (int i = 0; i < 45; ++i)
-            if (i < np * 9) o[i] = SPLIT ? acc[i] * a.inv_c : ff::apply_act(acc[i] * a.inv_c, a.act);
+        for (int i = 0; i < 36; ++i) so[i] = acc[i] * a.inv_c;
+        if (np == 5) {
+#pragma unroll
+            for (int i = 36; i < 45; ++i) so[i] = acc[i] * a.inv_c;
+        }
+    }
+    __syncthreads();
+    float* const dst = SPLIT ? a.ws + (long long)blockIdx.z * a.B * a.H * a.W * 81 : a.out;
+    const int dld = SPLIT ? 81 : a.out_ld;
+    const int act = SPLIT ? FF_ACT_NONE : a.act;
+#pragma unroll 2
+    for (int e = threadIdx.x; e < N_OUT; e += 256) {
+        const int q = e / 81, d = e - q * 81;
+        const int y = y0 + q / TW, x = x0 + q % TW;
+        if (y < a.H && x < a.W) dst[(((long long)b * a.H + y) * a.W + x) * dld + d] = ff::apply_act(s_all[e], act);
     }
 }
 
@@ -138,6 +186,7 @@ __global__ __launch_bounds__(256) void costvolume_bwd_kernel(const CvArgs a) {  
         stage_halo(s_two, a.two, a.two_ld, b, y0, x0, c0, a.H, a.W, a.C);
         __syncthreads();
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1      // (unrolled, the 243 LDS reads of a chunk are hoisted above the arithmetic: 256 registers + 364 bytes of scratch per lane)
         for (int ip = 0; ip < 9; ++ip) {
             const float* row = s_two + ((ly + ip) * HW + lx) * LDP + hc * 8;
 #pragma unroll
@@ -287,6 +336,7 @@ extern "C" int ff_pwc_costvolume_fwd_ex(const float* one, int one_ld, const floa
     if (int rc = check_cv("ff_pwc_costvolume_fwd", one, one_ld, two, two_ld, out, out_ld, B, H, W, C, C, 81)) return rc;
     FF_REQUIRE(one_ld % 4 == 0 && two_ld % 4 == 0 && ff::aligned16(one) && ff::aligned16(two), "ff_pwc_costvolume_fwd: alignment");
     FF_REQUIRE(splits <= 1 || ws, "ff_pwc_costvolume_fwd_ex: splits need a workspace");
+    FF_REQUIRE((long long)B * H * W * std::max(one_ld, two_ld) < (1ll << 31), "ff_pwc_costvolume_fwd: tensor beyond 2^31 elements");
     CvArgs a{one, one_ld, two, two_ld, out, out_ld, B, H, W, C, 1.f / (float)C, act, ws, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int tiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);

@@ -50,6 +50,10 @@ class GraphScope:
         # An entry counts only while its tensor is ALIVE at that address: a gradient nobody consumed (the norm of a frozen
         # branch whose conv takes no hint) may be freed and its address handed to another gradient of the same shape.
         self.amax_hint = {}
+        # (data_ptr, numel) of a residual block's input -> the gradient of its skip connection: left by the block's last norm
+        # (NormFn.backward, defer_res), added by the block's FIRST convolution inside its input-gradient launch (ConvFn.backward,
+        # take_res: the epilogue's residual operand) - instead of autograd's own add over two full-size tensors
+        self.res_grads = {}
         if device is not None and torch.device(device).type == "cuda":
             self._refill(device)       # on the stream that opens the pass (the main stream), before any side stream exists
 
@@ -182,6 +186,14 @@ _UNPACK_GROUP = True     # one gradient-unpacking launch per packed convolution 
 _LOOKUP_BWD_ALL = True   # one lookup-backward launch per pass instead of one per iteration
 _ZERO_ARENA = True       # one zero fill per pass for the backward's accumulation buffers
 _AMAX_HINT = True        # the norm backward measures max|dx| for the conv it feeds
+_RES_GRAD_FUSED = os.environ.get("FF_TRAIN_RES_GRAD", "1") != "0"      # A/B switch: a residual block's skip gradient added inside its first convolution's input-gradient launch
+
+
+def res_grad_fused(pc) -> bool:
+    """Whether a residual block that opens with convolution `pc` (stride 1: its input IS the skip connection) hands the skip
+    connection's gradient to that convolution's input-gradient launch in this pass: conv(..., take_res=True) and
+    NormFn(..., defer_res=True) must be given the same answer."""
+    return _RES_GRAD_FUSED and _scope is not None and pc.stride == 1
 
 
 def begin_graph(device=None) -> GraphScope:
@@ -196,7 +208,7 @@ def end_graph():
     _scope = None
 
 
-NFIX = 9   # non-tensor arguments of ConvFn.forward
+NFIX = 10  # non-tensor arguments of ConvFn.forward
 
 
 class ConvFn(torch.autograd.Function):
@@ -204,8 +216,10 @@ class ConvFn(torch.autograd.Function):
     then follows the sum: the GRU gates over a pre-computed context share).  tensors = xs..., [res], (w_i, b_i)..."""
 
     @staticmethod
-    def forward(ctx, pc, act, out_scale, nseg, has_res, pad_out, fill_tail, scope, stats_out, *tensors):
+    def forward(ctx, pc, act, out_scale, nseg, has_res, pad_out, fill_tail, scope, stats_out, take_res, *tensors):
         xs = list(tensors[:nseg])
+        assert not take_res or (res_grad_fused(pc) and nseg == 1)
+        ctx.take_res = (xs[0].data_ptr(), xs[0].numel()) if take_res else None
         res = tensors[nseg] if has_res else None
         assert not (has_res and act != ACT_NONE and out_scale != 1.0), "residual + activation + out_scale: no such layer"
         w, b = pc.get()
@@ -250,6 +264,7 @@ class ConvFn(torch.autograd.Function):
         # input gradient: forward conv over g with flipped/transposed weights
         need_dx = any(ctx.needs_input_grad[NFIX + i] for i in range(nseg))
         dxs = [None] * nseg
+        skip = ctx.hints.res_grads.pop(ctx.take_res, None) if (ctx.take_res is not None and ctx.hints is not None) else None
         if need_dx:
             wd, dfmt = pc.get_dgrad()
             cin_tot = sum(x.shape[3] for x in xs)
@@ -261,7 +276,8 @@ class ConvFn(torch.autograd.Function):
                 raise NotImplementedError("stride > 2")
             d = pc.dil
             dx = ops.conv2d([gi], wd, None, cin_tot, pc.kh, pc.kw, 1, (d * (pc.kh - 1) - pc.pad[0], d * (pc.kw - 1) - pc.pad[1]),
-                            w_fmt=dfmt, x_amax=amax if dfmt else None, dilation=d, w_frag=pc.frag_dgrad() if pc.stride == 1 else None)
+                            w_fmt=dfmt, x_amax=amax if dfmt else None, dilation=d, w_frag=pc.frag_dgrad() if pc.stride == 1 else None,
+                            res=skip)          # (+ the skip connection's gradient: the block input's total leaves this launch)
             off = 0
             for i, x in enumerate(xs):
                 if ctx.needs_input_grad[NFIX + i]:
@@ -302,10 +318,14 @@ class NormFn(torch.autograd.Function):
     """y = relu?(norm(x)) ; with res: y = relu(y + res).  Instance (per-sample) or batch statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, per_sample, fixed, eps, relu, stats):
+    def forward(ctx, x, gamma, beta, res, per_sample, fixed, eps, relu, stats, defer_res=False):
         y = ops.norm_apply(x, stats, per_sample, eps, gamma, beta, act=ACT_RELU if relu else ACT_NONE, res=res)
         ctx.meta = (per_sample, fixed, eps, relu, res is not None)
         ctx.scope = _scope
+        # defer_res: `res` is the input of the residual block's first convolution (conv(..., take_res=True)), which adds d res
+        # inside its own input-gradient launch
+        assert not defer_res or (res is not None and _scope is not None)
+        ctx.res_key = (res.data_ptr(), res.numel()) if defer_res else None
         ctx.save_for_backward(x, gamma, beta, y if res is not None else None, stats)
         return y
 
@@ -324,7 +344,10 @@ class NormFn(torch.autograd.Function):
             dgamma = bst[0, :, 1].float()
         if beta is not None and ctx.needs_input_grad[2]:
             dbeta = bst[0, :, 0].float()
-        return dx, dgamma, dbeta, dres, None, None, None, None, None
+        if ctx.res_key is not None and dres is not None and ctx.needs_input_grad[3]:
+            scope.res_grads[ctx.res_key] = dres
+            dres = None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
 class ActFn(torch.autograd.Function):
@@ -514,9 +537,10 @@ def recording(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail=None, want_stats=False):
+def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail=None, want_stats=False, take_res=False):
     """Convolution through a PackedConv group.  pad_out: return the channel-padded tensor.  want_stats: -> (y, stats),
-    the per-sample {sum, sum of squares} table of y (ops.conv2d: from the convolution's epilogue where it can)."""
+    the per-sample {sum, sum of squares} table of y (ops.conv2d: from the convolution's epilogue where it can).  take_res: the
+    input is also the skip connection of the residual block this convolution opens (NormFn defer_res)."""
     if not isinstance(xs, (list, tuple)):
         xs = [xs]
     params = pc.params()
@@ -526,7 +550,7 @@ def conv(pc, xs, act=ACT_NONE, res=None, out_scale=1.0, pad_out=False, fill_tail
             scope, params = _scope, _scope.gated(pc, params)
         args = list(xs) + ([res] if res is not None else []) + params
         holder = [] if want_stats else None
-        y = ConvFn.apply(pc, act, out_scale, len(xs), res is not None, pad_out, fill_tail, scope, holder, *args)
+        y = ConvFn.apply(pc, act, out_scale, len(xs), res is not None, pad_out, fill_tail, scope, holder, take_res, *args)
         return (y, holder[0]) if want_stats else y
     if pad_out:
         b, h, w, _ = xs[0].shape

@@ -676,8 +676,18 @@ def _zero_stats(s, c, device):
     return out
 
 
+BATCH_STATS_PER_IMAGE = os.environ.get("FF_BATCH_STATS_PER_IMAGE", "1") != "0"      # A/B switch
+
+
 def norm_stats(x: Tensor, per_sample: bool) -> Tensor:
     b, h, w, c = x.shape
+    if not per_sample and b > 1 and BATCH_STATS_PER_IMAGE:
+        # batch statistics: every block of the pass ends in one fp64 atomic pair per channel, and with ONE row of sums for the whole
+        # batch those chains are B times longer than an InstanceNorm's (8 x 184 x 248 x 64: 75 us, of which the bytes are worth 20 -
+        # tools/norm_lab.py).  Per-image rows + a sum over them costs one small launch more and keeps the chains short.
+        part = _zero_stats(b, c, x.device)
+        _hip.call("ff_norm_stats", _p(x), _ld(x), b, h * w, c, 1, _p(part), _stream())
+        return part.sum(0, keepdim=True)
     stats = _zero_stats(b if per_sample else 1, c, x.device)
     _hip.call("ff_norm_stats", _p(x), _ld(x), b, h * w, c, int(per_sample), _p(stats), _stream())
     return stats
