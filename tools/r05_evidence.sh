@@ -28,6 +28,9 @@ python tools/make_traffic_json.py "$out/bench_pmc" lookup_dma_kernel 24576 2904 
 echo "== counter passes of bench.py at BASELINE configs[4], 16 pairs (lookup traffic, fp16 pyramid)"
 PASSES="4 6 8" bash tools/prof_pmc.sh r05/c4_pmc bench.py --steps 2 --warmup 1 --batch 16 --height 544 --width 960 --iters 32 --pyramid fp16 --no-secondary --no-cpu-baseline > "$out/c4_pmc.log" 2>&1
 python tools/make_traffic_json.py "$out/c4_pmc" lookup_dma_kernel 130560 2104 "$out/lookup_traffic_fp16.json" "the lookup launches of bench.py --steps 2 --warmup 1 --batch 16 --height 544 --width 960 --iters 32 --pyramid fp16 itself (BASELINE configs[4] at 16 pairs), tools/prof_pmc.sh passes 4 6 8 + a kernel-trace pass"
+echo "== FF-PWC leg and kernel trace (8 pairs)"
+python tools/pwc_leg.py > "$out/pwc_leg.txt" 2>&1; tail -6 "$out/pwc_leg.txt"
+bash tools/r05_pwc_trace.sh > "$out/pwc_trace_summary.txt" 2>&1; head -8 "$out/pwc_trace_summary.txt"
 echo "== per-layer table"
 python tools/conv_table.py > "$out/conv_table.txt" 2>&1; head -12 "$out/conv_table.txt"
 fi
@@ -42,6 +45,9 @@ echo "== same-box A/Bs"
 bash tools/r05_ab.sh FF_TRAIN_LOOP "1 0 1 0" train
 bash tools/r05_ab.sh FF_TRAIN_FUSED_FWD "1 0 1 0" train
 bash tools/r05_ab.sh FF_TRAIN_WGRAD_STREAM "1 0 1 0" train
+bash tools/r05_ab.sh FF_TRAIN_DEFER_WGRAD "1 0 1 0" train
+bash tools/r05_ab.sh FF_TRAIN_RES_GRAD "1 0 1 0" train
+bash tools/r05_ab.sh FF_BATCH_STATS_PER_IMAGE "1 0 1 0" train
 bash tools/r05_ab.sh FF_DMA_F32 "1 0 1 0" train
 bash tools/r05_ab.sh FF_DMA_F32 "1 0 1 0" forward
 fi
