@@ -1266,9 +1266,12 @@ def corr_volume_bwd(dvol: Tensor, f1: Tensor, f2: Tensor, tiled: bool = False):
         if qp != q:      # odd plane sizes: the kernels read the contraction index in 16-byte groups -> zero-pad its rows
             dvol = torch.nn.functional.pad(dvol, (0, qp - q))
         f2r = f2.contiguous().view(b, q, c)
-    f2t = torch.zeros((b, c, qp), dtype=torch.float32, device=f1.device)      # [c][j] = f2[j][c]
-    for i in range(b):
-        _hip.call("ff_pack_conv_weight_dgrad", _p(f2r[i]), qn, c, 1, 1, _p(f2t[i]), qp, 0, _stream())
+    if qp == qn:
+        f2t = f2r.transpose(1, 2).contiguous()                                    # [c][j] = f2[j][c]: one launch for the batch
+    else:
+        f2t = torch.zeros((b, c, qp), dtype=torch.float32, device=f1.device)
+        for i in range(b):
+            _hip.call("ff_pack_conv_weight_dgrad", _p(f2r[i]), qn, c, 1, 1, _p(f2t[i]), qp, 0, _stream())
     df1 = grouped_1x1(dvol, f2t, s).view(b, h, w, c)
     df2 = torch.zeros((b, qn, c), dtype=torch.float32, device=f1.device)
     p = FFConvParams()
